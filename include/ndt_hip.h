@@ -1,0 +1,239 @@
+/*
+ * ndt_hip.h -- C-ABI of the MI355X-native NDT scan-matching engine.
+ *
+ * This is the drop-in boundary for the registration path of khalisfadil/slam-sam:
+ * the `pcl::Registration<PointXYZI,PointXYZI>::Ptr registration` member of
+ * RegisterCallback (ref: include/registercallback.hpp:35) which the drivers fill
+ * with a `pclomp::NormalDistributionsTransform` (ref: run/pipeline.cpp:464-481)
+ * and drive with setInputTarget / setInputSource / align / getFinalTransformation
+ * / getResult (ref: run/pipeline.cpp:557-568, run/pipeline_ligo_tc.cpp:529-538).
+ * The C++ adapter include/ndt_hip/ndt_hip.hpp maps those method names onto the
+ * functions below; INTEGRATION.md shows the reference-side binding.
+ *
+ * Conventions (all citations relative to the reference tree):
+ *  - plain C: opaque handle, POD structs, caller-allocated outputs; every call
+ *    returns an ndt_status (0 = ok, < 0 = error) and never throws.  The engine
+ *    needs a gfx950 device: without one every compute entry point fails with
+ *    NDT_ERR_NO_DEVICE -- there is no CPU fallback.
+ *  - matrices are 4x4 float, COLUMN-major (Eigen::Matrix4f layout), source ->
+ *    target frame (ref: run/pipeline.cpp:561,566).
+ *  - the 6-vector pose is [x, y, z, roll, pitch, yaw] with R = Rx*Ry*Rz
+ *    (ref: extern/svn_ndt/include/svn_ndt_impl.hpp:256-260,272-279).
+ *  - score / gradient / Hessian are those of the POSITIVE score that NDT
+ *    maximises, so the Hessian is negative definite near the optimum and callers
+ *    form cov = -(H + 1e-6 I)^-1 (ref: run/pipeline.cpp:594-596).  Hessians are
+ *    6x6 double, row-major (symmetric).
+ *  - a handle is NOT thread-safe; distinct handles are independent (the
+ *    reference uses one engine per thread, ref: run/pipeline.cpp:432,464).
+ *  - the engine never keeps caller pointers after a call returns.
+ */
+#ifndef NDT_HIP_H_
+#define NDT_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NDT_HIP_ABI_VERSION 1
+
+typedef enum ndt_status {
+  NDT_OK = 0,
+  NDT_ERR_INVALID_ARG = -1,
+  NDT_ERR_NO_DEVICE = -2,   /* no usable gfx950 device / HIP runtime failure at init */
+  NDT_ERR_HIP = -3,         /* a HIP call failed; see ndt_last_error() */
+  NDT_ERR_NO_TARGET = -4,   /* align/eval before a target with >= 1 valid voxel */
+  NDT_ERR_NO_SOURCE = -5,
+  NDT_ERR_GRID_OVERFLOW = -6, /* dx*dy*dz > INT32_MAX (ref: voxel_grid_covariance_impl.hpp:108-125) */
+  NDT_ERR_ALLOC = -7,
+  NDT_ERR_COMM = -8,        /* RCCL / shared-memory reduction failure */
+  NDT_ERR_UNSUPPORTED = -9
+} ndt_status;
+
+/* same order as pclomp::NeighborSearchMethod (ref: run/pipeline.cpp:471-480) */
+typedef enum ndt_search_method {
+  NDT_KDTREE = 0,   /* not implemented yet: NDT_ERR_UNSUPPORTED */
+  NDT_DIRECT26 = 1, /* not implemented yet: NDT_ERR_UNSUPPORTED */
+  NDT_DIRECT7 = 2,
+  NDT_DIRECT1 = 3
+} ndt_search_method;
+
+typedef enum ndt_hessian_mode {
+  NDT_HESSIAN_FULL = 0,         /* Magnusson eq. 6.13 (pclomp; svn_ndt_impl.hpp:472-494) */
+  NDT_HESSIAN_GAUSS_NEWTON = 1  /* J^T C^-1 J only (svn default, svn_ndt_impl.hpp:496-499) */
+} ndt_hessian_mode;
+
+typedef enum ndt_cov_mode {
+  NDT_COV_SVN = 0,          /* ss/n - mu mu^T, * n/(n-1)  (voxel_grid_covariance_impl.hpp:287-291) */
+  NDT_COV_PCL_RECALLED = 1  /* upstream PCL form, * (n-1)/n -- recalled, unverifiable offline */
+} ndt_cov_mode;
+
+typedef enum ndt_reduce_mode {
+  NDT_REDUCE_NONE = 0, /* single GPU */
+  NDT_REDUCE_RCCL = 1, /* ncclAllReduce of the 32-double partial over xGMI */
+  NDT_REDUCE_SHM = 2,  /* pinned-host partials summed through POSIX shared memory */
+  NDT_REDUCE_HOOK = 3  /* caller-supplied all-reduce callback */
+} ndt_reduce_mode;
+
+/* Parameter block; mirrors the pclomp / svn_ndt setters the drivers call and
+ * RegisterCallback's JSON fields (ref: include/registercallback.hpp:37-54,
+ * src/registercallback.cpp:24-91). */
+typedef struct ndt_params {
+  float resolution;              /* setResolution; voxel leaf size in metres */
+  double step_size;              /* setStepSize; More-Thuente step_max */
+  double trans_epsilon;          /* setTransformationEpsilon */
+  int max_iterations;            /* setMaximumIterations */
+  double outlier_ratio;          /* setOutlierRatio (0.55) */
+  int search_method;             /* ndt_search_method */
+  int min_points_per_voxel;      /* 6; clamped to >= 3 (voxel_grid_covariance.h:153,176-184) */
+  double eig_inflation_ratio;    /* 0.01 (voxel_grid_covariance.h:154) */
+  int hessian_mode;              /* ndt_hessian_mode */
+  int cov_mode;                  /* ndt_cov_mode */
+  int add_ridge;                 /* H += 1e-6 I after accumulation (svn_ndt_impl.hpp:650-653) */
+  int use_line_search;           /* 1: More-Thuente; 0: fixed step min(|dp|, step_size) */
+  float regularization_scale_factor; /* setRegularizationScaleFactor (run/pipeline_ligo_tc.cpp:293) */
+  int num_threads;               /* setNumThreads; recorded only -- there is no CPU path */
+  int device_id;                 /* HIP device ordinal; -1 = current device */
+} ndt_params;
+
+typedef struct ndt_handle ndt_handle;
+
+/* pclomp::NdtResult + pcl::Registration outputs (ref: run/pipeline.cpp:566-568,594;
+ * include/map.hpp:96-97 for the two timing/iteration statistics). */
+typedef struct ndt_result {
+  float final_transformation[16]; /* getFinalTransformation(), column-major */
+  double final_pose[6];           /* [x,y,z,roll,pitch,yaw] */
+  int converged;                  /* hasConverged() */
+  int iterations;                 /* getFinalNumIteration() / NdtResult::iteration_num */
+  int n_evaluations;              /* derivative evaluations incl. line-search trials */
+  double hessian[36];             /* NdtResult::hessian, row-major */
+  double score;
+  double transform_probability;   /* score / #source points */
+  double nearest_voxel_transformation_likelihood;
+  int64_t n_pairs;                /* (point, voxel) pairs of the last evaluation */
+  int64_t n_points_with_neighbors;
+  double ms_total;                /* wall time of ndt_align */
+  double ms_device;               /* sum of device-side evaluation time (HIP events) */
+} ndt_result;
+
+/* Per-voxel statistics, the accessors extractNdtData() uses
+ * (ref: include/pipeline.hpp:175-206; Leaf: voxel_grid_covariance.h:99-131). */
+typedef struct ndt_leaf {
+  int64_t index;     /* 1-D voxel index ijk0 + ijk1*div_x + ijk2*div_x*div_y */
+  int32_t point_count;
+  float center[3];   /* getLeafCenter(index) */
+  double mean[3];
+  double cov[9];     /* row-major */
+  double icov[9];
+  double evecs[9];   /* eigenvectors as columns, eigenvalues ascending */
+  double evals[3];
+} ndt_leaf;
+
+typedef struct ndt_grid_info {
+  int min_b[3], max_b[3], div_b[3];
+  float leaf_size, inverse_leaf_size;
+  int64_t n_leaves;        /* valid voxels */
+  int64_t n_cells;         /* dx*dy*dz of the dense index grid */
+  int64_t n_target_points;
+  double ms_build;         /* device time of the last target build */
+} ndt_grid_info;
+
+/* one derivative evaluation: [score, g(6), H upper-tri (21), nvtl_sum,
+ * n_points_with_neighbors, n_pairs, pad] */
+#define NDT_EVAL_WORDS 32
+
+/* ---- lifecycle ---------------------------------------------------------- */
+int ndt_abi_version(void);
+void ndt_default_params(ndt_params* p);
+int ndt_create(const ndt_params* p, ndt_handle** out);   /* new pclomp::NormalDistributionsTransform */
+int ndt_destroy(ndt_handle* h);
+int ndt_set_params(ndt_handle* h, const ndt_params* p);  /* a changed resolution rebuilds the grid */
+int ndt_get_params(const ndt_handle* h, ndt_params* p);
+const char* ndt_last_error(const ndt_handle* h);
+/* human-readable device description; returns the number of visible devices or < 0 */
+int ndt_backend_info(char* buf, size_t cap);
+
+/* ---- clouds ------------------------------------------------------------- */
+/* setInputTarget (ref: run/pipeline.cpp:557): uploads and builds the voxel grid.
+ * xyz points to the first x; consecutive points are stride_bytes apart (12 for
+ * packed xyz, 32 for pcl::PointXYZI, 16 for pcl::PointXYZ). */
+int ndt_set_target(ndt_handle* h, const float* xyz, size_t n, size_t stride_bytes);
+/* SoA host arrays (LidarFrame x/y/z, ref: include/dataframe.hpp:344-346) */
+int ndt_set_target_soa(ndt_handle* h, const float* x, const float* y, const float* z, size_t n);
+/* SoA arrays already resident in device memory (consumed during the call) */
+int ndt_set_target_device(ndt_handle* h, const float* dx, const float* dy, const float* dz, size_t n);
+/* setInputSource (ref: run/pipeline.cpp:558) */
+int ndt_set_source(ndt_handle* h, const float* xyz, size_t n, size_t stride_bytes);
+int ndt_set_source_soa(ndt_handle* h, const float* x, const float* y, const float* z, size_t n);
+int ndt_set_source_device(ndt_handle* h, const float* dx, const float* dy, const float* dz, size_t n);
+
+/* setRegularizationPose (ref: run/pipeline_ligo_tc.cpp:531) */
+int ndt_set_regularization_pose(ndt_handle* h, const float pose_colmajor[16]);
+int ndt_clear_regularization_pose(ndt_handle* h);
+
+/* ---- registration ------------------------------------------------------- */
+/* align(out, guess) / computeTransformation (ref: run/pipeline.cpp:561,
+ * test_svn_ndt.cpp:171).  Blocks until the result is on the host. */
+int ndt_align(ndt_handle* h, const float guess_colmajor[16], ndt_result* out);
+
+/* Derivatives at K poses in one call (computeDerivatives; and Stage 1 of
+ * svn_ndt::align, ref: svn_ndt_impl.hpp:758-781).  poses6: K x 6 doubles.
+ * transforms: optional K x 16 floats (column-major) applied to the source;
+ * NULL = the matrix built from each pose.  out: K x NDT_EVAL_WORDS doubles. */
+int ndt_eval_derivatives(ndt_handle* h, const double* poses6, const float* transforms,
+                         int K, int compute_hessian, double* out);
+/* unpack one evaluation into score, g[6], H[36] (row-major) */
+void ndt_unpack_eval(const double* eval_words, double* score, double* g6, double* H36);
+
+/* output cloud of align(): source transformed by T (device-side), packed xyz */
+int ndt_transform_source(ndt_handle* h, const float T_colmajor[16], float* out_xyz, size_t cap_points);
+
+/* ---- voxel grid accessors ------------------------------------------------ */
+int ndt_get_grid_info(const ndt_handle* h, ndt_grid_info* out);
+/* getTargetCells().getLeaves(): valid leaves sorted by ascending index; returns
+ * the number written (<= cap) or < 0 */
+int64_t ndt_export_leaves(ndt_handle* h, ndt_leaf* out, size_t cap);
+
+/* ---- host Newton driver with an external evaluator ----------------------- */
+/* fn must fill out[NDT_EVAL_WORDS] with the GLOBAL (already reduced) evaluation
+ * at pose6 / T; return 0 on success. */
+typedef int (*ndt_eval_fn)(void* ctx, const double pose6[6], const float T_colmajor[16],
+                           int compute_hessian, double out[NDT_EVAL_WORDS]);
+int ndt_newton_align(const ndt_params* p, int64_t n_source_total,
+                     const float guess_colmajor[16], const float* regularization_pose_or_null,
+                     ndt_eval_fn fn, void* ctx, ndt_result* out);
+
+/* ---- multi-GPU: one process per GPU, source sharded, target replicated ---- */
+/* contiguous shard of n items for rank r of nranks */
+void ndt_shard_range(size_t n, int rank, int nranks, size_t* begin, size_t* count);
+/* rank 0 creates the id (128 bytes) and the caller broadcasts it (e.g. through
+ * torch.distributed); then every rank calls ndt_comm_init_rccl. */
+int ndt_comm_unique_id(void* out128);
+int ndt_comm_init_rccl(ndt_handle* h, const void* id128, int rank, int nranks);
+/* host-side reduction through a POSIX shared-memory segment named `name` */
+int ndt_comm_init_shm(ndt_handle* h, const char* name, int rank, int nranks);
+/* caller-supplied all-reduce(sum) over NDT_EVAL_WORDS doubles, in place */
+typedef int (*ndt_allreduce_fn)(void* ctx, double* words, int n);
+int ndt_comm_init_hook(ndt_handle* h, ndt_allreduce_fn fn, void* ctx, int rank, int nranks);
+int ndt_comm_destroy(ndt_handle* h);
+/* total source points over all ranks (for transform_probability); set by the
+ * caller after sharding, defaults to the local count */
+int ndt_set_global_source_size(ndt_handle* h, int64_t n_total);
+
+/* ---- instrumentation ------------------------------------------------------ */
+typedef struct ndt_timing {
+  double ms_last_eval_kernel;   /* HIP-event time of the last derivative kernel */
+  double ms_last_reduce_kernel;
+  double ms_last_build;
+  int64_t n_eval_launches;      /* since handle creation */
+  double ms_eval_kernel_total;  /* summed HIP-event time of derivative kernels when timing is on */
+} ndt_timing;
+int ndt_enable_kernel_timing(ndt_handle* h, int on);
+int ndt_get_timing(const ndt_handle* h, ndt_timing* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NDT_HIP_H_ */

@@ -1,0 +1,752 @@
+// ndt_api.hip -- the C-ABI of include/ndt_hip.h on top of the HIP kernels.
+//
+// One handle = one engine instance = one HIP stream on one gfx950 device; it
+// owns every device allocation.  There is no CPU path: without a device every
+// compute call fails with NDT_ERR_NO_DEVICE.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/ndt_hip.h"
+#include "ndt_comm.h"
+#include "ndt_kernels.h"
+#include "ndt_newton.h"
+
+using namespace ndt;
+
+namespace {
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = n + n / 8 + 64;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T));
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+template <typename T>
+struct PinBuf {  // pinned, device-mapped host memory
+  T* h = nullptr;
+  T* d = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t n) {
+    if (n <= cap) return hipSuccess;
+    release();
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&h), n * sizeof(T), hipHostMallocMapped);
+    if (e != hipSuccess) { h = nullptr; return e; }
+    e = hipHostGetDevicePointer(reinterpret_cast<void**>(&d), h, 0);
+    if (e != hipSuccess) { (void)hipHostFree(h); h = nullptr; return e; }
+    cap = n;
+    return hipSuccess;
+  }
+  void release() {
+    if (h) (void)hipHostFree(h);
+    h = nullptr; d = nullptr; cap = 0;
+  }
+};
+
+}  // namespace
+
+struct ndt_handle {
+  ndt_params prm;
+  int device = -1;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+  std::string err;
+
+  // target
+  DevBuf<float> tx, ty, tz;          // owned copy when the target came from the host
+  size_t n_tgt = 0;
+  bool have_grid = false;
+  GridGeom geom{};
+  int max_b[3] = {0, 0, 0};
+  DevBuf<int> bounds;                // 8 ints
+  DevBuf<uint32_t> keys, vals, keys2, vals2;
+  DevBuf<char> sort_tmp;
+  DevBuf<int> nleaf;                 // [0] slots, [1] valid
+  DevBuf<int> leaf_start, leaf_cnt;
+  DevBuf<int> cell2leaf;
+  DevBuf<VoxelRecord> rec;
+  DevBuf<LeafStats> stats;
+  int n_slots = 0, n_valid = 0;
+  double ms_build = 0;
+
+  // source
+  DevBuf<float> sx, sy, sz;
+  size_t n_src = 0;
+  int64_t n_src_global = -1;
+
+  // staging
+  PinBuf<float> stage;               // host->device upload staging
+  PinBuf<double> result;             // evaluation results (K * EV_WORDS)
+  PinBuf<int> small;                 // bounds / counters read-back
+  DevBuf<double> partials, dres;
+  DevBuf<PoseConsts> dposes;
+  PinBuf<PoseConsts> hposes;
+
+  bool have_reg = false;
+  float reg_pose[16];
+
+  Reducer red;
+
+  bool timing = false;
+  ndt_timing tm{};
+};
+
+namespace {
+
+int fail(ndt_handle* h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  return code;
+}
+
+#define HIP_TRY(h, expr)                                                                  \
+  do {                                                                                    \
+    hipError_t e__ = (expr);                                                              \
+    if (e__ != hipSuccess)                                                                \
+      return fail(h, (e__ == hipErrorOutOfMemory) ? NDT_ERR_ALLOC : NDT_ERR_HIP,          \
+                  std::string(#expr) + ": " + hipGetErrorString(e__));                    \
+  } while (0)
+
+int bind_device(ndt_handle* h) {
+  HIP_TRY(h, hipSetDevice(h->device));
+  return NDT_OK;
+}
+
+bool params_valid(const ndt_params* p, std::string* why) {
+  if (!(p->resolution > 1e-6f)) { *why = "resolution must be positive"; return false; }
+  if (p->search_method != NDT_DIRECT7 && p->search_method != NDT_DIRECT1) {
+    *why = "search method not implemented (DIRECT7 / DIRECT1 only)";
+    return false;
+  }
+  if (!(p->outlier_ratio >= 0.0 && p->outlier_ratio < 1.0)) { *why = "outlier_ratio must be in [0,1)"; return false; }
+  if (p->max_iterations < 0) { *why = "max_iterations must be >= 0"; return false; }
+  return true;
+}
+
+// host AoS / SoA -> device SoA through the pinned staging buffer
+int upload_soa(ndt_handle* h, const float* xyz, const float* x, const float* y, const float* z,
+               size_t n, size_t stride, DevBuf<float>& dx, DevBuf<float>& dy, DevBuf<float>& dz) {
+  HIP_TRY(h, dx.ensure(n));
+  HIP_TRY(h, dy.ensure(n));
+  HIP_TRY(h, dz.ensure(n));
+  if (n == 0) return NDT_OK;
+  HIP_TRY(h, h->stage.ensure(3 * n));
+  float* s = h->stage.h;
+  if (xyz) {
+    const char* base = reinterpret_cast<const char*>(xyz);
+    for (size_t i = 0; i < n; ++i) {
+      const float* p = reinterpret_cast<const float*>(base + i * stride);
+      s[i] = p[0];
+      s[n + i] = p[1];
+      s[2 * n + i] = p[2];
+    }
+  } else {
+    std::memcpy(s, x, n * sizeof(float));
+    std::memcpy(s + n, y, n * sizeof(float));
+    std::memcpy(s + 2 * n, z, n * sizeof(float));
+  }
+  HIP_TRY(h, hipMemcpyAsync(dx.p, s, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(dy.p, s + n, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(dz.p, s + 2 * n, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));  // staging buffer is reused
+  return NDT_OK;
+}
+
+// the voxel-grid build proper; x/y/z are device pointers
+int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, size_t n) {
+  h->have_grid = false;
+  h->n_tgt = n;
+  h->n_slots = h->n_valid = 0;
+  if (n == 0) return fail(h, NDT_ERR_NO_TARGET, "empty target cloud");
+  if (n > (size_t)std::numeric_limits<int>::max() / 2) return fail(h, NDT_ERR_INVALID_ARG, "target too large");
+  hipStream_t s = h->stream;
+  HIP_TRY(h, h->bounds.ensure(8));
+  HIP_TRY(h, h->small.ensure(16));
+  HIP_TRY(h, hipEventRecord(h->ev0, s));
+  launch_bounds(x, y, z, n, h->bounds.p, s);
+  HIP_TRY(h, hipMemcpyAsync(h->small.h, h->bounds.p, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipStreamSynchronize(s));
+  if (h->small.h[6] == 0) return fail(h, NDT_ERR_NO_TARGET, "target has no finite point");
+
+  // grid geometry in f32, as the reference computes it
+  // (ref: voxel_grid_covariance_impl.hpp:108-140)
+  GridGeom g{};
+  g.leaf = h->prm.resolution;
+  g.inv_leaf = 1.0f / h->prm.resolution;
+  float mn[3], mx[3];
+  for (int a = 0; a < 3; ++a) { mn[a] = decode_ordered(h->small.h[a]); mx[a] = decode_ordered(h->small.h[3 + a]); }
+  int64_t d[3];
+  for (int a = 0; a < 3; ++a) d[a] = (int64_t)((mx[a] - mn[a]) * g.inv_leaf) + 1;
+  const int64_t lim = std::numeric_limits<int32_t>::max();
+  if (d[0] < 0 || d[1] < 0 || d[2] < 0 || d[0] > lim || d[1] > lim || d[2] > lim ||
+      d[0] * d[1] > lim || d[0] * d[1] * d[2] > lim)
+    return fail(h, NDT_ERR_GRID_OVERFLOW, "leaf size too small for the target extent (index overflow)");
+  int64_t ncells = 1;
+  for (int a = 0; a < 3; ++a) {
+    g.min_b[a] = (int)std::floor(mn[a] * g.inv_leaf);
+    h->max_b[a] = (int)std::floor(mx[a] * g.inv_leaf);
+    g.div_b[a] = h->max_b[a] - g.min_b[a] + 1;
+    g.lo[a] = (float)g.min_b[a] * g.leaf;
+    g.hi[a] = (float)(h->max_b[a] + 1) * g.leaf;
+    ncells *= g.div_b[a];
+  }
+  if (ncells >= lim) return fail(h, NDT_ERR_GRID_OVERFLOW, "voxel index grid too large");
+  g.mul1 = g.div_b[0];
+  g.mul2 = g.div_b[0] * g.div_b[1];
+  g.ncells = (int)ncells;
+  h->geom = g;
+
+  const int min_pts = std::max(3, h->prm.min_points_per_voxel);  // ref: voxel_grid_covariance.h:176-184
+  const int max_leaves = (int)(n / (size_t)min_pts) + 1;
+  HIP_TRY(h, h->cell2leaf.ensure((size_t)g.ncells));
+  HIP_TRY(h, h->keys.ensure(n));
+  HIP_TRY(h, h->vals.ensure(n));
+  HIP_TRY(h, h->keys2.ensure(n));
+  HIP_TRY(h, h->vals2.ensure(n));
+  HIP_TRY(h, h->nleaf.ensure(2));
+  HIP_TRY(h, h->leaf_start.ensure((size_t)max_leaves));
+  HIP_TRY(h, h->leaf_cnt.ensure((size_t)max_leaves));
+  HIP_TRY(h, h->rec.ensure((size_t)max_leaves));
+  HIP_TRY(h, h->stats.ensure((size_t)max_leaves));
+  const size_t tmp_bytes = sort_temp_bytes(n);
+  HIP_TRY(h, h->sort_tmp.ensure(tmp_bytes));
+
+  HIP_TRY(h, hipMemsetAsync(h->cell2leaf.p, 0xFF, (size_t)g.ncells * sizeof(int), s));
+  HIP_TRY(h, hipMemsetAsync(h->nleaf.p, 0, 2 * sizeof(int), s));
+  launch_cell_keys(x, y, z, n, g, h->keys.p, h->vals.p, s);
+  int bits = 1;
+  while (bits < 32 && (1ull << bits) <= (unsigned long long)g.ncells) ++bits;  // sentinel = ncells
+  HIP_TRY(h, sort_pairs(h->sort_tmp.p, tmp_bytes, h->keys.p, h->keys2.p, h->vals.p, h->vals2.p, n, bits, s));
+  launch_find_runs(h->keys2.p, n, g.ncells, min_pts, h->nleaf.p, h->leaf_start.p, h->leaf_cnt.p, s);
+  FinalizeParams fp{h->prm.eig_inflation_ratio, h->prm.cov_mode};
+  launch_finalize_leaves(x, y, z, h->keys2.p, h->vals2.p, h->nleaf.p, h->leaf_start.p, h->leaf_cnt.p,
+                         max_leaves, fp, h->rec.p, h->stats.p, h->cell2leaf.p, s);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(h->small.h + 8, h->nleaf.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipEventRecord(h->ev1, s));
+  HIP_TRY(h, hipStreamSynchronize(s));
+  float ms = 0;
+  HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  h->ms_build = ms;
+  h->tm.ms_last_build = ms;
+  h->n_slots = h->small.h[8];
+  h->n_valid = h->small.h[9];
+  h->have_grid = true;
+  return NDT_OK;
+}
+
+void fill_pose_consts(const double p[6], const float T[16], PoseConsts* pc) {
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) pc->R[3 * i + j] = T[4 * j + i];
+    pc->t[i] = T[12 + i];
+  }
+  angle_tables(p, pc->jang, pc->hang);
+}
+
+EvalConsts make_eval_consts(const ndt_handle* h, bool need_h) {
+  EvalConsts ec{};
+  gauss_constants((double)h->prm.resolution, h->prm.outlier_ratio, &ec.d1, &ec.d2);
+  ec.direct7 = h->prm.search_method == NDT_DIRECT7 ? 1 : 0;
+  ec.need_hessian = need_h ? 1 : 0;
+  ec.gauss_newton = h->prm.hessian_mode == NDT_HESSIAN_GAUSS_NEWTON ? 1 : 0;
+  return ec;
+}
+
+int ready_for_eval(ndt_handle* h) {
+  if (!h->have_grid || h->n_valid <= 0) return fail(h, NDT_ERR_NO_TARGET, "no target voxel grid (setInputTarget first)");
+  if (h->n_src == 0 && h->red.mode() == NDT_REDUCE_NONE) return fail(h, NDT_ERR_NO_SOURCE, "no source cloud (setInputSource first)");
+  return NDT_OK;
+}
+
+// one global evaluation at (p, T): local kernel + cross-rank sum
+int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, Eval* out) {
+  hipStream_t s = h->stream;
+  PoseConsts pc;
+  fill_pose_consts(p, T, &pc);
+  const EvalConsts ec = make_eval_consts(h, need_h);
+  const int blocks = derivs_grid_blocks(h->n_src);
+  HIP_TRY(h, h->partials.ensure((size_t)blocks * EV_WORDS));
+  HIP_TRY(h, h->result.ensure(EV_WORDS));
+  const bool dev_out = h->red.wants_device_buffer();
+  if (dev_out) HIP_TRY(h, h->dres.ensure(EV_WORDS));
+  double* d_out = dev_out ? h->dres.p : h->result.d;
+  if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, s));
+  launch_derivatives(h->sx.p, h->sy.p, h->sz.p, h->n_src, h->geom, h->cell2leaf.p, h->rec.p, pc,
+                     nullptr, 1, ec, h->partials.p, d_out, s);
+  if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, s));
+  if (dev_out) {
+    int rc = h->red.allreduce_device(h->dres.p, EV_WORDS, s, &h->err);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->result.h, h->dres.p, EV_WORDS * sizeof(double), hipMemcpyDeviceToHost, s));
+  }
+  HIP_TRY(h, hipStreamSynchronize(s));
+  h->tm.n_eval_launches++;
+  if (h->timing) {
+    float ms = 0;
+    HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->tm.ms_last_eval_kernel = ms;
+    h->tm.ms_eval_kernel_total += ms;
+  }
+  double words[EV_WORDS];
+  std::memcpy(words, h->result.h, sizeof(words));
+  if (!dev_out) {
+    int rc = h->red.allreduce_host(words, EV_WORDS, &h->err);
+    if (rc) return rc;
+  }
+  unpack_eval(words, out);
+  finish_eval(h->prm, h->have_reg ? h->reg_pose : nullptr, p, need_h, out);
+  return NDT_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int ndt_abi_version(void) { return NDT_HIP_ABI_VERSION; }
+
+void ndt_default_params(ndt_params* p) {
+  if (!p) return;
+  std::memset(p, 0, sizeof(*p));
+  p->resolution = 1.0f;
+  p->step_size = 0.1;
+  p->trans_epsilon = 0.1;   // pclomp's constructor default
+  p->max_iterations = 35;
+  p->outlier_ratio = 0.55;
+  p->search_method = NDT_DIRECT7;
+  p->min_points_per_voxel = 6;
+  p->eig_inflation_ratio = 0.01;
+  p->hessian_mode = NDT_HESSIAN_FULL;
+  p->cov_mode = NDT_COV_SVN;
+  p->add_ridge = 0;
+  p->use_line_search = 1;
+  p->regularization_scale_factor = 0.0f;
+  p->num_threads = 1;
+  p->device_id = -1;
+}
+
+int ndt_backend_info(char* buf, size_t cap) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    if (buf && cap) snprintf(buf, cap, "no HIP device (%s)", e == hipSuccess ? "count 0" : hipGetErrorString(e));
+    return e == hipSuccess ? 0 : NDT_ERR_NO_DEVICE;
+  }
+  hipDeviceProp_t prop;
+  if (buf && cap) {
+    if (hipGetDeviceProperties(&prop, 0) == hipSuccess)
+      snprintf(buf, cap, "%d device(s); device 0: %s (%s), %d CUs, %.1f GiB", n, prop.name,
+               prop.gcnArchName, prop.multiProcessorCount, (double)prop.totalGlobalMem / (1 << 30));
+    else
+      snprintf(buf, cap, "%d device(s)", n);
+  }
+  return n;
+}
+
+int ndt_create(const ndt_params* p, ndt_handle** out) {
+  if (!out) return NDT_ERR_INVALID_ARG;
+  *out = nullptr;
+  ndt_params prm;
+  if (p) prm = *p; else ndt_default_params(&prm);
+  std::string why;
+  if (!params_valid(&prm, &why)) return NDT_ERR_INVALID_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return NDT_ERR_NO_DEVICE;
+  int dev = prm.device_id;
+  if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return NDT_ERR_NO_DEVICE;
+  if (dev >= ndev) return NDT_ERR_INVALID_ARG;
+  if (hipSetDevice(dev) != hipSuccess) return NDT_ERR_NO_DEVICE;
+  ndt_handle* h = new ndt_handle();
+  h->prm = prm;
+  h->device = dev;
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
+      hipEventCreate(&h->ev2) != hipSuccess) {
+    delete h;
+    return NDT_ERR_HIP;
+  }
+  *out = h;
+  return NDT_OK;
+}
+
+int ndt_destroy(ndt_handle* h) {
+  if (!h) return NDT_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  h->red.destroy();
+  h->tx.release(); h->ty.release(); h->tz.release();
+  h->bounds.release(); h->keys.release(); h->vals.release(); h->keys2.release(); h->vals2.release();
+  h->sort_tmp.release(); h->nleaf.release(); h->leaf_start.release(); h->leaf_cnt.release();
+  h->cell2leaf.release(); h->rec.release(); h->stats.release();
+  h->sx.release(); h->sy.release(); h->sz.release();
+  h->stage.release(); h->result.release(); h->small.release(); h->partials.release();
+  h->dres.release(); h->dposes.release(); h->hposes.release();
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->ev2) (void)hipEventDestroy(h->ev2);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return NDT_OK;
+}
+
+const char* ndt_last_error(const ndt_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int ndt_get_params(const ndt_handle* h, ndt_params* p) {
+  if (!h || !p) return NDT_ERR_INVALID_ARG;
+  *p = h->prm;
+  return NDT_OK;
+}
+
+int ndt_set_params(ndt_handle* h, const ndt_params* p) {
+  if (!h || !p) return NDT_ERR_INVALID_ARG;
+  std::string why;
+  if (!params_valid(p, &why)) return fail(h, NDT_ERR_INVALID_ARG, why);
+  const bool rebuild = h->have_grid && h->tx.p && h->n_tgt > 0 &&
+                       (std::fabs(p->resolution - h->prm.resolution) > 1e-6f ||
+                        p->min_points_per_voxel != h->prm.min_points_per_voxel ||
+                        p->eig_inflation_ratio != h->prm.eig_inflation_ratio ||
+                        p->cov_mode != h->prm.cov_mode);
+  const int dev = h->prm.device_id;
+  h->prm = *p;
+  h->prm.device_id = dev;  // a handle never migrates
+  if (rebuild) {
+    // setResolution on a loaded target re-voxelises it (ref: svn_ndt_impl.hpp:162-176)
+    int rc = bind_device(h);
+    if (rc) return rc;
+    return build_grid(h, h->tx.p, h->ty.p, h->tz.p, h->n_tgt);
+  }
+  return NDT_OK;
+}
+
+int ndt_set_target(ndt_handle* h, const float* xyz, size_t n, size_t stride_bytes) {
+  if (!h || (!xyz && n) || stride_bytes < 12 || stride_bytes % 4) return NDT_ERR_INVALID_ARG;
+  int rc = bind_device(h);
+  if (rc) return rc;
+  rc = upload_soa(h, xyz, nullptr, nullptr, nullptr, n, stride_bytes, h->tx, h->ty, h->tz);
+  if (rc) return rc;
+  return build_grid(h, h->tx.p, h->ty.p, h->tz.p, n);
+}
+
+int ndt_set_target_soa(ndt_handle* h, const float* x, const float* y, const float* z, size_t n) {
+  if (!h || ((!x || !y || !z) && n)) return NDT_ERR_INVALID_ARG;
+  int rc = bind_device(h);
+  if (rc) return rc;
+  rc = upload_soa(h, nullptr, x, y, z, n, 0, h->tx, h->ty, h->tz);
+  if (rc) return rc;
+  return build_grid(h, h->tx.p, h->ty.p, h->tz.p, n);
+}
+
+int ndt_set_target_device(ndt_handle* h, const float* dx, const float* dy, const float* dz, size_t n) {
+  if (!h || ((!dx || !dy || !dz) && n)) return NDT_ERR_INVALID_ARG;
+  int rc = bind_device(h);
+  if (rc) return rc;
+  // built straight from the caller's arrays; nothing is retained, so a later
+  // resolution change cannot re-voxelise this target
+  h->tx.release(); h->ty.release(); h->tz.release();
+  return build_grid(h, dx, dy, dz, n);
+}
+
+int ndt_set_source(ndt_handle* h, const float* xyz, size_t n, size_t stride_bytes) {
+  if (!h || (!xyz && n) || stride_bytes < 12 || stride_bytes % 4) return NDT_ERR_INVALID_ARG;
+  int rc = bind_device(h);
+  if (rc) return rc;
+  rc = upload_soa(h, xyz, nullptr, nullptr, nullptr, n, stride_bytes, h->sx, h->sy, h->sz);
+  if (rc) return rc;
+  h->n_src = n;
+  return NDT_OK;
+}
+
+int ndt_set_source_soa(ndt_handle* h, const float* x, const float* y, const float* z, size_t n) {
+  if (!h || ((!x || !y || !z) && n)) return NDT_ERR_INVALID_ARG;
+  int rc = bind_device(h);
+  if (rc) return rc;
+  rc = upload_soa(h, nullptr, x, y, z, n, 0, h->sx, h->sy, h->sz);
+  if (rc) return rc;
+  h->n_src = n;
+  return NDT_OK;
+}
+
+int ndt_set_source_device(ndt_handle* h, const float* dx, const float* dy, const float* dz, size_t n) {
+  if (!h || ((!dx || !dy || !dz) && n)) return NDT_ERR_INVALID_ARG;
+  int rc = bind_device(h);
+  if (rc) return rc;
+  HIP_TRY(h, h->sx.ensure(n));
+  HIP_TRY(h, h->sy.ensure(n));
+  HIP_TRY(h, h->sz.ensure(n));
+  if (n) {
+    HIP_TRY(h, hipMemcpyAsync(h->sx.p, dx, n * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->sy.p, dy, n * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->sz.p, dz, n * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
+  h->n_src = n;
+  return NDT_OK;
+}
+
+int ndt_set_global_source_size(ndt_handle* h, int64_t n_total) {
+  if (!h) return NDT_ERR_INVALID_ARG;
+  h->n_src_global = n_total;
+  return NDT_OK;
+}
+
+int ndt_set_regularization_pose(ndt_handle* h, const float pose[16]) {
+  if (!h || !pose) return NDT_ERR_INVALID_ARG;
+  std::memcpy(h->reg_pose, pose, sizeof(h->reg_pose));
+  h->have_reg = true;
+  return NDT_OK;
+}
+
+int ndt_clear_regularization_pose(ndt_handle* h) {
+  if (!h) return NDT_ERR_INVALID_ARG;
+  h->have_reg = false;
+  return NDT_OK;
+}
+
+int ndt_align(ndt_handle* h, const float guess[16], ndt_result* out) {
+  if (!h || !guess || !out) return NDT_ERR_INVALID_ARG;
+  int rc = bind_device(h);
+  if (rc) return rc;
+  rc = ready_for_eval(h);
+  if (rc) {
+    // the reference returns the prior with converged = false (ref: svn_ndt_impl.hpp:682-702)
+    std::memset(out, 0, sizeof(*out));
+    std::memcpy(out->final_transformation, guess, sizeof(float) * 16);
+    return rc;
+  }
+  const double dev_ms0 = h->tm.ms_eval_kernel_total;
+  EvalFn fn = [h](const double* p, const float* T, bool need_h, Eval* e) { return evaluate(h, p, T, need_h, e); };
+  const int64_t n_total = h->n_src_global >= 0 ? h->n_src_global : (int64_t)h->n_src;
+  rc = newton_align(h->prm, n_total, guess, fn, out);
+  out->ms_device = h->tm.ms_eval_kernel_total - dev_ms0;
+  return rc;
+}
+
+int ndt_eval_derivatives(ndt_handle* h, const double* poses6, const float* transforms, int K,
+                         int compute_hessian, double* out) {
+  if (!h || !poses6 || !out || K <= 0) return NDT_ERR_INVALID_ARG;
+  int rc = bind_device(h);
+  if (rc) return rc;
+  rc = ready_for_eval(h);
+  if (rc) return rc;
+  hipStream_t s = h->stream;
+  HIP_TRY(h, h->hposes.ensure((size_t)K));
+  HIP_TRY(h, h->dposes.ensure((size_t)K));
+  for (int k = 0; k < K; ++k) {
+    float T[16];
+    const float* Tk = transforms ? transforms + 16 * (size_t)k : T;
+    if (!transforms) pose_to_matrix(poses6 + 6 * (size_t)k, T);
+    fill_pose_consts(poses6 + 6 * (size_t)k, Tk, &h->hposes.h[k]);
+  }
+  const EvalConsts ec = make_eval_consts(h, compute_hessian != 0);
+  const int blocks = derivs_grid_blocks(h->n_src);
+  HIP_TRY(h, h->partials.ensure((size_t)K * blocks * EV_WORDS));
+  HIP_TRY(h, h->result.ensure((size_t)K * EV_WORDS));
+  HIP_TRY(h, h->dres.ensure((size_t)K * EV_WORDS));
+  HIP_TRY(h, hipMemcpyAsync(h->dposes.p, h->hposes.h, (size_t)K * sizeof(PoseConsts), hipMemcpyHostToDevice, s));
+  if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, s));
+  launch_derivatives(h->sx.p, h->sy.p, h->sz.p, h->n_src, h->geom, h->cell2leaf.p, h->rec.p,
+                     h->hposes.h[0], h->dposes.p, K, ec, h->partials.p, h->dres.p, s);
+  if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, s));
+  if (h->red.wants_device_buffer()) {
+    rc = h->red.allreduce_device(h->dres.p, K * EV_WORDS, s, &h->err);
+    if (rc) return rc;
+  }
+  HIP_TRY(h, hipMemcpyAsync(h->result.h, h->dres.p, (size_t)K * EV_WORDS * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipStreamSynchronize(s));
+  h->tm.n_eval_launches++;
+  if (h->timing) {
+    float ms = 0;
+    HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->tm.ms_last_eval_kernel = ms;
+    h->tm.ms_eval_kernel_total += ms;
+  }
+  std::memcpy(out, h->result.h, (size_t)K * EV_WORDS * sizeof(double));
+  if (!h->red.wants_device_buffer() && h->red.mode() != NDT_REDUCE_NONE) {
+    for (int k = 0; k < K; ++k) {
+      rc = h->red.allreduce_host(out + (size_t)k * EV_WORDS, EV_WORDS, &h->err);
+      if (rc) return rc;
+    }
+  }
+  // ridge / regularisation / guards, then repack so callers see finished values
+  for (int k = 0; k < K; ++k) {
+    double* w = out + (size_t)k * EV_WORDS;
+    Eval e;
+    unpack_eval(w, &e);
+    finish_eval(h->prm, h->have_reg ? h->reg_pose : nullptr, poses6 + 6 * (size_t)k, compute_hessian != 0, &e);
+    w[EV_SCORE] = e.score;
+    for (int i = 0; i < 6; ++i) w[EV_G + i] = e.g[i];
+    int idx = EV_H;
+    for (int i = 0; i < 6; ++i)
+      for (int j = i; j < 6; ++j) w[idx++] = e.H[6 * i + j];
+  }
+  return NDT_OK;
+}
+
+void ndt_unpack_eval(const double* w, double* score, double* g6, double* H36) {
+  Eval e;
+  unpack_eval(w, &e);
+  if (score) *score = e.score;
+  if (g6) std::memcpy(g6, e.g, sizeof(e.g));
+  if (H36) std::memcpy(H36, e.H, sizeof(e.H));
+}
+
+int ndt_transform_source(ndt_handle* h, const float T[16], float* out_xyz, size_t cap_points) {
+  if (!h || !T || !out_xyz) return NDT_ERR_INVALID_ARG;
+  int rc = bind_device(h);
+  if (rc) return rc;
+  if (cap_points < h->n_src) return fail(h, NDT_ERR_INVALID_ARG, "output buffer too small");
+  if (h->n_src == 0) return NDT_OK;
+  PoseConsts pc{};
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) pc.R[3 * i + j] = T[4 * j + i];
+    pc.t[i] = T[12 + i];
+  }
+  DevBuf<float> tmp;
+  HIP_TRY(h, tmp.ensure(3 * h->n_src));
+  launch_transform(h->sx.p, h->sy.p, h->sz.p, h->n_src, pc, tmp.p, h->stream);
+  hipError_t e = hipMemcpyAsync(out_xyz, tmp.p, 3 * h->n_src * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  tmp.release();
+  HIP_TRY(h, e);
+  return NDT_OK;
+}
+
+int ndt_get_grid_info(const ndt_handle* h, ndt_grid_info* out) {
+  if (!h || !out) return NDT_ERR_INVALID_ARG;
+  std::memset(out, 0, sizeof(*out));
+  if (!h->have_grid) return NDT_ERR_NO_TARGET;
+  for (int a = 0; a < 3; ++a) {
+    out->min_b[a] = h->geom.min_b[a];
+    out->max_b[a] = h->max_b[a];
+    out->div_b[a] = h->geom.div_b[a];
+  }
+  out->leaf_size = h->geom.leaf;
+  out->inverse_leaf_size = h->geom.inv_leaf;
+  out->n_leaves = h->n_valid;
+  out->n_cells = h->geom.ncells;
+  out->n_target_points = (int64_t)h->n_tgt;
+  out->ms_build = h->ms_build;
+  return NDT_OK;
+}
+
+int64_t ndt_export_leaves(ndt_handle* h, ndt_leaf* out, size_t cap) {
+  if (!h || (!out && cap)) return NDT_ERR_INVALID_ARG;
+  if (!h->have_grid) return NDT_ERR_NO_TARGET;
+  if (bind_device(h)) return NDT_ERR_HIP;
+  std::vector<LeafStats> st((size_t)h->n_slots);
+  if (h->n_slots) {
+    hipError_t e = hipMemcpy(st.data(), h->stats.p, st.size() * sizeof(LeafStats), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail(h, NDT_ERR_HIP, hipGetErrorString(e));
+  }
+  std::vector<const LeafStats*> ok;
+  ok.reserve(st.size());
+  for (const auto& L : st)
+    if (L.count > 0) ok.push_back(&L);
+  std::sort(ok.begin(), ok.end(), [](const LeafStats* a, const LeafStats* b) { return a->cell < b->cell; });
+  const size_t n = std::min(cap, ok.size());
+  const GridGeom& g = h->geom;
+  for (size_t i = 0; i < n; ++i) {
+    const LeafStats& L = *ok[i];
+    ndt_leaf& o = out[i];
+    o.index = L.cell;
+    o.point_count = L.count;
+    const int i0 = L.cell % g.div_b[0], i1 = (L.cell / g.div_b[0]) % g.div_b[1], i2 = L.cell / g.mul2;
+    o.center[0] = ((float)(g.min_b[0] + i0) + 0.5f) * g.leaf;
+    o.center[1] = ((float)(g.min_b[1] + i1) + 0.5f) * g.leaf;
+    o.center[2] = ((float)(g.min_b[2] + i2) + 0.5f) * g.leaf;
+    std::memcpy(o.mean, L.mean, sizeof(o.mean));
+    std::memcpy(o.cov, L.cov, sizeof(o.cov));
+    std::memcpy(o.icov, L.icov, sizeof(o.icov));
+    std::memcpy(o.evecs, L.evecs, sizeof(o.evecs));
+    std::memcpy(o.evals, L.evals, sizeof(o.evals));
+  }
+  return (int64_t)n;
+}
+
+int ndt_newton_align(const ndt_params* p, int64_t n_source_total, const float guess[16],
+                     const float* reg_pose, ndt_eval_fn fn, void* ctx, ndt_result* out) {
+  if (!p || !guess || !fn || !out) return NDT_ERR_INVALID_ARG;
+  const ndt_params prm = *p;
+  EvalFn wrap = [&](const double* pose, const float* T, bool need_h, Eval* e) -> int {
+    double words[NDT_EVAL_WORDS];
+    std::memset(words, 0, sizeof(words));
+    int rc = fn(ctx, pose, T, need_h ? 1 : 0, words);
+    if (rc) return rc;
+    unpack_eval(words, e);
+    finish_eval(prm, reg_pose, pose, need_h, e);
+    return 0;
+  };
+  return newton_align(prm, n_source_total, guess, wrap, out);
+}
+
+void ndt_shard_range(size_t n, int rank, int nranks, size_t* begin, size_t* count) {
+  if (nranks < 1) nranks = 1;
+  if (rank < 0) rank = 0;
+  if (rank >= nranks) rank = nranks - 1;
+  const size_t b = n * (size_t)rank / (size_t)nranks, e = n * (size_t)(rank + 1) / (size_t)nranks;
+  if (begin) *begin = b;
+  if (count) *count = e - b;
+}
+
+int ndt_comm_unique_id(void* out128) {
+  if (!out128) return NDT_ERR_INVALID_ARG;
+  return Reducer::unique_id(out128);
+}
+
+int ndt_comm_init_rccl(ndt_handle* h, const void* id128, int rank, int nranks) {
+  if (!h || !id128) return NDT_ERR_INVALID_ARG;
+  int rc = bind_device(h);
+  if (rc) return rc;
+  return h->red.init_rccl(id128, rank, nranks, &h->err);
+}
+
+int ndt_comm_init_shm(ndt_handle* h, const char* name, int rank, int nranks) {
+  if (!h) return NDT_ERR_INVALID_ARG;
+  return h->red.init_shm(name, rank, nranks, &h->err);
+}
+
+int ndt_comm_init_hook(ndt_handle* h, ndt_allreduce_fn fn, void* ctx, int rank, int nranks) {
+  if (!h) return NDT_ERR_INVALID_ARG;
+  return h->red.init_hook(fn, ctx, rank, nranks);
+}
+
+int ndt_comm_destroy(ndt_handle* h) {
+  if (!h) return NDT_ERR_INVALID_ARG;
+  h->red.destroy();
+  return NDT_OK;
+}
+
+int ndt_enable_kernel_timing(ndt_handle* h, int on) {
+  if (!h) return NDT_ERR_INVALID_ARG;
+  h->timing = on != 0;
+  return NDT_OK;
+}
+
+int ndt_get_timing(const ndt_handle* h, ndt_timing* out) {
+  if (!h || !out) return NDT_ERR_INVALID_ARG;
+  *out = h->tm;
+  return NDT_OK;
+}
+
+}  // extern "C"

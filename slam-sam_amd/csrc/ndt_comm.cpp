@@ -1,0 +1,208 @@
+// ndt_comm.cpp -- RCCL / shared-memory / hook reduction of evaluation partials.
+#include "ndt_comm.h"
+
+#include <fcntl.h>
+#include <rccl/rccl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstring>
+#include <thread>
+
+namespace ndt {
+
+namespace {
+
+constexpr int kMaxRanks = 64;
+constexpr uint64_t kMagic = 0x4e44545f53484d31ull;  // "NDT_SHM1"
+
+// One cache line per rank for the sequence words so ranks do not false-share.
+struct alignas(64) SeqWord {
+  std::atomic<uint64_t> v;
+  char pad[56];
+};
+
+struct ShmSeg {
+  std::atomic<uint64_t> magic;
+  int nranks;
+  char pad[52];
+  SeqWord seq[kMaxRanks];
+  double slot[2][kMaxRanks][NDT_EVAL_WORDS];
+};
+
+}  // namespace
+
+int Reducer::unique_id(void* out128) {
+  ncclUniqueId id;
+  if (ncclGetUniqueId(&id) != ncclSuccess) return NDT_ERR_COMM;
+  static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+  std::memcpy(out128, &id, 128);
+  return NDT_OK;
+}
+
+int Reducer::init_rccl(const void* id128, int rank, int nranks, std::string* err) {
+  destroy();
+  if (nranks < 1 || rank < 0 || rank >= nranks) return NDT_ERR_INVALID_ARG;
+  ncclUniqueId id;
+  std::memcpy(&id, id128, 128);
+  ncclComm_t comm = nullptr;
+  ncclResult_t rc = ncclCommInitRank(&comm, nranks, id, rank);
+  if (rc != ncclSuccess) {
+    if (err) *err = std::string("ncclCommInitRank: ") + ncclGetErrorString(rc);
+    return NDT_ERR_COMM;
+  }
+  nccl_comm_ = comm;
+  mode_ = NDT_REDUCE_RCCL;
+  rank_ = rank;
+  nranks_ = nranks;
+  return NDT_OK;
+}
+
+int Reducer::init_shm(const char* name, int rank, int nranks, std::string* err) {
+  destroy();
+  if (!name || nranks < 1 || nranks > kMaxRanks || rank < 0 || rank >= nranks)
+    return NDT_ERR_INVALID_ARG;
+  const size_t bytes = sizeof(ShmSeg);
+  int fd = -1;
+  if (rank == 0) {
+    shm_unlink(name);
+    fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) {
+      if (err) *err = std::string("shm_open/ftruncate failed for ") + name;
+      if (fd >= 0) close(fd);
+      return NDT_ERR_COMM;
+    }
+  } else {
+    // wait for rank 0 to create and size the segment (bounded: 60 s)
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      fd = shm_open(name, O_RDWR, 0600);
+      if (fd >= 0) {
+        struct stat st;
+        if (fstat(fd, &st) == 0 && (size_t)st.st_size >= bytes) break;
+        close(fd);
+        fd = -1;
+      }
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
+        if (err) *err = std::string("timed out waiting for shm segment ") + name;
+        return NDT_ERR_COMM;
+      }
+      std::this_thread::sleep_for(std::chrono::milliseconds(2));
+    }
+  }
+  void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) {
+    if (err) *err = "mmap of shm segment failed";
+    return NDT_ERR_COMM;
+  }
+  ShmSeg* seg = static_cast<ShmSeg*>(p);
+  if (rank == 0) {
+    seg->nranks = nranks;
+    for (int r = 0; r < kMaxRanks; ++r) seg->seq[r].v.store(0, std::memory_order_relaxed);
+    seg->magic.store(kMagic, std::memory_order_release);
+  } else {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (seg->magic.load(std::memory_order_acquire) != kMagic) {
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
+        munmap(p, bytes);
+        if (err) *err = "timed out waiting for shm segment initialisation";
+        return NDT_ERR_COMM;
+      }
+      std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+  }
+  shm_ = p;
+  shm_bytes_ = bytes;
+  shm_name_ = name;
+  shm_round_ = 0;
+  mode_ = NDT_REDUCE_SHM;
+  rank_ = rank;
+  nranks_ = nranks;
+  return NDT_OK;
+}
+
+int Reducer::init_hook(ndt_allreduce_fn fn, void* ctx, int rank, int nranks) {
+  destroy();
+  if (!fn || nranks < 1 || rank < 0 || rank >= nranks) return NDT_ERR_INVALID_ARG;
+  hook_ = fn;
+  hook_ctx_ = ctx;
+  mode_ = NDT_REDUCE_HOOK;
+  rank_ = rank;
+  nranks_ = nranks;
+  return NDT_OK;
+}
+
+void Reducer::destroy() {
+  if (nccl_comm_) {
+    ncclCommDestroy(static_cast<ncclComm_t>(nccl_comm_));
+    nccl_comm_ = nullptr;
+  }
+  if (shm_) {
+    munmap(shm_, shm_bytes_);
+    if (rank_ == 0) shm_unlink(shm_name_.c_str());
+    shm_ = nullptr;
+  }
+  hook_ = nullptr;
+  hook_ctx_ = nullptr;
+  mode_ = NDT_REDUCE_NONE;
+  rank_ = 0;
+  nranks_ = 1;
+}
+
+int Reducer::allreduce_device(double* d_words, int n, hipStream_t s, std::string* err) {
+  if (mode_ != NDT_REDUCE_RCCL) return NDT_ERR_INVALID_ARG;
+  ncclResult_t rc = ncclAllReduce(d_words, d_words, (size_t)n, ncclDouble, ncclSum,
+                                  static_cast<ncclComm_t>(nccl_comm_), s);
+  if (rc != ncclSuccess) {
+    if (err) *err = std::string("ncclAllReduce: ") + ncclGetErrorString(rc);
+    return NDT_ERR_COMM;
+  }
+  return NDT_OK;
+}
+
+int Reducer::allreduce_host(double* words, int n, std::string* err) {
+  if (mode_ == NDT_REDUCE_NONE) return NDT_OK;
+  if (mode_ == NDT_REDUCE_HOOK) {
+    if (hook_(hook_ctx_, words, n) != 0) {
+      if (err) *err = "all-reduce hook reported failure";
+      return NDT_ERR_COMM;
+    }
+    return NDT_OK;
+  }
+  if (mode_ != NDT_REDUCE_SHM || n > NDT_EVAL_WORDS) return NDT_ERR_INVALID_ARG;
+  // Every rank publishes its partial in the slot of this round's parity, bumps
+  // its sequence word, waits for all sequence words, then sums the slots in
+  // rank order (so every rank obtains bit-identical sums).  A rank can be at
+  // most one round ahead of the slowest, hence two slot generations suffice.
+  ShmSeg* seg = static_cast<ShmSeg*>(shm_);
+  const uint64_t round = ++shm_round_;
+  const int gen = (int)(round & 1);
+  std::memcpy(seg->slot[gen][rank_], words, sizeof(double) * n);
+  seg->seq[rank_].v.store(round, std::memory_order_release);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int r = 0; r < nranks_; ++r) {
+    int spins = 0;
+    while (seg->seq[r].v.load(std::memory_order_acquire) < round) {
+      if (++spins > 4096) {
+        spins = 0;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
+          if (err) *err = "shared-memory all-reduce timed out";
+          return NDT_ERR_COMM;
+        }
+        std::this_thread::yield();
+      }
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    double s = 0.0;
+    for (int r = 0; r < nranks_; ++r) s += seg->slot[gen][r][i];
+    words[i] = s;
+  }
+  return NDT_OK;
+}
+
+}  // namespace ndt

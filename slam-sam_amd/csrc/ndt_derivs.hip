@@ -1,0 +1,299 @@
+// ndt_derivs.hip -- NDT score / gradient / Hessian accumulation on gfx950.
+//
+// Computes what the reference's computeParticleDerivatives (= pclomp
+// computeDerivatives) computes (ref: extern/svn_ndt/include/svn_ndt_impl.hpp:
+// 518-668, per-pair update :401-513, point derivatives :339-396), for one pose
+// or a batch of poses, but organised for CDNA4:
+//   * SoA f32 source, one thread per source point, the rigid transform fused in
+//     (the reference materialises a transformed cloud, :761);
+//   * neighbour lookup = <= 7 loads from a dense int32 cell->leaf grid followed
+//     by <= 7 80-byte record loads, all issued before any arithmetic;
+//   * algebra refactored: with J = [I | A(x)] every per-pair term of the
+//     gradient and Hessian is J^T (.) J of a 3-vector / symmetric 3x3, so a
+//     pair only accumulates  w += f v,  S += f (C - d2 v v^T)  (v = C (x'-mu));
+//     the 6-vector / 6x6 expansion happens once per POINT, not per pair;
+//   * 31 f64 accumulators per thread, wave64 shuffle reduction, LDS across the
+//     4 waves, one partial row per block, fixed-order final sum (deterministic).
+// No MFMA: 3x3 / 6x6 work is not a dense contraction.
+// Compiled with -ffp-contract=off; the transform and the index arithmetic must
+// round exactly as written to classify points into the same voxels as the ref.
+#include "ndt_kernels.h"
+
+namespace ndt {
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int NACC = 31;  // EV_SCORE .. EV_NPAIRS
+
+// ref: voxel_grid_covariance_impl.hpp:46-71 (f32 bounds) +
+// voxel_grid_covariance.h:297-300 (index).  -1 = outside the grid.
+__device__ __forceinline__ int probe_cell(float px, float py, float pz, const GridGeom& g) {
+  bool in = px >= g.lo[0] && px < g.hi[0] && py >= g.lo[1] && py < g.hi[1] && pz >= g.lo[2] &&
+            pz < g.hi[2];
+  if (!in) return -1;
+  int i0 = (int)(floorf(px * g.inv_leaf) - (float)g.min_b[0]);
+  int i1 = (int)(floorf(py * g.inv_leaf) - (float)g.min_b[1]);
+  int i2 = (int)(floorf(pz * g.inv_leaf) - (float)g.min_b[2]);
+  int idx = i0 + i1 * g.mul1 + i2 * g.mul2;
+  // The reference looks idx up in its hash map whatever its value (f32 rounding at
+  // an upper face can alias into the next row); an idx outside [0, ncells) can
+  // never be a stored key there, so it is a miss here too -- same outcome.
+  return (idx >= 0 && idx < g.ncells) ? idx : -1;
+}
+
+struct PairAcc {
+  double w[3];
+  double S[6];
+  double score, best;
+  int npairs;
+};
+
+// ref: svn_ndt_impl.hpp:401-447 (guards, exp, factor); accumulation refactored
+__device__ __forceinline__ void pair_update(PairAcc& a, const VoxelRecord& r, float xt, float yt,
+                                            float zt, const EvalConsts& ec) {
+  double x0 = (double)xt - r.mean[0], x1 = (double)yt - r.mean[1], x2 = (double)zt - r.mean[2];
+  double v0 = r.icov[0] * x0 + r.icov[1] * x1 + r.icov[2] * x2;
+  double v1 = r.icov[1] * x0 + r.icov[3] * x1 + r.icov[4] * x2;
+  double v2 = r.icov[2] * x0 + r.icov[4] * x1 + r.icov[5] * x2;
+  double q = x0 * v0 + x1 * v1 + x2 * v2;
+  a.npairs += 1;
+  if (!isfinite(q) || q < -1e-9) return;
+  if (q < 0.0) q = 0.0;
+  double earg = ec.d2 * q * 0.5;
+  if (earg > 50.0) return;
+  double e = exp(-earg);
+  double sc = -ec.d1 * e;
+  a.score += sc;
+  a.best = fmax(a.best, sc);
+  double f = ec.d1 * ec.d2 * e;
+  if (!(fabs(f) >= 1e-15)) return;
+  a.w[0] += f * v0; a.w[1] += f * v1; a.w[2] += f * v2;
+  if (ec.need_hessian) {
+    a.S[0] += f * r.icov[0]; a.S[1] += f * r.icov[1]; a.S[2] += f * r.icov[2];
+    a.S[3] += f * r.icov[3]; a.S[4] += f * r.icov[4]; a.S[5] += f * r.icov[5];
+    if (!ec.gauss_newton) {
+      double fd = f * ec.d2;
+      a.S[0] -= fd * v0 * v0; a.S[1] -= fd * v0 * v1; a.S[2] -= fd * v0 * v2;
+      a.S[3] -= fd * v1 * v1; a.S[4] -= fd * v1 * v2; a.S[5] -= fd * v2 * v2;
+    }
+  }
+}
+
+__device__ __forceinline__ float dot3f(const float* m, float x, float y, float z) {
+  return m[0] * x + m[1] * y + m[2] * z;
+}
+
+__device__ __forceinline__ void point_body(double acc[NACC], float x, float y, float z,
+                                           const GridGeom& g, const int* __restrict__ cell2leaf,
+                                           const VoxelRecord* __restrict__ rec, const PoseConsts& P,
+                                           const EvalConsts& ec) {
+  // x' = r0*x + (r1*y + (r2*z + t)), f32, unfused (transformPointCloud, ref :761)
+  float xt = P.R[0] * x + (P.R[1] * y + (P.R[2] * z + P.t[0]));
+  float yt = P.R[3] * x + (P.R[4] * y + (P.R[5] * z + P.t[1]));
+  float zt = P.R[6] * x + (P.R[7] * y + (P.R[8] * z + P.t[2]));
+  if (!(isfinite(xt) && isfinite(yt) && isfinite(zt))) return;  // ref :573
+
+  // ref: voxel_grid_covariance_impl.hpp:560-600 -- neighbours are found by
+  // offsetting the POINT by +-leaf in f32 and re-classifying it.
+  const float w = g.leaf;
+  int cell[7];
+  cell[0] = probe_cell(xt, yt, zt, g);
+  if (ec.direct7) {
+    cell[1] = probe_cell(xt + w, yt, zt, g);
+    cell[2] = probe_cell(xt - w, yt, zt, g);
+    cell[3] = probe_cell(xt, yt + w, zt, g);
+    cell[4] = probe_cell(xt, yt - w, zt, g);
+    cell[5] = probe_cell(xt, yt, zt + w, g);
+    cell[6] = probe_cell(xt, yt, zt - w, g);
+  } else {
+#pragma unroll
+    for (int k = 1; k < 7; ++k) cell[k] = -1;
+  }
+  int slot[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) slot[k] = cell[k] >= 0 ? cell2leaf[cell[k]] : -1;
+
+  PairAcc a;
+  a.w[0] = a.w[1] = a.w[2] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) a.S[k] = 0.0;
+  a.score = 0.0; a.best = 0.0; a.npairs = 0;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    if (slot[k] >= 0) {
+      VoxelRecord r = rec[slot[k]];
+      pair_update(a, r, xt, yt, zt, ec);
+    }
+  }
+  if (a.npairs == 0) return;  // ref :592
+
+  acc[EV_SCORE] += a.score;
+  acc[EV_NVTL] += a.best;
+  acc[EV_NWITH] += 1.0;
+  acc[EV_NPAIRS] += (double)a.npairs;
+
+  // point Jacobian, angular block A (3x3) from the ORIGINAL point (ref :339-363)
+  double A10 = (double)dot3f(P.jang + 0, x, y, z), A20 = (double)dot3f(P.jang + 3, x, y, z);
+  double A01 = (double)dot3f(P.jang + 6, x, y, z), A11 = (double)dot3f(P.jang + 9, x, y, z);
+  double A21 = (double)dot3f(P.jang + 12, x, y, z);
+  double A02 = (double)dot3f(P.jang + 15, x, y, z), A12 = (double)dot3f(P.jang + 18, x, y, z);
+  double A22 = (double)dot3f(P.jang + 21, x, y, z);
+  const double w0 = a.w[0], w1 = a.w[1], w2 = a.w[2];
+  acc[EV_G + 0] += w0;
+  acc[EV_G + 1] += w1;
+  acc[EV_G + 2] += w2;
+  acc[EV_G + 3] += A10 * w1 + A20 * w2;
+  acc[EV_G + 4] += A01 * w0 + A11 * w1 + A21 * w2;
+  acc[EV_G + 5] += A02 * w0 + A12 * w1 + A22 * w2;
+  if (!ec.need_hessian) return;
+
+  const double Sxx = a.S[0], Sxy = a.S[1], Sxz = a.S[2], Syy = a.S[3], Syz = a.S[4], Szz = a.S[5];
+  // B = S * A
+  double B00 = Sxy * A10 + Sxz * A20, B01 = Sxx * A01 + Sxy * A11 + Sxz * A21,
+         B02 = Sxx * A02 + Sxy * A12 + Sxz * A22;
+  double B10 = Syy * A10 + Syz * A20, B11 = Sxy * A01 + Syy * A11 + Syz * A21,
+         B12 = Sxy * A02 + Syy * A12 + Syz * A22;
+  double B20 = Syz * A10 + Szz * A20, B21 = Sxz * A01 + Syz * A11 + Szz * A21,
+         B22 = Sxz * A02 + Syz * A12 + Szz * A22;
+  double* H = acc + EV_H;
+  // row 0: H00..H05 ; row 1: H11..H15 ; row 2: H22..H25
+  H[0] += Sxx; H[1] += Sxy; H[2] += Sxz; H[3] += B00; H[4] += B01; H[5] += B02;
+  H[6] += Syy; H[7] += Syz; H[8] += B10; H[9] += B11; H[10] += B12;
+  H[11] += Szz; H[12] += B20; H[13] += B21; H[14] += B22;
+  // rotational block A^T S A (+ second-derivative term, full Hessian only)
+  double R33 = A10 * B10 + A20 * B20;
+  double R34 = A10 * B11 + A20 * B21;
+  double R35 = A10 * B12 + A20 * B22;
+  double R44 = A01 * B01 + A11 * B11 + A21 * B21;
+  double R45 = A01 * B02 + A11 * B12 + A21 * B22;
+  double R55 = A02 * B02 + A12 * B12 + A22 * B22;
+  if (!ec.gauss_newton) {
+    // ref :369-394 layout of the 15 second-derivative rows; term 3 of :479-489
+    const float* h = P.hang;
+    R33 += w1 * (double)dot3f(h + 0, x, y, z) + w2 * (double)dot3f(h + 3, x, y, z);
+    R34 += w1 * (double)dot3f(h + 6, x, y, z) + w2 * (double)dot3f(h + 9, x, y, z);
+    R35 += w1 * (double)dot3f(h + 12, x, y, z) + w2 * (double)dot3f(h + 15, x, y, z);
+    R44 += w0 * (double)dot3f(h + 18, x, y, z) + w1 * (double)dot3f(h + 21, x, y, z) +
+           w2 * (double)dot3f(h + 24, x, y, z);
+    R45 += w0 * (double)dot3f(h + 27, x, y, z) + w1 * (double)dot3f(h + 30, x, y, z) +
+           w2 * (double)dot3f(h + 33, x, y, z);
+    R55 += w0 * (double)dot3f(h + 36, x, y, z) + w1 * (double)dot3f(h + 39, x, y, z) +
+           w2 * (double)dot3f(h + 42, x, y, z);
+  }
+  H[15] += R33; H[16] += R34; H[17] += R35; H[18] += R44; H[19] += R45; H[20] += R55;
+}
+
+__device__ __forceinline__ void block_reduce_store(double acc[NACC], double* __restrict__ out_row) {
+  __shared__ double lds[BLOCK / 64][NACC + 1];
+#pragma unroll
+  for (int v = 0; v < NACC; ++v) {
+    double a = acc[v];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
+    acc[v] = a;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int v = 0; v < NACC; ++v) lds[wave][v] = acc[v];
+  }
+  __syncthreads();
+  if (threadIdx.x < EV_WORDS) {
+    double sum = 0.0;
+    if (threadIdx.x < NACC) {
+#pragma unroll
+      for (int wv = 0; wv < BLOCK / 64; ++wv) sum += lds[wv][threadIdx.x];
+    }
+    out_row[threadIdx.x] = sum;
+  }
+}
+
+template <bool BATCH>
+__global__ void __launch_bounds__(BLOCK) k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy,
+                                                      const float* __restrict__ sz, int n, GridGeom g,
+                                                      const int* __restrict__ cell2leaf,
+                                                      const VoxelRecord* __restrict__ rec, PoseConsts pose_arg,
+                                                      const PoseConsts* __restrict__ poses, EvalConsts ec,
+                                                      double* __restrict__ partials) {
+  __shared__ PoseConsts pose_lds;
+  const PoseConsts* P = &pose_arg;
+  if (BATCH) {
+    // stage this pose's constants in LDS once per block
+    const float* src = reinterpret_cast<const float*>(poses + blockIdx.y);
+    float* dst = reinterpret_cast<float*>(&pose_lds);
+    for (int i = threadIdx.x; i < (int)(sizeof(PoseConsts) / 4); i += BLOCK) dst[i] = src[i];
+    __syncthreads();
+    P = &pose_lds;
+  }
+  double acc[NACC];
+#pragma unroll
+  for (int v = 0; v < NACC; ++v) acc[v] = 0.0;
+  const int stride = gridDim.x * BLOCK;
+  for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride)
+    point_body(acc, sx[i], sy[i], sz[i], g, cell2leaf, rec, *P, ec);
+  block_reduce_store(acc, partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * EV_WORDS);
+}
+
+// fixed-order sum of the per-block rows: thread (c, v) sums blocks c, c+8, ...
+__global__ void __launch_bounds__(256) k_final_reduce(const double* __restrict__ partials, int nblocks,
+                                                     double* __restrict__ out) {
+  __shared__ double lds[8][EV_WORDS];
+  const double* base = partials + (size_t)blockIdx.x * nblocks * EV_WORDS;
+  const int v = threadIdx.x & 31, c = threadIdx.x >> 5;
+  double s = 0.0;
+  for (int b = c; b < nblocks; b += 8) s += base[(size_t)b * EV_WORDS + v];
+  lds[c][v] = s;
+  __syncthreads();
+  if (threadIdx.x < EV_WORDS) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += lds[k][threadIdx.x];
+    out[(size_t)blockIdx.x * EV_WORDS + threadIdx.x] = t;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_transform(const float* __restrict__ sx, const float* __restrict__ sy,
+                                                  const float* __restrict__ sz, int n, PoseConsts P,
+                                                  float* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float x = sx[i], y = sy[i], z = sz[i];
+  out[3 * i + 0] = P.R[0] * x + (P.R[1] * y + (P.R[2] * z + P.t[0]));
+  out[3 * i + 1] = P.R[3] * x + (P.R[4] * y + (P.R[5] * z + P.t[1]));
+  out[3 * i + 2] = P.R[6] * x + (P.R[7] * y + (P.R[8] * z + P.t[2]));
+}
+
+}  // namespace
+
+int derivs_grid_blocks(size_t n_src) {
+  size_t blocks = (n_src + BLOCK - 1) / BLOCK;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  return (int)blocks;
+}
+
+void launch_derivatives(const float* sx, const float* sy, const float* sz, size_t n_src,
+                        const GridGeom& g, const int* cell2leaf, const VoxelRecord* rec,
+                        const PoseConsts& pose, const PoseConsts* d_poses, int K,
+                        const EvalConsts& ec, double* d_partials, double* d_out, hipStream_t s) {
+  const int blocks = derivs_grid_blocks(n_src);
+  if (d_poses) {
+    hipLaunchKernelGGL(k_derivatives<true>, dim3(blocks, K), dim3(BLOCK), 0, s, sx, sy, sz,
+                       (int)n_src, g, cell2leaf, rec, pose, d_poses, ec, d_partials);
+  } else {
+    hipLaunchKernelGGL(k_derivatives<false>, dim3(blocks, 1), dim3(BLOCK), 0, s, sx, sy, sz,
+                       (int)n_src, g, cell2leaf, rec, pose, d_poses, ec, d_partials);
+    K = 1;
+  }
+  hipLaunchKernelGGL(k_final_reduce, dim3(K), dim3(256), 0, s, d_partials, blocks, d_out);
+}
+
+void launch_transform(const float* sx, const float* sy, const float* sz, size_t n,
+                      const PoseConsts& pose, float* out_xyz, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_transform, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sx, sy, sz,
+                     (int)n, pose, out_xyz);
+}
+
+}  // namespace ndt

@@ -1,0 +1,74 @@
+// ndt_device.h -- structures shared by the host code and the HIP kernels of the
+// NDT engine (gfx950 only).  Not part of the public ABI (that is include/ndt_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ndt {
+
+// Dense-index voxel grid geometry.  Everything a lookup needs, computed on the
+// host in f32 exactly as the reference does (ref:
+// extern/svn_ndt/include/voxel_grid_covariance_impl.hpp:129-140 for min_b /
+// div_b / divb_mul, :59-64 for the f32 bounds).
+struct GridGeom {
+  float leaf;
+  float inv_leaf;
+  int min_b[3];
+  int div_b[3];
+  float lo[3];  // (float)min_b * leaf
+  float hi[3];  // (float)(max_b + 1) * leaf
+  int mul1;     // div_b[0]
+  int mul2;     // div_b[0] * div_b[1]
+  int ncells;   // div_b[0] * div_b[1] * div_b[2]
+};
+
+// What the derivative kernel reads per (point, voxel) pair: 80 B, five 16-B
+// loads.  mean + upper triangle of the inverse covariance in f64 -- the
+// reference keeps both in f64 and forms the Mahalanobis distance in f64
+// (ref: svn_ndt_impl.hpp:418, voxel_grid_covariance.h:125-128).
+struct alignas(16) VoxelRecord {
+  double mean[3];
+  double icov[6];  // xx, xy, xz, yy, yz, zz
+  double pad;
+};
+
+// Full per-leaf statistics kept for export (ref: voxel_grid_covariance.h:99-131).
+struct LeafStats {
+  int32_t cell;
+  int32_t count;  // < 0: rejected by the eigenvalue / inverse checks
+  double mean[3];
+  double cov[9];
+  double icov[9];
+  double evecs[9];
+  double evals[3];
+};
+
+// Pose-dependent constants of one derivative evaluation.  Passed by value as a
+// kernel argument (K = 1) or read from a device array (pose batches).
+struct PoseConsts {
+  float R[9];      // row-major rotation, f32
+  float t[3];
+  float jang[24];  // 8x3  (ref: svn_ndt_impl.hpp:271-290)
+  float hang[45];  // 15x3 (ref: svn_ndt_impl.hpp:299-331)
+};
+
+struct EvalConsts {
+  double d1, d2;   // Gauss constants (ref: svn_ndt_impl.hpp:80-131)
+  int direct7;     // 1: centre + 6 face neighbours, 0: centre only
+  int need_hessian;
+  int gauss_newton;
+};
+
+// layout of one evaluation (matches NDT_EVAL_WORDS in include/ndt_hip.h)
+enum {
+  EV_SCORE = 0,
+  EV_G = 1,        // 6
+  EV_H = 7,        // 21, upper triangle row by row
+  EV_NVTL = 28,
+  EV_NWITH = 29,
+  EV_NPAIRS = 30,
+  EV_WORDS = 32
+};
+
+}  // namespace ndt

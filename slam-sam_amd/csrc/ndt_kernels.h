@@ -1,0 +1,49 @@
+// ndt_kernels.h -- launch wrappers of the HIP kernels (internal).
+#pragma once
+
+#include "ndt_device.h"
+
+namespace ndt {
+
+// ---- target voxel-grid build (ndt_target.hip) ------------------------------
+// d_bounds: 8 ints = ordered-int encoded {min x,y,z, max x,y,z}, #finite, pad
+void launch_bounds(const float* x, const float* y, const float* z, size_t n,
+                   int* d_bounds, hipStream_t s);
+float decode_ordered(int enc);
+
+void launch_cell_keys(const float* x, const float* y, const float* z, size_t n,
+                      const GridGeom& g, uint32_t* keys, uint32_t* vals, hipStream_t s);
+
+size_t sort_temp_bytes(size_t n);
+hipError_t sort_pairs(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
+                      const uint32_t* vals_in, uint32_t* vals_out, size_t n, int end_bit,
+                      hipStream_t s);
+
+// runs of equal cell key with >= min_pts points get a leaf slot
+void launch_find_runs(const uint32_t* keys_sorted, size_t n, int ncells, int min_pts,
+                      int* d_nleaf, int* leaf_start, int* leaf_cnt, hipStream_t s);
+
+struct FinalizeParams {
+  double eig_ratio;
+  int cov_mode;  // 0 svn, 1 pcl (recalled)
+};
+void launch_finalize_leaves(const float* x, const float* y, const float* z,
+                            const uint32_t* keys_sorted, const uint32_t* vals_sorted,
+                            int* d_nleaf /* [0]=slots, [1]=valid */, const int* leaf_start,
+                            const int* leaf_cnt, int max_leaves, FinalizeParams fp, VoxelRecord* rec, LeafStats* stats,
+                            int* cell2leaf, hipStream_t s);
+
+// ---- derivative evaluation (ndt_derivs.hip) ---------------------------------
+int derivs_grid_blocks(size_t n_src);
+// d_partials: K * blocks * EV_WORDS doubles; d_out: K * EV_WORDS doubles
+// (device memory or device-mapped pinned host memory).  If d_poses is null the
+// single pose `pose` is passed as a kernel argument.
+void launch_derivatives(const float* sx, const float* sy, const float* sz, size_t n_src,
+                        const GridGeom& g, const int* cell2leaf, const VoxelRecord* rec,
+                        const PoseConsts& pose, const PoseConsts* d_poses, int K,
+                        const EvalConsts& ec, double* d_partials, double* d_out, hipStream_t s);
+
+void launch_transform(const float* sx, const float* sy, const float* sz, size_t n,
+                      const PoseConsts& pose, float* out_xyz, hipStream_t s);
+
+}  // namespace ndt

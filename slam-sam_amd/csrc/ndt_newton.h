@@ -1,0 +1,41 @@
+// ndt_newton.h -- host side of align(): Newton iterations with a More-Thuente
+// line search on the 6-vector pose, driving an abstract derivative evaluator
+// (the HIP kernels in production).  Internal header.
+#pragma once
+
+#include <functional>
+
+#include "../../include/ndt_hip.h"
+
+namespace ndt {
+
+// One global evaluation (already summed over shards / GPUs).
+struct Eval {
+  double score = 0;
+  double g[6] = {0, 0, 0, 0, 0, 0};
+  double H[36];  // row-major, symmetric
+  double nvtl_sum = 0;
+  double n_with = 0;
+  double n_pairs = 0;
+};
+
+// pose6 -> f32 4x4 (column-major), R = Rx*Ry*Rz built in f32
+void pose_to_matrix(const double p[6], float T[16]);
+// inverse, angles as Eigen's eulerAngles(0,1,2) returns them
+void matrix_to_pose(const float T[16], double p[6]);
+// Gauss constants d1, d2 (ref: extern/svn_ndt/include/svn_ndt_impl.hpp:80-131)
+void gauss_constants(double resolution, double outlier_ratio, double* d1, double* d2);
+// angle tables (ref: svn_ndt_impl.hpp:255-334)
+void angle_tables(const double p[6], float jang[24], float hang[45]);
+// expands NDT_EVAL_WORDS packed words into an Eval
+void unpack_eval(const double* w, Eval* e);
+// adds the ridge / regularisation terms and applies the non-finite guards
+void finish_eval(const ndt_params& prm, const float* reg_pose, const double p[6], bool need_h, Eval* e);
+
+// fn(pose6, T, need_hessian, out) -> 0 on success
+using EvalFn = std::function<int(const double*, const float*, bool, Eval*)>;
+
+int newton_align(const ndt_params& prm, int64_t n_source_total, const float guess[16],
+                 const EvalFn& fn, ndt_result* out);
+
+}  // namespace ndt

@@ -1,0 +1,364 @@
+// ndt_target.hip -- target voxel-grid build on gfx950 (MI355X).
+//
+// What it computes is the reference's VoxelGridCovariance::applyFilter
+// (ref: extern/svn_ndt/include/voxel_grid_covariance_impl.hpp:77-379): bounds,
+// integer grid, per-voxel point count / mean / 3x3 covariance, eigenvalue
+// inflation, inverse covariance, validity filtering.  How it computes it is
+// MI355X-first and shares nothing with the reference's single-threaded
+// hash-map loop:
+//   1. bounds        : one streaming pass, wave-shuffle min/max, 6 int atomics/block
+//   2. cell keys     : one streaming pass (f32 floor, bit-compatible with the ref)
+//   3. stable LSD radix sort of (cell, point index) -- points of one voxel become
+//                      contiguous and stay in input order (deterministic sums)
+//   4. run detection : heads find their run length by galloping search
+//   5. leaf finalise : 8 lanes per voxel gather + reduce in f64, lane 0 does the
+//                      3x3 Jacobi eigen-solve / inflation / inverse and publishes
+//                      an 80-byte VoxelRecord and the dense cell -> leaf index.
+// Compiled with -ffp-contract=off: f32 index arithmetic must round as written.
+#include "ndt_kernels.h"
+
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include <climits>
+
+namespace ndt {
+
+namespace {
+
+__device__ __forceinline__ int encode_ordered(float f) {
+  int i = __float_as_int(f);
+  return i >= 0 ? i : i ^ 0x7fffffff;
+}
+
+__device__ __forceinline__ bool finite3(float a, float b, float c) {
+  return isfinite(a) && isfinite(b) && isfinite(c);
+}
+
+__global__ void k_bounds_init(int* b) {
+  int t = threadIdx.x;
+  if (t < 3) b[t] = INT_MAX;
+  else if (t < 6) b[t] = INT_MIN;
+  else if (t < 8) b[t] = 0;
+}
+
+// ref: pcl::getMinMax3D at voxel_grid_covariance_impl.hpp:103 (non-finite skipped)
+__global__ void __launch_bounds__(256) k_bounds(const float* __restrict__ x, const float* __restrict__ y,
+                                               const float* __restrict__ z, size_t n, int* bounds) {
+  int mn[3] = {INT_MAX, INT_MAX, INT_MAX};
+  int mx[3] = {INT_MIN, INT_MIN, INT_MIN};
+  int cnt = 0;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float a = x[i], b = y[i], c = z[i];
+    if (!finite3(a, b, c)) continue;
+    int ea = encode_ordered(a), eb = encode_ordered(b), ec = encode_ordered(c);
+    mn[0] = min(mn[0], ea); mx[0] = max(mx[0], ea);
+    mn[1] = min(mn[1], eb); mx[1] = max(mx[1], eb);
+    mn[2] = min(mn[2], ec); mx[2] = max(mx[2], ec);
+    ++cnt;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      mn[a] = min(mn[a], __shfl_xor(mn[a], off));
+      mx[a] = max(mx[a], __shfl_xor(mx[a], off));
+    }
+    cnt += __shfl_xor(cnt, off);
+  }
+  if ((threadIdx.x & 63) == 0 && cnt > 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      atomicMin(&bounds[a], mn[a]);
+      atomicMax(&bounds[3 + a], mx[a]);
+    }
+    atomicAdd(&bounds[6], cnt);
+  }
+}
+
+// ref: voxel_grid_covariance_impl.hpp:222-225 -- floor in f32, f32 subtraction
+// of min_b, truncation; 1-D index with divb_mul = (1, dx, dx*dy).
+__device__ __forceinline__ int cell_of(float px, float py, float pz, const GridGeom& g) {
+  int i0 = (int)(floorf(px * g.inv_leaf) - (float)g.min_b[0]);
+  int i1 = (int)(floorf(py * g.inv_leaf) - (float)g.min_b[1]);
+  int i2 = (int)(floorf(pz * g.inv_leaf) - (float)g.min_b[2]);
+  return i0 + i1 * g.mul1 + i2 * g.mul2;
+}
+
+__global__ void __launch_bounds__(256) k_cell_keys(const float* __restrict__ x, const float* __restrict__ y,
+                                                  const float* __restrict__ z, size_t n, GridGeom g,
+                                                  uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float a = x[i], b = y[i], c = z[i];
+  uint32_t key = (uint32_t)g.ncells;  // sentinel sorts behind every real cell
+  if (finite3(a, b, c)) {
+    int idx = cell_of(a, b, c, g);
+    if (idx >= 0 && idx < g.ncells) key = (uint32_t)idx;
+  }
+  keys[i] = key;
+  vals[i] = (uint32_t)i;
+}
+
+__global__ void __launch_bounds__(256) k_find_runs(const uint32_t* __restrict__ keys, int n, int ncells,
+                                                  int min_pts, int* nleaf, int* __restrict__ leaf_start,
+                                                  int* __restrict__ leaf_cnt) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  uint32_t key = keys[s];
+  if (key >= (uint32_t)ncells) return;
+  if (s > 0 && keys[s - 1] == key) return;  // not a run head
+  // gallop, then bisect, for the first position whose key differs
+  int lo = s, hi, step = 1;
+  for (;;) {
+    int nx = lo + step;
+    if (nx >= n) { hi = n; break; }
+    if (keys[nx] != key) { hi = nx; break; }
+    lo = nx;
+    step <<= 1;
+  }
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (keys[mid] == key) lo = mid; else hi = mid;
+  }
+  int cnt = hi - s;
+  if (cnt < min_pts) return;  // ref: voxel_grid_covariance_impl.hpp:270-273
+  int slot = atomicAdd(nleaf, 1);
+  leaf_start[slot] = s;
+  leaf_cnt[slot] = cnt;
+}
+
+// one Jacobi rotation of the symmetric 3x3 A (full storage) in the (P,Q) plane
+template <int P, int Q>
+__device__ __forceinline__ void jacobi_rot(double A[9], double V[9]) {
+  double apq = A[3 * P + Q];
+  if (apq == 0.0) return;
+  double theta = (A[3 * Q + Q] - A[3 * P + P]) / (2.0 * apq);
+  double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+  double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    double akp = A[3 * k + P], akq = A[3 * k + Q];
+    A[3 * k + P] = c * akp - s * akq;
+    A[3 * k + Q] = s * akp + c * akq;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    double apk = A[3 * P + k], aqk = A[3 * Q + k];
+    A[3 * P + k] = c * apk - s * aqk;
+    A[3 * Q + k] = s * apk + c * aqk;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    double vkp = V[3 * k + P], vkq = V[3 * k + Q];
+    V[3 * k + P] = c * vkp - s * vkq;
+    V[3 * k + Q] = s * vkp + c * vkq;
+  }
+}
+
+#define NDT_SWAP_COL(a, b)                                          \
+  {                                                                 \
+    double td = d[a]; d[a] = d[b]; d[b] = td;                       \
+    _Pragma("unroll") for (int k = 0; k < 3; ++k) {                 \
+      double tv = V[3 * k + a]; V[3 * k + a] = V[3 * k + b]; V[3 * k + b] = tv; \
+    }                                                               \
+  }
+
+constexpr int LANES_PER_LEAF = 8;
+
+// ref: voxel_grid_covariance_impl.hpp:236-239 (sums), :265-343 (finalisation)
+__global__ void __launch_bounds__(256) k_finalize_leaves(
+    const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+    const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, int* __restrict__ nleaf_p,
+    const int* __restrict__ leaf_start, const int* __restrict__ leaf_cnt, FinalizeParams fp,
+    VoxelRecord* __restrict__ rec, LeafStats* __restrict__ stats, int* __restrict__ cell2leaf) {
+  const int nleaf = *nleaf_p;
+  const int slot = (blockIdx.x * blockDim.x + threadIdx.x) / LANES_PER_LEAF;
+  const int sub = threadIdx.x & (LANES_PER_LEAF - 1);
+  const bool live = slot < nleaf;
+  int start = 0, cnt = 0;
+  if (live) { start = leaf_start[slot]; cnt = leaf_cnt[slot]; }
+  double s[3] = {0, 0, 0}, ss[6] = {0, 0, 0, 0, 0, 0};
+  for (int j = sub; j < cnt; j += LANES_PER_LEAF) {
+    uint32_t pi = vals[start + j];
+    double a = (double)x[pi], b = (double)y[pi], c = (double)z[pi];
+    s[0] += a; s[1] += b; s[2] += c;
+    ss[0] += a * a; ss[1] += a * b; ss[2] += a * c;
+    ss[3] += b * b; ss[4] += b * c; ss[5] += c * c;
+  }
+#pragma unroll
+  for (int off = 1; off < LANES_PER_LEAF; off <<= 1) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) s[a] += __shfl_xor(s[a], off);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) ss[a] += __shfl_xor(ss[a], off);
+  }
+  if (!live || sub != 0) return;
+
+  const int cell = (int)keys[start];
+  const double n = (double)cnt;
+  double mean[3] = {s[0] / n, s[1] / n, s[2] / n};  // ref :278
+  double C[9];
+  const int tri[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
+  if (fp.cov_mode == 0) {
+    // ref :287-291
+    const double k = n / (n - 1.0);
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+        C[3 * a + b] = ((ss[tri[3 * a + b]] / n) - (mean[a] * mean[b])) * k;
+  } else {
+    const double k = (n - 1.0) / n;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+        C[3 * a + b] = ((ss[tri[3 * a + b]] - 2.0 * (s[a] * mean[b])) / n + mean[a] * mean[b]) * k;
+  }
+
+  LeafStats L;
+  L.cell = cell;
+  L.count = cnt;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) L.mean[a] = mean[a];
+
+  // eigen-decomposition (ref :298-300), cyclic Jacobi in f64
+  double A[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+#pragma unroll
+  for (int a = 0; a < 9; ++a) A[a] = C[a];
+  for (int sweep = 0; sweep < 64; ++sweep) {
+    double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+    double diag = A[0] * A[0] + A[4] * A[4] + A[8] * A[8];
+    if (off <= 1e-32 * diag || off == 0.0) break;
+    jacobi_rot<0, 1>(A, V);
+    jacobi_rot<0, 2>(A, V);
+    jacobi_rot<1, 2>(A, V);
+  }
+  double d[3] = {A[0], A[4], A[8]};
+  if (d[0] > d[1]) NDT_SWAP_COL(0, 1);
+  if (d[1] > d[2]) NDT_SWAP_COL(1, 2);
+  if (d[0] > d[1]) NDT_SWAP_COL(0, 1);
+
+  bool ok = !(d[0] < 0 || d[1] < 0 || d[2] < 1e-12);  // ref :303-309
+  // ref :311-331
+  const double floor_ev = fmax(1e-12, d[2] * fp.eig_ratio);
+  bool recompose = false;
+  if (d[0] < floor_ev) { d[0] = floor_ev; recompose = true; }
+  if (d[1] < floor_ev) { d[1] = floor_ev; recompose = true; }
+  if (recompose) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        double acc = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc += V[3 * a + k] * d[k] * V[3 * b + k];
+        C[3 * a + b] = acc;
+      }
+  }
+  // inverse by cofactors (ref :334)
+  double c00 = C[4] * C[8] - C[5] * C[7];
+  double c01 = C[5] * C[6] - C[3] * C[8];
+  double c02 = C[3] * C[7] - C[4] * C[6];
+  double det = C[0] * c00 + C[1] * c01 + C[2] * c02;
+  double id = 1.0 / det;
+  double I[9];
+  I[0] = c00 * id;
+  I[1] = (C[2] * C[7] - C[1] * C[8]) * id;
+  I[2] = (C[1] * C[5] - C[2] * C[4]) * id;
+  I[3] = c01 * id;
+  I[4] = (C[0] * C[8] - C[2] * C[6]) * id;
+  I[5] = (C[2] * C[3] - C[0] * C[5]) * id;
+  I[6] = c02 * id;
+  I[7] = (C[1] * C[6] - C[0] * C[7]) * id;
+  I[8] = (C[0] * C[4] - C[1] * C[3]) * id;
+  double amax = 0;
+#pragma unroll
+  for (int a = 0; a < 9; ++a) {
+    if (!isfinite(I[a])) ok = false;
+    amax = fmax(amax, fabs(I[a]));
+  }
+  if (amax > 1e12) ok = false;  // ref :337-343
+
+#pragma unroll
+  for (int a = 0; a < 9; ++a) { L.cov[a] = C[a]; L.icov[a] = I[a]; L.evecs[a] = V[a]; }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) L.evals[a] = d[a];
+  if (!ok) L.count = -cnt;
+  stats[slot] = L;
+  if (ok) {
+    VoxelRecord r;
+    r.mean[0] = mean[0]; r.mean[1] = mean[1]; r.mean[2] = mean[2];
+    r.icov[0] = I[0]; r.icov[1] = I[1]; r.icov[2] = I[2];
+    r.icov[3] = I[4]; r.icov[4] = I[5]; r.icov[5] = I[8];
+    r.pad = (double)cnt;
+    rec[slot] = r;
+    cell2leaf[cell] = slot;
+    atomicAdd(nleaf_p + 1, 1);  // leaves that passed every check
+  }
+}
+
+}  // namespace
+
+float decode_ordered(int enc) {
+  int i = enc >= 0 ? enc : enc ^ 0x7fffffff;
+  float f;
+  memcpy(&f, &i, sizeof(f));
+  return f;
+}
+
+void launch_bounds(const float* x, const float* y, const float* z, size_t n, int* d_bounds,
+                   hipStream_t s) {
+  hipLaunchKernelGGL(k_bounds_init, dim3(1), dim3(64), 0, s, d_bounds);
+  if (n == 0) return;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_bounds, dim3((unsigned)blocks), dim3(256), 0, s, x, y, z, n, d_bounds);
+}
+
+void launch_cell_keys(const float* x, const float* y, const float* z, size_t n, const GridGeom& g,
+                      uint32_t* keys, uint32_t* vals, hipStream_t s) {
+  if (n == 0) return;
+  size_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(k_cell_keys, dim3((unsigned)blocks), dim3(256), 0, s, x, y, z, n, g, keys, vals);
+}
+
+size_t sort_temp_bytes(size_t n) {
+  size_t bytes = 0;
+  uint32_t* p = nullptr;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, p, p, p, p, n, 0, 32, (hipStream_t)0);
+  return bytes;
+}
+
+hipError_t sort_pairs(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
+                      const uint32_t* vals_in, uint32_t* vals_out, size_t n, int end_bit,
+                      hipStream_t s) {
+  return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0,
+                                   (unsigned)end_bit, s);
+}
+
+void launch_find_runs(const uint32_t* keys_sorted, size_t n, int ncells, int min_pts, int* d_nleaf,
+                      int* leaf_start, int* leaf_cnt, hipStream_t s) {
+  if (n == 0) return;
+  size_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(k_find_runs, dim3((unsigned)blocks), dim3(256), 0, s, keys_sorted, (int)n,
+                     ncells, min_pts, d_nleaf, leaf_start, leaf_cnt);
+}
+
+void launch_finalize_leaves(const float* x, const float* y, const float* z,
+                            const uint32_t* keys_sorted, const uint32_t* vals_sorted,
+                            int* d_nleaf, const int* leaf_start, const int* leaf_cnt,
+                            int max_leaves, FinalizeParams fp, VoxelRecord* rec, LeafStats* stats,
+                            int* cell2leaf, hipStream_t s) {
+  if (max_leaves <= 0) return;
+  size_t threads = (size_t)max_leaves * LANES_PER_LEAF;
+  size_t blocks = (threads + 255) / 256;
+  hipLaunchKernelGGL(k_finalize_leaves, dim3((unsigned)blocks), dim3(256), 0, s, x, y, z,
+                     keys_sorted, vals_sorted, d_nleaf, leaf_start, leaf_cnt, fp, rec, stats,
+                     cell2leaf);
+}
+
+}  // namespace ndt
