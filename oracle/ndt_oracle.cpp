@@ -190,6 +190,7 @@ extern "C" void oracle_default_params(oracle_params* p) {
   p->num_threads = 1;
   p->use_regularization = 0;
   p->regularization_scale_factor = 0.0f;
+  p->symmetrize_hessian = 0;
 }
 
 // ref: voxel_grid_covariance_impl.hpp:222-225 -- f32 floor, f32 subtraction of
@@ -739,6 +740,9 @@ extern "C" void oracle_derivatives(const oracle_grid* g, const float* src, size_
     out->n_with_neighbors += accs[t].n_with;
     out->n_pairs += accs[t].n_pairs;
   }
+  if (need_h && prm->symmetrize_hessian)
+    for (int i = 0; i < 6; ++i)
+      for (int j = i + 1; j < 6; ++j) out->hessian[6 * j + i] = out->hessian[6 * i + j];
   if (need_h && prm->add_ridge)  // ref :650-653
     for (int a = 0; a < 6; ++a) out->hessian[7 * a] += 1e-6;
 

@@ -62,6 +62,8 @@ typedef struct oracle_params {
   int use_regularization;      /* tier4 longitudinal regularisation [RECALLED] */
   float regularization_scale_factor;
   float regularization_pose[16]; /* column-major 4x4 */
+  int symmetrize_hessian;      /* test seam: mirror the upper triangle of H (the f32 J^T C^-1 J
+                                  product of svn_ndt_impl.hpp:470 is only symmetric to rounding) */
 } oracle_params;
 
 void oracle_default_params(oracle_params* p);

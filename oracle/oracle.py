@@ -38,6 +38,7 @@ class Params(C.Structure):
         ("use_regularization", C.c_int),
         ("regularization_scale_factor", C.c_float),
         ("regularization_pose", C.c_float * 16),
+        ("symmetrize_hessian", C.c_int),
     ]
 
 

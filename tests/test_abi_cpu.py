@@ -1,0 +1,151 @@
+"""CPU tests of the boundary and the host logic: the C-ABI library loads and exports every
+symbol include/ndt_hip.h declares, fails loudly without a GPU (no fallback), and the host
+Newton / More-Thuente driver reproduces the oracle's trajectory when fed the same
+evaluations (no compute kernels run here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    txt = open(os.path.join(ROOT, "include", "ndt_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = set(re.findall(r"\b(ndt_[a-z0-9_]+)\s*\(", txt))
+    # function-pointer typedefs are types, not exports
+    return sorted(n for n in names if n not in ("ndt_eval_fn", "ndt_allreduce_fn"))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    L = pkg.lib()
+    declared = header_functions()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(L, name), "libndt_hip.so lacks %s" % name
+    assert sorted(pkg.ABI_SYMBOLS) == declared  # the Python binding covers the whole ABI
+    assert L.ndt_abi_version() == 1
+
+
+def test_abi_signatures_have_no_torch_types():
+    txt = open(os.path.join(ROOT, "include", "ndt_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)  # declarations only
+    assert "torch" not in txt and "at::" not in txt and "std::" not in txt
+
+
+def test_default_params_follow_reference_defaults(pkg):
+    p = pkg.default_params()
+    assert p.resolution == 1.0 and p.outlier_ratio == 0.55       # svn_ndt_impl.hpp:62
+    assert p.min_points_per_voxel == 6 and p.eig_inflation_ratio == 0.01  # voxel_grid_covariance.h:153-154
+    assert p.search_method == pkg.DIRECT7
+    assert p.hessian_mode == pkg.HESSIAN_FULL and p.use_line_search == 1
+
+
+def test_no_gpu_means_loud_failure_not_fallback(pkg):
+    n, info = pkg.backend_info()
+    if n > 0:
+        pytest.skip("a HIP device is present: " + info)
+    with pytest.raises(pkg.NdtError) as ei:
+        pkg.NormalDistributionsTransform()
+    assert ei.value.code == -2  # NDT_ERR_NO_DEVICE
+
+
+def test_invalid_arguments_are_rejected(pkg):
+    L = pkg.lib()
+    h = C.c_void_p()
+    bad = pkg.default_params(resolution=0.0)
+    assert L.ndt_create(C.byref(bad), C.byref(h)) == -1
+    bad = pkg.default_params(search_method=pkg.KDTREE)
+    assert L.ndt_create(C.byref(bad), C.byref(h)) == -1
+    assert L.ndt_align(None, None, None) == -1
+    assert L.ndt_get_grid_info(None, None) == -1
+    assert L.ndt_destroy(None) == 0
+
+
+def test_shard_range_partitions(pkg):
+    for n in (0, 1, 7, 200000, 200003):
+        for w in (1, 2, 3, 4, 8):
+            covered = 0
+            for r in range(w):
+                b, c = pkg.shard_range(n, r, w)
+                assert b == covered
+                covered += c
+                assert abs(c - n / w) < 1
+            assert covered == n
+
+
+def oracle_evaluator(pkg, O, grid, src, prm, log=None):
+    def fn(pose, T, need_h):
+        d = grid.derivatives(src, pose, T=T, compute_hessian=need_h, params=prm)
+        if log is not None:
+            log.append((pose.copy(), T.copy(), need_h))
+        return pkg.pack_eval(d["score"], d["gradient"], d["hessian"], d["nvtl_sum"],
+                             d["n_with_neighbors"], d["n_pairs"])
+    return fn
+
+
+@pytest.mark.parametrize("line_search", [1, 0])
+def test_newton_driver_matches_oracle_trajectory(pkg, O, S, line_search):
+    """Same evaluations in -> the product's host loop must take the oracle's steps."""
+    src, tgt, gt, guess = S.two_planes(seed=2024, max_points=3000)
+    kw = dict(resolution=1.0, step_size=0.1, trans_epsilon=1e-4, max_iterations=50, use_line_search=line_search)
+    # the packed evaluation carries the upper triangle of H only: give the oracle the same H
+    oprm = O.default_params(symmetrize_hessian=1, **kw)
+    grid = O.Grid(tgt, oprm)
+    ref = grid.align(src, guess)
+    log = []
+    got = pkg.newton_align(pkg.default_params(**kw), len(src), guess,
+                           oracle_evaluator(pkg, O, grid, src, oprm, log))
+    assert got["converged"] == ref["converged"]
+    assert got["iterations"] == ref["iterations"]
+    assert got["n_evaluations"] == ref["n_evaluations"] == len(log)
+    np.testing.assert_allclose(got["pose"], ref["pose"], rtol=0, atol=1e-9)
+    np.testing.assert_array_equal(got["T"].astype(np.float32), ref["T"].astype(np.float32))
+    np.testing.assert_allclose(got["hessian"], ref["hessian"], rtol=1e-12)
+    assert got["score"] == pytest.approx(ref["score"], rel=1e-12)
+    assert got["nvtl"] == pytest.approx(ref["nvtl"], rel=1e-12)
+    # the f32 transform the product builds from a pose is bit-identical to the oracle's
+    for pose, T, _ in log[1:]:
+        np.testing.assert_array_equal(T.astype(np.float32), O.pose_to_matrix(pose).astype(np.float32))
+    # first evaluation uses the guess matrix itself and Eigen-style Euler angles
+    np.testing.assert_array_equal(log[0][1].astype(np.float32), np.asarray(guess, np.float32))
+    np.testing.assert_allclose(log[0][0], O.matrix_to_pose(guess), atol=1e-12)
+
+
+def test_newton_driver_regularization_and_ridge(pkg, O, S):
+    src, tgt, gt, guess = S.two_planes(seed=2024, max_points=3000)
+    kw = dict(resolution=1.0, step_size=0.1, trans_epsilon=1e-4, max_iterations=30)
+    reg_pose = S.pose_matrix(0.45, 0.02, 0.3, 0, 0, 0.26)
+    oprm = O.default_params(use_regularization=1, regularization_scale_factor=0.01,
+                            regularization_pose=reg_pose, add_ridge=1, symmetrize_hessian=1, **kw)
+    grid = O.Grid(tgt, oprm)
+    ref = grid.align(src, guess)
+    plain = O.default_params(**kw)  # the evaluator returns the un-regularised sums
+    got = pkg.newton_align(pkg.default_params(regularization_scale_factor=0.01, add_ridge=1, **kw), len(src),
+                           guess, oracle_evaluator(pkg, O, grid, src, plain), regularization_pose=reg_pose)
+    assert got["iterations"] == ref["iterations"]
+    np.testing.assert_allclose(got["pose"], ref["pose"], atol=1e-9)
+    np.testing.assert_allclose(got["hessian"], ref["hessian"], rtol=1e-10)
+
+
+def test_newton_driver_propagates_evaluator_failure(pkg, S):
+    src, tgt, gt, guess = S.two_planes(seed=1, max_points=500)
+    def boom(pose, T, need_h):
+        raise RuntimeError("evaluator failed")
+    with pytest.raises(pkg.NdtError):
+        pkg.newton_align(pkg.default_params(), len(src), guess, boom)
+
+
+def test_pack_unpack_roundtrip(pkg):
+    rng = np.random.default_rng(0)
+    g = rng.normal(size=6)
+    H = rng.normal(size=(6, 6))
+    H = H + H.T
+    w = pkg.pack_eval(1.5, g, H, 2.5, 7, 11)
+    u = pkg.unpack_eval(w)
+    assert u["score"] == 1.5 and u["n_with_neighbors"] == 7 and u["n_pairs"] == 11
+    np.testing.assert_array_equal(u["gradient"], g)
+    np.testing.assert_array_equal(u["hessian"], H)

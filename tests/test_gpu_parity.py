@@ -1,0 +1,378 @@
+"""GPU parity tests: the HIP path, called through the C-ABI, against the CPU oracle on the
+same seeded inputs, against the committed golden vectors, and -- at BASELINE.json's full
+sizes -- through size-independent properties.
+
+Tolerances (written where used):
+  * voxel membership, point counts, neighbour counts: BIT-EXACT (integer work);
+  * voxel mean: 1e-12 relative; covariance / inverse: 1e-9 of the matrix' largest entry
+    (f64 sums in a different association; at km-scale coordinates the reference's own
+    single-pass cancellation bounds it at ~1e-4, see the shifted case);
+  * score 1e-9 relative; gradient / Hessian 1e-6 of their norms (the oracle rounds the
+    per-pair products to f32 as the reference does, the kernel keeps f64);
+  * final transform: <= 1 mm and <= 0.1 mrad from the oracle, and the
+    reference test's own 0.05 m / 0.035 rad from ground truth.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ALIGN_TOL_M, ALIGN_TOL_RAD = 1e-3, 1e-4
+
+
+def make_ndt(pkg, **kw):
+    n, info = pkg.backend_info()
+    assert n > 0, "GPU test on a box without a HIP device: " + info
+    base = dict(resolution=1.0, step_size=0.1, trans_epsilon=1e-4, max_iterations=50)
+    base.update(kw)
+    return pkg.NormalDistributionsTransform(device_id=0, **base)
+
+
+def assert_leaves_match(L, OL, cov_rtol=1e-9):
+    assert np.array_equal(L["cell"], OL["cell"])
+    assert np.array_equal(L["count"], OL["count"])
+    np.testing.assert_allclose(L["mean"], OL["mean"], rtol=1e-12, atol=0)
+    for k in ("cov", "icov"):
+        scale = np.abs(OL[k]).max(axis=(1, 2), keepdims=True)
+        assert (np.abs(L[k] - OL[k]) / scale).max() < (cov_rtol if k == "cov" else 100 * cov_rtol), k
+    scale = np.abs(OL["evals"]).max(axis=1, keepdims=True)
+    assert (np.abs(L["evals"] - OL["evals"]) / scale).max() < 100 * cov_rtol
+
+
+def assert_derivs_match(e, d, tol=1e-6):
+    assert e["n_pairs"] == d["n_pairs"]
+    assert e["n_with_neighbors"] == d["n_with_neighbors"]
+    assert e["score"] == pytest.approx(d["score"], rel=1e-9, abs=1e-9)
+    assert e["nvtl_sum"] == pytest.approx(d["nvtl_sum"], rel=1e-9, abs=1e-9)
+    gn, hn = np.linalg.norm(d["gradient"]), np.linalg.norm(d["hessian"])
+    assert np.linalg.norm(e["gradient"] - d["gradient"]) <= tol * gn + 1e-12
+    assert np.linalg.norm(e["hessian"] - d["hessian"]) <= tol * hn + 1e-12
+
+
+# ---------------------------------------------------------------------------------------
+# golden vectors through the HIP path
+# ---------------------------------------------------------------------------------------
+def test_golden_g1_through_hip(pkg, golden_dir):
+    z = np.load(os.path.join(golden_dir, "g1_two_plane_3k.npz"))
+    ndt = make_ndt(pkg)
+    ndt.setInputTarget(z["target"])
+    gi = ndt.getGridInfo()
+    assert np.array_equal(gi["min_b"], z["min_b"]) and np.array_equal(gi["div_b"], z["div_b"])
+    L = ndt.getLeaves()
+    assert_leaves_match(L, dict(cell=z["leaf_cell"], count=z["leaf_count"], mean=z["leaf_mean"],
+                                cov=z["leaf_cov"], icov=z["leaf_icov"], evals=z["leaf_evals"]))
+    ndt.setInputSource(z["source"])
+    for i, e in enumerate(ndt.evalDerivatives(z["poses"])):
+        assert_derivs_match(e, dict(score=z["score"][i], gradient=z["gradient"][i], hessian=z["hessian"][i],
+                                    n_pairs=z["n_pairs"][i], n_with_neighbors=z["n_with"][i],
+                                    nvtl_sum=z["nvtl_sum"][i]))
+    T = ndt.align(z["guess"])
+    r = ndt.getResult()
+    assert r["converged"] == bool(z["align_converged"])
+    dt, dr = pkg.synth.pose_error(T, z["align_T"])
+    assert dt < ALIGN_TOL_M and dr < ALIGN_TOL_RAD
+    # variants
+    ndt.setParams(hessian_mode=pkg.HESSIAN_GAUSS_NEWTON, add_ridge=1)
+    e = ndt.evalDerivatives(z["poses"][0])[0]
+    np.testing.assert_allclose(e["hessian"], z["gn_hessian"], rtol=0, atol=1e-6 * np.linalg.norm(z["gn_hessian"]))
+    ndt.setParams(hessian_mode=pkg.HESSIAN_FULL, add_ridge=0, search_method=pkg.DIRECT1)
+    e = ndt.evalDerivatives(z["poses"][0])[0]
+    assert e["n_pairs"] == int(z["d1_n_pairs"])
+    np.testing.assert_allclose(e["gradient"], z["d1_gradient"], rtol=0, atol=1e-6 * np.linalg.norm(z["d1_gradient"]))
+
+
+# ---------------------------------------------------------------------------------------
+# the reference's own test, through the product
+# ---------------------------------------------------------------------------------------
+def test_reference_convergence_test_through_hip(pkg, O, S):
+    """ConvergenceComparison.PclOmp (ref: test_svn_ndt.cpp:138-199) with the HIP engine."""
+    src, tgt, gt, guess = O.two_plane_fixture()
+    ndt = make_ndt(pkg, resolution=1.0, max_iterations=50, trans_epsilon=1e-4, step_size=0.1)
+    ndt.setNeighborhoodSearchMethod(pkg.DIRECT7)
+    ndt.setNumThreads(20)
+    ndt.setInputTarget(tgt)
+    ndt.setInputSource(src)
+    T = ndt.computeTransformation(guess)
+    assert ndt.hasConverged()
+    assert ndt.getFinalNumIteration() < 50
+    trans_err, rot_err = S.se3_log_error(T, gt)
+    assert trans_err < 0.05 and rot_err < 0.035
+    ref = O.Grid(tgt, O.default_params(resolution=1.0, max_iterations=50, trans_epsilon=1e-4, step_size=0.1)).align(src, guess)
+    dt, dr = S.pose_error(T, ref["T"])
+    assert dt < ALIGN_TOL_M and dr < ALIGN_TOL_RAD
+
+
+# ---------------------------------------------------------------------------------------
+# configuration-level parity
+# ---------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def c2(S):
+    return S.config_c2()
+
+
+@pytest.mark.parametrize("name", ["c1", "c2"])
+def test_config_parity(pkg, O, S, c2, name):
+    cfg = S.config_c1() if name == "c1" else c2
+    res = float(cfg["resolution"])
+    prm = O.default_params(resolution=res, step_size=0.1, trans_epsilon=1e-4, max_iterations=35, num_threads=8)
+    grid = O.Grid(cfg["target"], prm)
+    ndt = make_ndt(pkg, resolution=res, max_iterations=35)
+    ndt.setInputTarget(cfg["target"])
+    assert_leaves_match(ndt.getLeaves(), grid.export())
+    ndt.setInputSource(cfg["source"])
+    p0 = O.matrix_to_pose(cfg["guess"])
+    poses = np.stack([p0, p0 + [0.05, -0.03, 0.02, 0.01, -0.005, 0.008], O.matrix_to_pose(cfg["gt"])])
+    for p, e in zip(poses, ndt.evalDerivatives(poses)):
+        assert_derivs_match(e, grid.derivatives(cfg["source"], p))
+    # single-pose launch path (kernel-argument pose) must agree with the batched one bit for bit
+    e1 = ndt.evalDerivatives(poses[1])[0]
+    eb = ndt.evalDerivatives(poses)[1]
+    assert e1["score"] == eb["score"] and np.array_equal(e1["hessian"], eb["hessian"])
+    T = ndt.align(cfg["guess"])
+    r = ndt.getResult()
+    ref = grid.align(cfg["source"], cfg["guess"])
+    assert r["converged"] and ref["converged"]
+    dt, dr = S.pose_error(T, ref["T"])
+    assert dt < ALIGN_TOL_M and dr < ALIGN_TOL_RAD, (dt, dr)
+    gt_t, gt_r = S.pose_error(T, cfg["gt"])
+    assert gt_t < 0.05 and gt_r < 0.035
+    # covariance the drivers derive from the result: -(H + 1e-6 I)^-1 (ref: run/pipeline.cpp:594-596)
+    cov = -np.linalg.inv(r["hessian"] + 1e-6 * np.eye(6))
+    cov_ref = -np.linalg.inv(ref["hessian"] + 1e-6 * np.eye(6))
+    assert np.linalg.norm(cov - cov_ref) < 1e-2 * np.linalg.norm(cov_ref)
+    # output cloud of align(): source transformed by the result
+    out = ndt.transformSource(T)
+    expect = S.transform(T, cfg["source"])
+    assert np.abs(out - expect).max() < 1e-4
+
+
+def test_km_scale_coordinates(pkg, O, S):
+    """+3 km offset (NED-scale): exercises f32 index arithmetic and f64 statistics."""
+    cfg = S.config_c1()
+    off = np.array([3000.0, -2000.0, 100.0], np.float32)
+    tgt = (cfg["target"] + off).astype(np.float32)
+    shift = np.eye(4)
+    shift[:3, 3] = off
+    guess, gt = shift @ cfg["guess"], shift @ cfg["gt"]
+    prm = O.default_params(resolution=1.0, step_size=0.1, trans_epsilon=1e-4, max_iterations=50)
+    grid = O.Grid(tgt, prm)
+    ndt = make_ndt(pkg)
+    ndt.setInputTarget(tgt)
+    # the reference's single-pass covariance loses ~|mu|^2 eps / sigma^2 here: compare at 1e-4
+    assert_leaves_match(ndt.getLeaves(), grid.export(), cov_rtol=1e-6)
+    ndt.setInputSource(cfg["source"])
+    p = O.matrix_to_pose(guess)
+    assert_derivs_match(ndt.evalDerivatives(p)[0], grid.derivatives(cfg["source"], p), tol=1e-5)
+    T = ndt.align(guess)
+    ref = grid.align(cfg["source"], guess)
+    dt, dr = S.pose_error(T, ref["T"])
+    assert dt < ALIGN_TOL_M and dr < ALIGN_TOL_RAD
+    assert S.pose_error(T, gt)[0] < 0.05
+
+
+def test_parameter_variants(pkg, O, S):
+    cfg = S.config_c1()
+    p = O.matrix_to_pose(cfg["guess"])
+    for kw, okw in (
+        (dict(resolution=2.0), dict(resolution=2.0)),
+        (dict(resolution=0.5, min_points_per_voxel=3), dict(resolution=0.5, min_points_per_voxel=3)),
+        (dict(cov_mode=1), dict(cov_mode=1)),
+        (dict(outlier_ratio=0.3), dict(outlier_ratio=0.3)),
+        (dict(search_method=3), dict(search_method=1)),
+        (dict(hessian_mode=1, add_ridge=1), dict(hessian_mode=1, add_ridge=1)),
+        (dict(eig_inflation_ratio=0.1), dict(eig_inflation_ratio=0.1)),
+    ):
+        grid = O.Grid(cfg["target"], O.default_params(**okw))
+        ndt = make_ndt(pkg, **kw)
+        ndt.setInputTarget(cfg["target"])
+        ndt.setInputSource(cfg["source"])
+        assert_leaves_match(ndt.getLeaves(), grid.export())
+        assert_derivs_match(ndt.evalDerivatives(p)[0], grid.derivatives(cfg["source"], p))
+        ndt.close()
+
+
+def test_regularization_and_fixed_step(pkg, O, S):
+    cfg = S.config_c1()
+    reg_pose = cfg["gt"] @ S.pose_matrix(0.05, 0.0, 0.0, 0, 0, 0)
+    kw = dict(resolution=1.0, step_size=0.1, trans_epsilon=1e-4, max_iterations=40)
+    oprm = O.default_params(use_regularization=1, regularization_scale_factor=0.01,
+                            regularization_pose=reg_pose, use_line_search=0, **kw)
+    grid = O.Grid(cfg["target"], oprm)
+    ndt = make_ndt(pkg, use_line_search=0, **{k: v for k, v in kw.items() if k != "resolution"})
+    ndt.setRegularizationScaleFactor(0.01)
+    ndt.setRegularizationPose(reg_pose)
+    ndt.setInputTarget(cfg["target"])
+    ndt.setInputSource(cfg["source"])
+    p = O.matrix_to_pose(cfg["guess"])
+    assert_derivs_match(ndt.evalDerivatives(p)[0], grid.derivatives(cfg["source"], p))
+    T = ndt.align(cfg["guess"])
+    ref = grid.align(cfg["source"], cfg["guess"])
+    dt, dr = S.pose_error(T, ref["T"])
+    assert dt < ALIGN_TOL_M and dr < ALIGN_TOL_RAD
+    assert ndt.getFinalNumIteration() == ref["iterations"]
+
+
+# ---------------------------------------------------------------------------------------
+# edge cases (empty, ragged, non-finite, no overlap, input layouts)
+# ---------------------------------------------------------------------------------------
+def test_edge_cases(pkg, O, S):
+    cfg = S.config_c1()
+    ndt = make_ndt(pkg)
+    # align before any cloud: loud status, prior returned
+    with pytest.raises(pkg.NdtError) as ei:
+        ndt.align(cfg["guess"])
+    assert ei.value.code == -4
+    # empty target / target without a valid voxel
+    with pytest.raises(pkg.NdtError):
+        ndt.setInputTarget(np.zeros((0, 3), np.float32))
+    ndt.setInputTarget(np.random.default_rng(0).uniform(-50, 50, (200, 3)).astype(np.float32))
+    assert ndt.getGridInfo()["n_leaves"] == 0
+    ndt.setInputSource(cfg["source"])
+    with pytest.raises(pkg.NdtError) as ei:
+        ndt.align(cfg["guess"])
+    assert ei.value.code == -4
+    # non-finite points in both clouds are skipped exactly as the oracle skips them
+    tgt = cfg["target"].copy()
+    tgt[::17] = np.nan
+    tgt[5::29, 1] = np.inf
+    src = cfg["source"].copy()
+    src[3::11, 2] = np.nan
+    grid = O.Grid(tgt, O.default_params(resolution=1.0))
+    ndt.setInputTarget(tgt)
+    assert_leaves_match(ndt.getLeaves(), grid.export())
+    ndt.setInputSource(src)
+    p = O.matrix_to_pose(cfg["guess"])
+    assert_derivs_match(ndt.evalDerivatives(p)[0], grid.derivatives(src, p))
+    # no overlap: zero score, zero iterations, converged like the oracle
+    far = S.pose_matrix(500.0, 0, 0, 0, 0, 0)
+    e = ndt.evalDerivatives(O.matrix_to_pose(far))[0]
+    assert e["n_pairs"] == 0 and e["score"] == 0.0 and not e["gradient"].any()
+    ndt.align(far)
+    assert ndt.getFinalNumIteration() == 0
+    # ragged sizes: 1 point, 63, 64, 65, 257 points
+    for n in (1, 63, 64, 65, 257):
+        ndt.setInputSource(cfg["source"][:n])
+        assert_derivs_match(ndt.evalDerivatives(p)[0], grid.derivatives(cfg["source"][:n], p))
+    # grid overflow guard (ref: voxel_grid_covariance_impl.hpp:108-125)
+    huge = np.array([[0, 0, 0], [4e6, 4e6, 4e6]], np.float32)
+    tiny = make_ndt(pkg, resolution=0.01)
+    with pytest.raises(pkg.NdtError) as ei:
+        tiny.setInputTarget(huge)
+    assert ei.value.code == -6
+
+
+def test_input_layouts_agree(pkg, S):
+    """packed xyz, PCL-style 32-byte AoS (PointXYZI) and SoA inputs give identical results."""
+    cfg = S.config_c1()
+    ndt = make_ndt(pkg)
+
+    def run():
+        return ndt.getLeaves(), ndt.evalDerivatives([0.4, 0.0, 0.3, 0.0, 0.05, 0.2])[0]
+
+    ndt.setInputTarget(cfg["target"]); ndt.setInputSource(cfg["source"])
+    L0, e0 = run()
+    aos_t = np.zeros((len(cfg["target"]), 8), np.float32); aos_t[:, :3] = cfg["target"]; aos_t[:, 4] = 7.0
+    aos_s = np.zeros((len(cfg["source"]), 8), np.float32); aos_s[:, :3] = cfg["source"]
+    ndt.setInputTarget(aos_t); ndt.setInputSource(aos_s)
+    L1, e1 = run()
+    ndt.setInputTargetSoA(*cfg["target"].T); ndt.setInputSourceSoA(*cfg["source"].T)
+    L2, e2 = run()
+    for L, e in ((L1, e1), (L2, e2)):
+        assert np.array_equal(L["cell"], L0["cell"]) and np.array_equal(L["cov"], L0["cov"])
+        assert e["score"] == e0["score"] and np.array_equal(e["hessian"], e0["hessian"])
+
+
+def test_set_resolution_rebuilds_target(pkg, O, S):
+    """setResolution on a loaded target re-voxelises it (ref: svn_ndt_impl.hpp:162-176)."""
+    cfg = S.config_c1()
+    ndt = make_ndt(pkg, resolution=1.0)
+    ndt.setInputTarget(cfg["target"])
+    n1 = ndt.getGridInfo()["n_leaves"]
+    ndt.setResolution(2.0)
+    grid = O.Grid(cfg["target"], O.default_params(resolution=2.0))
+    assert ndt.getGridInfo()["n_leaves"] == grid.n_leaves != n1
+    assert_leaves_match(ndt.getLeaves(), grid.export())
+
+
+# ---------------------------------------------------------------------------------------
+# full-size workload (C3: 200k -> 1M, 0.5 m): size-independent properties + oracle spot checks
+# ---------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def c3(S):
+    return S.config_c3()
+
+
+@pytest.fixture(scope="module")
+def c3_ndt(pkg, c3):
+    ndt = make_ndt(pkg, resolution=0.5, max_iterations=35)
+    ndt.setInputTarget(c3["target"])
+    ndt.setInputSource(c3["source"])
+    return ndt
+
+
+def test_full_size_leaves_and_derivatives_vs_oracle(pkg, O, S, c3, c3_ndt):
+    prm = O.default_params(resolution=0.5, step_size=0.1, trans_epsilon=1e-4, max_iterations=35, num_threads=16)
+    grid = O.Grid(c3["target"], prm)
+    assert_leaves_match(c3_ndt.getLeaves(), grid.export())
+    p = O.matrix_to_pose(c3["guess"])
+    assert_derivs_match(c3_ndt.evalDerivatives(p)[0], grid.derivatives(c3["source"], p))
+    T = c3_ndt.align(c3["guess"])
+    ref = grid.align(c3["source"], c3["guess"])
+    dt, dr = S.pose_error(T, ref["T"])
+    assert dt < ALIGN_TOL_M and dr < ALIGN_TOL_RAD, (dt, dr)
+    assert S.pose_error(T, c3["gt"])[0] < 0.05
+
+
+def test_full_size_determinism_and_idempotence(pkg, O, c3, c3_ndt):
+    p = O.matrix_to_pose(c3["guess"])
+    a = c3_ndt.evalDerivatives(p)[0]
+    b = c3_ndt.evalDerivatives(p)[0]
+    assert a["score"] == b["score"] and np.array_equal(a["gradient"], b["gradient"]) and np.array_equal(a["hessian"], b["hessian"])
+    T1 = c3_ndt.align(c3["guess"]); r1 = c3_ndt.getResult()
+    T2 = c3_ndt.align(c3["guess"]); r2 = c3_ndt.getResult()
+    assert np.array_equal(T1, T2) and r1["iterations"] == r2["iterations"] and r1["n_evaluations"] == r2["n_evaluations"]
+    L1 = c3_ndt.getLeaves()
+    c3_ndt.setInputTarget(c3["target"])  # rebuild: bit-identical statistics
+    L2 = c3_ndt.getLeaves()
+    for k in ("cell", "count", "mean", "cov", "icov"):
+        assert np.array_equal(L1[k], L2[k]), k
+
+
+def test_full_size_linearity_over_shards(pkg, O, c3, c3_ndt):
+    """The evaluation is a sum over source points: shards add up, order does not matter."""
+    p = O.matrix_to_pose(c3["guess"])
+    full = c3_ndt.evalDerivatives(p)[0]
+    src = c3["source"]
+    for world in (2, 3, 8):
+        acc = None
+        for r in range(world):
+            b, c = pkg.shard_range(len(src), r, world)
+            c3_ndt.setInputSource(src[b:b + c])
+            e = c3_ndt.evalDerivatives(p)[0]
+            acc = e if acc is None else {k: acc[k] + e[k] for k in e}
+        assert acc["n_pairs"] == full["n_pairs"] and acc["n_with_neighbors"] == full["n_with_neighbors"]
+        assert acc["score"] == pytest.approx(full["score"], rel=1e-12)
+        assert np.linalg.norm(acc["hessian"] - full["hessian"]) < 1e-11 * np.linalg.norm(full["hessian"])
+    perm = np.random.default_rng(0).permutation(len(src))
+    c3_ndt.setInputSource(src[perm])
+    e = c3_ndt.evalDerivatives(p)[0]
+    assert e["n_pairs"] == full["n_pairs"]
+    assert np.linalg.norm(e["hessian"] - full["hessian"]) < 1e-11 * np.linalg.norm(full["hessian"])
+    c3_ndt.setInputSource(src)
+
+
+def test_full_size_leaf_invariants(c3_ndt):
+    """Checksum-of-checksums style invariants of the voxel table."""
+    L = c3_ndt.getLeaves()
+    gi = c3_ndt.getGridInfo()
+    assert len(L["cell"]) == gi["n_leaves"] > 1000
+    assert (np.diff(L["cell"]) > 0).all()                       # sorted, unique
+    assert (L["count"] >= 6).all() and L["count"].sum() <= gi["n_target_points"]
+    assert np.abs(L["mean"] - L["center"]).max() <= 0.25 + 1e-4  # mean inside its voxel (leaf/2)
+    eye = np.einsum("nij,njk->nik", L["cov"], L["icov"])
+    assert np.abs(eye - np.eye(3)).max() < 1e-6
+    ev = L["evals"]
+    assert (ev[:, 0] <= ev[:, 1] + 1e-15).all() and (ev[:, 1] <= ev[:, 2] + 1e-15).all()
+    assert (ev[:, 0] >= 0.01 * ev[:, 2] * (1 - 1e-9)).all()      # inflation floor (ref :311-323)
