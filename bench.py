@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""NDT align() benchmark on MI355X -- the metric of BASELINE.json.
+
+A "step" is one scan registration of workload C3 (a 200 000-point scan into a
+1 000 000-point voxelised submap, 0.5 m voxels, DIRECT7): setInputTarget (voxel-grid
+build) + setInputSource + align(), with both clouds already resident in HBM when the
+timed region starts.  `value` = Newton iterations / wall second over the K timed steps
+(build time included), whole job.  With N > 1 (one process per GPU under
+torch.distributed.run) the target is replicated, the source is sharded and every
+derivative evaluation ends in one 256-byte all-reduce (RCCL over xGMI by default,
+NDT_BENCH_REDUCE=shm for the shared-memory reducer): strong scaling.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (k_derivatives):
+algorithmic bytes per launch = N_src * (12 + 7*4 + nbar*48) over its mean
+HIP-event duration, measured in an instrumented repeat of the timed steps.  `cpu_baseline`
+is the CPU oracle (OpenMP, all host cores) on a bounded sample of the same steps -- a
+reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402  (device buffers + torch.distributed plumbing)
+import torch.distributed as dist  # noqa: E402
+
+import __graft_entry__ as ge  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+ALGO_BYTES_PER_POINT = lambda nbar: 12.0 + 7 * 4.0 + nbar * 48.0  # noqa: E731  SURVEY.md section 8(d)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, params, seconds):
+    """The oracle timed on this box's host cores; step = grid build + align, like the GPU step."""
+    O = ge.load_oracle()
+    O.build()
+    # a 1-GPU box gives this job a 16-CPU share (more threads only oversubscribe it)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, int(os.environ.get("NDT_BENCH_CPU_THREADS", "16"))))
+    prm = O.default_params(num_threads=cores, **params)
+    iters, steps, t_build, t_align = 0, 0, 0.0, 0.0
+    t0 = time.perf_counter()
+    while True:
+        ta = time.perf_counter()
+        grid = O.Grid(cfg["target"], prm)
+        tb = time.perf_counter()
+        r = grid.align(cfg["source"], cfg["guess"])
+        tc = time.perf_counter()
+        iters += r["iterations"]
+        steps += 1
+        t_build += tb - ta
+        t_align += tc - tb
+        if (tc - t0 >= seconds and steps >= 2) or steps >= 200:
+            break
+    wall = time.perf_counter() - t0
+    return {"value": iters / wall, "unit": "iterations/s", "cores": cores, "kind": "port",
+            "sample": "%d full steps (oracle grid build + align) of the same C3 workload, %.1f s, OpenMP %d threads"
+                      % (steps, wall, cores),
+            "ms_per_step": 1e3 * wall / steps, "ms_build": 1e3 * t_build / steps,
+            "ms_align": 1e3 * t_align / steps, "iterations_per_step": iters / steps}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    pkg = ge.load_package()
+    S = pkg.synth
+    cfg = S.config_c3()
+    params = dict(resolution=float(cfg["resolution"]), step_size=0.1, trans_epsilon=1e-4, max_iterations=35)
+    n_src_total = len(cfg["source"])
+    b, c = pkg.shard_range(n_src_total, rank, world)
+
+    # inputs resident in HBM before the timed region (SoA float32)
+    tgt = [torch.from_numpy(np.ascontiguousarray(cfg["target"][:, a])).to(dev) for a in range(3)]
+    src = [torch.from_numpy(np.ascontiguousarray(cfg["source"][b:b + c, a])).to(dev) for a in range(3)]
+    torch.cuda.synchronize()
+
+    ndt = pkg.NormalDistributionsTransform(device_id=local_rank, **params)
+    reduce_mode = "none"
+    if world > 1:
+        reduce_mode = os.environ.get("NDT_BENCH_REDUCE", "rccl")
+        if reduce_mode == "rccl":
+            box = [pkg.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            ndt.commInitRccl(box[0], rank, world)
+        elif reduce_mode == "shm":
+            box = ["/ndt_bench_%d" % os.getpid() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            ndt.commInitShm(box[0], rank, world)
+        else:
+            raise SystemExit("NDT_BENCH_REDUCE must be rccl or shm")
+        ndt.setGlobalSourceSize(n_src_total)
+
+    def step():
+        t0 = time.perf_counter()
+        ndt.setInputTargetDevice(tgt[0].data_ptr(), tgt[1].data_ptr(), tgt[2].data_ptr(), len(cfg["target"]))
+        t1 = time.perf_counter()
+        ndt.setInputSourceDevice(src[0].data_ptr(), src[1].data_ptr(), src[2].data_ptr(), c)
+        ndt.align(cfg["guess"])
+        t2 = time.perf_counter()
+        r = ndt.getResult()
+        return r, t1 - t0, t2 - t1
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    iters = evals = 0
+    t_build = t_align = 0.0
+    for _ in range(args.steps):
+        r, tb, ta = step()
+        iters += r["iterations"]
+        evals += r["n_evaluations"]
+        t_build += tb
+        t_align += ta
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # instrumented repeat: HIP events around k_derivatives on the engine's own stream
+    ndt.enableKernelTiming(True)
+    tm0 = ndt.getTiming()
+    for _ in range(args.steps):
+        r, _, _ = step()
+    tm1 = ndt.getTiming()
+    ndt.enableKernelTiming(False)
+    n_timed = tm1["n_timed_evals"] - tm0["n_timed_evals"]
+    ms_kernel = (tm1["ms_eval_kernel_total"] - tm0["ms_eval_kernel_total"]) / max(n_timed, 1)
+    ms_reduce = (tm1["ms_reduce_kernel_total"] - tm0["ms_reduce_kernel_total"]) / max(n_timed, 1)
+    gi = ndt.getGridInfo()
+    nbar = r["n_pairs"] / float(n_src_total)          # global pairs / global points (last evaluation)
+    algo_bytes = c * ALGO_BYTES_PER_POINT(nbar)       # this rank's launch
+    achieved = algo_bytes / (ms_kernel * 1e-3) / 1e9 if ms_kernel > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_k_derivatives.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    final = ndt.getResult()
+    err_t, err_r = S.pose_error(final["T"], cfg["gt"])
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "ndt_align_iterations_per_sec", "value": iters / elapsed, "unit": "iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C3 scan-to-map: 200k-pt source into 1M-pt voxelised submap, 0.5 m voxel, DIRECT7, "
+                                   "outlier 0.55, eps 1e-4, step 0.1, max 35 it; step = voxel-grid build + align",
+                       "n_source": n_src_total, "n_target": len(cfg["target"]), "voxels": int(gi["n_leaves"]),
+                       "grid_cells": int(gi["n_cells"]), "mean_neighbors": nbar, "sharding": "source/%d" % world,
+                       "reduce": reduce_mode},
+            "ms_scan": 1e3 * elapsed / args.steps, "ms_target_build": 1e3 * t_build / args.steps,
+            "ms_align": 1e3 * t_align / args.steps, "ms_target_build_device": gi["ms_build"],
+            "iterations_per_align": iters / args.steps, "evaluations_per_align": evals / args.steps,
+            "align_only_iterations_per_sec": iters / t_align, "evaluations_per_sec": evals / t_align,
+            "final_error_vs_ground_truth": {"m": err_t, "rad": err_r},
+            "roofline": {"bound": "hbm", "kernel": "k_derivatives", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": algo_bytes, "ms_per_launch": ms_kernel,
+                         "ms_final_reduce": ms_reduce, "launches_timed": int(n_timed)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, params, args.cpu_seconds)
+    if world > 1:
+        ndt.commDestroy()
+        dist.barrier()
+        dist.destroy_process_group()
+    ndt.close()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

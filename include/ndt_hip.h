@@ -228,7 +228,9 @@ typedef struct ndt_timing {
   double ms_last_reduce_kernel;
   double ms_last_build;
   int64_t n_eval_launches;      /* since handle creation */
-  double ms_eval_kernel_total;  /* summed HIP-event time of derivative kernels when timing is on */
+  double ms_eval_kernel_total;  /* summed HIP-event time of the accumulation kernel while timing is on */
+  double ms_reduce_kernel_total;
+  int64_t n_timed_evals;        /* evaluations covered by the two totals */
 } ndt_timing;
 int ndt_enable_kernel_timing(ndt_handle* h, int on);
 int ndt_get_timing(const ndt_handle* h, ndt_timing* out);

@@ -79,7 +79,8 @@ class Timing(C.Structure):
     _fields_ = [
         ("ms_last_eval_kernel", C.c_double), ("ms_last_reduce_kernel", C.c_double),
         ("ms_last_build", C.c_double), ("n_eval_launches", C.c_int64),
-        ("ms_eval_kernel_total", C.c_double),
+        ("ms_eval_kernel_total", C.c_double), ("ms_reduce_kernel_total", C.c_double),
+        ("n_timed_evals", C.c_int64),
     ]
 
 
@@ -396,8 +397,10 @@ class NormalDistributionsTransform:
     def getTiming(self):
         t = Timing()
         self._check(lib().ndt_get_timing(self._h, C.byref(t)))
-        return dict(ms_last_eval_kernel=t.ms_last_eval_kernel, ms_last_build=t.ms_last_build,
-                    n_eval_launches=t.n_eval_launches, ms_eval_kernel_total=t.ms_eval_kernel_total)
+        return dict(ms_last_eval_kernel=t.ms_last_eval_kernel, ms_last_reduce_kernel=t.ms_last_reduce_kernel,
+                    ms_last_build=t.ms_last_build, n_eval_launches=t.n_eval_launches,
+                    ms_eval_kernel_total=t.ms_eval_kernel_total,
+                    ms_reduce_kernel_total=t.ms_reduce_kernel_total, n_timed_evals=t.n_timed_evals)
 
 
 def comm_unique_id():

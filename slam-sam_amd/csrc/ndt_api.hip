@@ -291,8 +291,8 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
   double* d_out = dev_out ? h->dres.p : h->result.d;
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, s));
   launch_derivatives(h->sx.p, h->sy.p, h->sz.p, h->n_src, h->geom, h->cell2leaf.p, h->rec.p, pc,
-                     nullptr, 1, ec, h->partials.p, d_out, s);
-  if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, s));
+                     nullptr, 1, ec, h->partials.p, d_out, s, h->timing ? h->ev1 : nullptr);
+  if (h->timing) HIP_TRY(h, hipEventRecord(h->ev2, s));
   if (dev_out) {
     int rc = h->red.allreduce_device(h->dres.p, EV_WORDS, s, &h->err);
     if (rc) return rc;
@@ -301,10 +301,14 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
   HIP_TRY(h, hipStreamSynchronize(s));
   h->tm.n_eval_launches++;
   if (h->timing) {
-    float ms = 0;
+    float ms = 0, ms2 = 0;
     HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    HIP_TRY(h, hipEventElapsedTime(&ms2, h->ev1, h->ev2));
     h->tm.ms_last_eval_kernel = ms;
+    h->tm.ms_last_reduce_kernel = ms2;
     h->tm.ms_eval_kernel_total += ms;
+    h->tm.ms_reduce_kernel_total += ms2;
+    h->tm.n_timed_evals++;
   }
   double words[EV_WORDS];
   std::memcpy(words, h->result.h, sizeof(words));
@@ -566,8 +570,8 @@ int ndt_eval_derivatives(ndt_handle* h, const double* poses6, const float* trans
   HIP_TRY(h, hipMemcpyAsync(h->dposes.p, h->hposes.h, (size_t)K * sizeof(PoseConsts), hipMemcpyHostToDevice, s));
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, s));
   launch_derivatives(h->sx.p, h->sy.p, h->sz.p, h->n_src, h->geom, h->cell2leaf.p, h->rec.p,
-                     h->hposes.h[0], h->dposes.p, K, ec, h->partials.p, h->dres.p, s);
-  if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, s));
+                     h->hposes.h[0], h->dposes.p, K, ec, h->partials.p, h->dres.p, s,
+                     h->timing ? h->ev1 : nullptr);
   if (h->red.wants_device_buffer()) {
     rc = h->red.allreduce_device(h->dres.p, K * EV_WORDS, s, &h->err);
     if (rc) return rc;
@@ -580,6 +584,7 @@ int ndt_eval_derivatives(ndt_handle* h, const double* poses6, const float* trans
     HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->tm.ms_last_eval_kernel = ms;
     h->tm.ms_eval_kernel_total += ms;
+    h->tm.n_timed_evals++;
   }
   std::memcpy(out, h->result.h, (size_t)K * EV_WORDS * sizeof(double));
   if (!h->red.wants_device_buffer() && h->red.mode() != NDT_REDUCE_NONE) {

@@ -276,7 +276,8 @@ int derivs_grid_blocks(size_t n_src) {
 void launch_derivatives(const float* sx, const float* sy, const float* sz, size_t n_src,
                         const GridGeom& g, const int* cell2leaf, const VoxelRecord* rec,
                         const PoseConsts& pose, const PoseConsts* d_poses, int K,
-                        const EvalConsts& ec, double* d_partials, double* d_out, hipStream_t s) {
+                        const EvalConsts& ec, double* d_partials, double* d_out, hipStream_t s,
+                        hipEvent_t ev_mid) {
   const int blocks = derivs_grid_blocks(n_src);
   if (d_poses) {
     hipLaunchKernelGGL(k_derivatives<true>, dim3(blocks, K), dim3(BLOCK), 0, s, sx, sy, sz,
@@ -286,6 +287,7 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
                        (int)n_src, g, cell2leaf, rec, pose, d_poses, ec, d_partials);
     K = 1;
   }
+  if (ev_mid) (void)hipEventRecord(ev_mid, s);
   hipLaunchKernelGGL(k_final_reduce, dim3(K), dim3(256), 0, s, d_partials, blocks, d_out);
 }
 

@@ -38,10 +38,13 @@ int derivs_grid_blocks(size_t n_src);
 // d_partials: K * blocks * EV_WORDS doubles; d_out: K * EV_WORDS doubles
 // (device memory or device-mapped pinned host memory).  If d_poses is null the
 // single pose `pose` is passed as a kernel argument.
+// ev_mid (optional) is recorded between the accumulation kernel and the final
+// reduction so the dominant kernel can be timed on its own.
 void launch_derivatives(const float* sx, const float* sy, const float* sz, size_t n_src,
                         const GridGeom& g, const int* cell2leaf, const VoxelRecord* rec,
                         const PoseConsts& pose, const PoseConsts* d_poses, int K,
-                        const EvalConsts& ec, double* d_partials, double* d_out, hipStream_t s);
+                        const EvalConsts& ec, double* d_partials, double* d_out, hipStream_t s,
+                        hipEvent_t ev_mid = nullptr);
 
 void launch_transform(const float* sx, const float* sy, const float* sz, size_t n,
                       const PoseConsts& pose, float* out_xyz, hipStream_t s);
