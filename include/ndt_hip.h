@@ -225,7 +225,7 @@ int ndt_set_global_source_size(ndt_handle* h, int64_t n_total);
 /* ---- instrumentation ------------------------------------------------------ */
 typedef struct ndt_timing {
   double ms_last_eval_kernel;   /* HIP-event time of the last derivative kernel */
-  double ms_last_reduce_kernel;
+  double ms_last_reduce_kernel; /* 0 since the final sum moved into the derivative kernel */
   double ms_last_build;
   int64_t n_eval_launches;      /* since handle creation */
   double ms_eval_kernel_total;  /* summed HIP-event time of the accumulation kernel while timing is on */

@@ -78,7 +78,6 @@ struct ndt_handle {
   bool have_grid = false;
   GridGeom geom{};
   int max_b[3] = {0, 0, 0};
-  DevBuf<int> bounds;                // 8 ints
   DevBuf<uint32_t> keys, vals, keys2, vals2;
   DevBuf<char> sort_tmp;
   DevBuf<int> nleaf;                 // [0] slots, [1] valid
@@ -99,6 +98,8 @@ struct ndt_handle {
   PinBuf<double> result;             // evaluation results (K * EV_WORDS)
   PinBuf<int> small;                 // bounds / counters read-back
   DevBuf<double> partials, dres;
+  DevBuf<unsigned int> counters;     // per-pose tickets of the in-kernel final reduction
+  size_t counters_zeroed = 0;
   DevBuf<PoseConsts> dposes;
   PinBuf<PoseConsts> hposes;
 
@@ -179,12 +180,12 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
   if (n == 0) return fail(h, NDT_ERR_NO_TARGET, "empty target cloud");
   if (n > (size_t)std::numeric_limits<int>::max() / 2) return fail(h, NDT_ERR_INVALID_ARG, "target too large");
   hipStream_t s = h->stream;
-  HIP_TRY(h, h->bounds.ensure(8));
-  HIP_TRY(h, h->small.ensure(16));
+  const int nrows = bounds_rows(n);
+  HIP_TRY(h, h->small.ensure(16 + 8 * (size_t)nrows));
   HIP_TRY(h, hipEventRecord(h->ev0, s));
-  launch_bounds(x, y, z, n, h->bounds.p, s);
-  HIP_TRY(h, hipMemcpyAsync(h->small.h, h->bounds.p, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
+  launch_bounds(x, y, z, n, h->small.d + 16, s);  // rows land in pinned host memory
   HIP_TRY(h, hipStreamSynchronize(s));
+  fold_bounds(h->small.h + 16, nrows, h->small.h);
   if (h->small.h[6] == 0) return fail(h, NDT_ERR_NO_TARGET, "target has no finite point");
 
   // grid geometry in f32, as the reference computes it
@@ -271,6 +272,14 @@ EvalConsts make_eval_consts(const ndt_handle* h, bool need_h) {
   return ec;
 }
 
+int ensure_counters(ndt_handle* h, size_t k) {
+  if (k <= h->counters_zeroed) return NDT_OK;
+  HIP_TRY(h, h->counters.ensure(k));
+  HIP_TRY(h, hipMemsetAsync(h->counters.p, 0, h->counters.cap * sizeof(unsigned int), h->stream));
+  h->counters_zeroed = h->counters.cap;
+  return NDT_OK;
+}
+
 int ready_for_eval(ndt_handle* h) {
   if (!h->have_grid || h->n_valid <= 0) return fail(h, NDT_ERR_NO_TARGET, "no target voxel grid (setInputTarget first)");
   if (h->n_src == 0 && h->red.mode() == NDT_REDUCE_NONE) return fail(h, NDT_ERR_NO_SOURCE, "no source cloud (setInputSource first)");
@@ -283,16 +292,19 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
   PoseConsts pc;
   fill_pose_consts(p, T, &pc);
   const EvalConsts ec = make_eval_consts(h, need_h);
-  const int blocks = derivs_grid_blocks(h->n_src);
-  HIP_TRY(h, h->partials.ensure((size_t)blocks * EV_WORDS));
+  HIP_TRY(h, h->partials.ensure(derivs_partials_words(h->n_src, 1)));
   HIP_TRY(h, h->result.ensure(EV_WORDS));
   const bool dev_out = h->red.wants_device_buffer();
   if (dev_out) HIP_TRY(h, h->dres.ensure(EV_WORDS));
+  {
+    int rc = ensure_counters(h, (size_t)derivs_counters_per_pose());
+    if (rc) return rc;
+  }
   double* d_out = dev_out ? h->dres.p : h->result.d;
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, s));
   launch_derivatives(h->sx.p, h->sy.p, h->sz.p, h->n_src, h->geom, h->cell2leaf.p, h->rec.p, pc,
-                     nullptr, 1, ec, h->partials.p, d_out, s, h->timing ? h->ev1 : nullptr);
-  if (h->timing) HIP_TRY(h, hipEventRecord(h->ev2, s));
+                     nullptr, 1, ec, h->partials.p, h->counters.p, d_out, s);
+  if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, s));
   if (dev_out) {
     int rc = h->red.allreduce_device(h->dres.p, EV_WORDS, s, &h->err);
     if (rc) return rc;
@@ -301,13 +313,10 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
   HIP_TRY(h, hipStreamSynchronize(s));
   h->tm.n_eval_launches++;
   if (h->timing) {
-    float ms = 0, ms2 = 0;
+    float ms = 0;
     HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-    HIP_TRY(h, hipEventElapsedTime(&ms2, h->ev1, h->ev2));
     h->tm.ms_last_eval_kernel = ms;
-    h->tm.ms_last_reduce_kernel = ms2;
     h->tm.ms_eval_kernel_total += ms;
-    h->tm.ms_reduce_kernel_total += ms2;
     h->tm.n_timed_evals++;
   }
   double words[EV_WORDS];
@@ -400,12 +409,12 @@ int ndt_destroy(ndt_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   h->red.destroy();
   h->tx.release(); h->ty.release(); h->tz.release();
-  h->bounds.release(); h->keys.release(); h->vals.release(); h->keys2.release(); h->vals2.release();
+  h->keys.release(); h->vals.release(); h->keys2.release(); h->vals2.release();
   h->sort_tmp.release(); h->nleaf.release(); h->leaf_start.release(); h->leaf_cnt.release();
   h->cell2leaf.release(); h->rec.release(); h->stats.release();
   h->sx.release(); h->sy.release(); h->sz.release();
   h->stage.release(); h->result.release(); h->small.release(); h->partials.release();
-  h->dres.release(); h->dposes.release(); h->hposes.release();
+  h->dres.release(); h->dposes.release(); h->hposes.release(); h->counters.release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->ev2) (void)hipEventDestroy(h->ev2);
@@ -563,15 +572,16 @@ int ndt_eval_derivatives(ndt_handle* h, const double* poses6, const float* trans
     fill_pose_consts(poses6 + 6 * (size_t)k, Tk, &h->hposes.h[k]);
   }
   const EvalConsts ec = make_eval_consts(h, compute_hessian != 0);
-  const int blocks = derivs_grid_blocks(h->n_src);
-  HIP_TRY(h, h->partials.ensure((size_t)K * blocks * EV_WORDS));
+  HIP_TRY(h, h->partials.ensure(derivs_partials_words(h->n_src, K)));
   HIP_TRY(h, h->result.ensure((size_t)K * EV_WORDS));
   HIP_TRY(h, h->dres.ensure((size_t)K * EV_WORDS));
+  rc = ensure_counters(h, (size_t)K * derivs_counters_per_pose());
+  if (rc) return rc;
   HIP_TRY(h, hipMemcpyAsync(h->dposes.p, h->hposes.h, (size_t)K * sizeof(PoseConsts), hipMemcpyHostToDevice, s));
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, s));
   launch_derivatives(h->sx.p, h->sy.p, h->sz.p, h->n_src, h->geom, h->cell2leaf.p, h->rec.p,
-                     h->hposes.h[0], h->dposes.p, K, ec, h->partials.p, h->dres.p, s,
-                     h->timing ? h->ev1 : nullptr);
+                     h->hposes.h[0], h->dposes.p, K, ec, h->partials.p, h->counters.p, h->dres.p, s);
+  if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, s));
   if (h->red.wants_device_buffer()) {
     rc = h->red.allreduce_device(h->dres.p, K * EV_WORDS, s, &h->err);
     if (rc) return rc;

@@ -12,8 +12,10 @@
 //     gradient and Hessian is J^T (.) J of a 3-vector / symmetric 3x3, so a
 //     pair only accumulates  w += f v,  S += f (C - d2 v v^T)  (v = C (x'-mu));
 //     the 6-vector / 6x6 expansion happens once per POINT, not per pair;
-//   * 31 f64 accumulators per thread, wave64 shuffle reduction, LDS across the
-//     4 waves, one partial row per block, fixed-order final sum (deterministic).
+//   * 31 f64 accumulators per thread; recursive-halving reduce-scatter across the
+//     wave (32 cross-lane moves, not 32*6), LDS across the 4 waves, one partial row
+//     per block; the last-arriving block adds the rows in fixed order inside the
+//     same launch (agent-scope release/acquire), so results are bit-reproducible.
 // No MFMA: 3x3 / 6x6 work is not a dense contraction.
 // Compiled with -ffp-contract=off; the transform and the index arithmetic must
 // round exactly as written to classify points into the same voxels as the ref.
@@ -24,7 +26,6 @@ namespace ndt {
 namespace {
 
 constexpr int BLOCK = 256;
-constexpr int NACC = 31;  // EV_SCORE .. EV_NPAIRS
 
 // ref: voxel_grid_covariance_impl.hpp:46-71 (f32 bounds) +
 // voxel_grid_covariance.h:297-300 (index).  -1 = outside the grid.
@@ -52,6 +53,7 @@ struct PairAcc {
 // ref: svn_ndt_impl.hpp:401-447 (guards, exp, factor); accumulation refactored
 __device__ __forceinline__ void pair_update(PairAcc& a, const VoxelRecord& r, float xt, float yt,
                                             float zt, const EvalConsts& ec) {
+#pragma clang fp contract(fast)  // f64 accumulation may fuse; only the f32 transform / index math may not
   double x0 = (double)xt - r.mean[0], x1 = (double)yt - r.mean[1], x2 = (double)zt - r.mean[2];
   double v0 = r.icov[0] * x0 + r.icov[1] * x1 + r.icov[2] * x2;
   double v1 = r.icov[1] * x0 + r.icov[3] * x1 + r.icov[4] * x2;
@@ -84,50 +86,11 @@ __device__ __forceinline__ float dot3f(const float* m, float x, float y, float z
   return m[0] * x + m[1] * y + m[2] * z;
 }
 
-__device__ __forceinline__ void point_body(double acc[NACC], float x, float y, float z,
-                                           const GridGeom& g, const int* __restrict__ cell2leaf,
-                                           const VoxelRecord* __restrict__ rec, const PoseConsts& P,
-                                           const EvalConsts& ec) {
-  // x' = r0*x + (r1*y + (r2*z + t)), f32, unfused (transformPointCloud, ref :761)
-  float xt = P.R[0] * x + (P.R[1] * y + (P.R[2] * z + P.t[0]));
-  float yt = P.R[3] * x + (P.R[4] * y + (P.R[5] * z + P.t[1]));
-  float zt = P.R[6] * x + (P.R[7] * y + (P.R[8] * z + P.t[2]));
-  if (!(isfinite(xt) && isfinite(yt) && isfinite(zt))) return;  // ref :573
-
-  // ref: voxel_grid_covariance_impl.hpp:560-600 -- neighbours are found by
-  // offsetting the POINT by +-leaf in f32 and re-classifying it.
-  const float w = g.leaf;
-  int cell[7];
-  cell[0] = probe_cell(xt, yt, zt, g);
-  if (ec.direct7) {
-    cell[1] = probe_cell(xt + w, yt, zt, g);
-    cell[2] = probe_cell(xt - w, yt, zt, g);
-    cell[3] = probe_cell(xt, yt + w, zt, g);
-    cell[4] = probe_cell(xt, yt - w, zt, g);
-    cell[5] = probe_cell(xt, yt, zt + w, g);
-    cell[6] = probe_cell(xt, yt, zt - w, g);
-  } else {
-#pragma unroll
-    for (int k = 1; k < 7; ++k) cell[k] = -1;
-  }
-  int slot[7];
-#pragma unroll
-  for (int k = 0; k < 7; ++k) slot[k] = cell[k] >= 0 ? cell2leaf[cell[k]] : -1;
-
-  PairAcc a;
-  a.w[0] = a.w[1] = a.w[2] = 0.0;
-#pragma unroll
-  for (int k = 0; k < 6; ++k) a.S[k] = 0.0;
-  a.score = 0.0; a.best = 0.0; a.npairs = 0;
-#pragma unroll
-  for (int k = 0; k < 7; ++k) {
-    if (slot[k] >= 0) {
-      VoxelRecord r = rec[slot[k]];
-      pair_update(a, r, xt, yt, zt, ec);
-    }
-  }
-  if (a.npairs == 0) return;  // ref :592
-
+// Per-POINT expansion of the pair sums into the 6-gradient / 21 Hessian words:
+// g = J^T w,  H = J^T S J (+ w . d2x'/dp_i dp_j), J = [I | A(x)] (ref :339-396, :449-494).
+__device__ __forceinline__ void expand_point(double acc[EV_WORDS], const PairAcc& a, float x, float y,
+                                             float z, const PoseConsts& P, const EvalConsts& ec) {
+#pragma clang fp contract(fast)
   acc[EV_SCORE] += a.score;
   acc[EV_NVTL] += a.best;
   acc[EV_NWITH] += 1.0;
@@ -184,73 +147,188 @@ __device__ __forceinline__ void point_body(double acc[NACC], float x, float y, f
   H[15] += R33; H[16] += R34; H[17] += R35; H[18] += R44; H[19] += R45; H[20] += R55;
 }
 
-__device__ __forceinline__ void block_reduce_store(double acc[NACC], double* __restrict__ out_row) {
-  __shared__ double lds[BLOCK / 64][NACC + 1];
+__device__ __forceinline__ void point_body(double acc[EV_WORDS], float x, float y, float z,
+                                           const GridGeom& g, const int* __restrict__ cell2leaf,
+                                           const VoxelRecord* __restrict__ rec, const PoseConsts& P,
+                                           const EvalConsts& ec) {
+  // x' = r0*x + (r1*y + (r2*z + t)), f32, unfused (transformPointCloud, ref :761)
+  float xt = P.R[0] * x + (P.R[1] * y + (P.R[2] * z + P.t[0]));
+  float yt = P.R[3] * x + (P.R[4] * y + (P.R[5] * z + P.t[1]));
+  float zt = P.R[6] * x + (P.R[7] * y + (P.R[8] * z + P.t[2]));
+  if (!(isfinite(xt) && isfinite(yt) && isfinite(zt))) return;  // ref :573
+
+  // ref: voxel_grid_covariance_impl.hpp:560-600 -- neighbours are found by
+  // offsetting the POINT by +-leaf in f32 and re-classifying it.
+  const float w = g.leaf;
+  int cell[7];
+  cell[0] = probe_cell(xt, yt, zt, g);
+  if (ec.direct7) {
+    cell[1] = probe_cell(xt + w, yt, zt, g);
+    cell[2] = probe_cell(xt - w, yt, zt, g);
+    cell[3] = probe_cell(xt, yt + w, zt, g);
+    cell[4] = probe_cell(xt, yt - w, zt, g);
+    cell[5] = probe_cell(xt, yt, zt + w, g);
+    cell[6] = probe_cell(xt, yt, zt - w, g);
+  } else {
 #pragma unroll
-  for (int v = 0; v < NACC; ++v) {
-    double a = acc[v];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
-    acc[v] = a;
+    for (int k = 1; k < 7; ++k) cell[k] = -1;
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) {
+  int slot[7];
 #pragma unroll
-    for (int v = 0; v < NACC; ++v) lds[wave][v] = acc[v];
-  }
-  __syncthreads();
-  if (threadIdx.x < EV_WORDS) {
-    double sum = 0.0;
-    if (threadIdx.x < NACC) {
+  for (int k = 0; k < 7; ++k) slot[k] = cell[k] >= 0 ? cell2leaf[cell[k]] : -1;
+
+  PairAcc a;
+  a.w[0] = a.w[1] = a.w[2] = 0.0;
 #pragma unroll
-      for (int wv = 0; wv < BLOCK / 64; ++wv) sum += lds[wv][threadIdx.x];
+  for (int k = 0; k < 6; ++k) a.S[k] = 0.0;
+  a.score = 0.0; a.best = 0.0; a.npairs = 0;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    if (slot[k] >= 0) {
+      VoxelRecord r = rec[slot[k]];
+      pair_update(a, r, xt, yt, zt, ec);
     }
-    out_row[threadIdx.x] = sum;
   }
+  if (a.npairs == 0) return;  // ref :592
+
+  expand_point(acc, a, x, y, z, P, ec);
 }
 
-template <bool BATCH>
-__global__ void __launch_bounds__(BLOCK) k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy,
-                                                      const float* __restrict__ sz, int n, GridGeom g,
-                                                      const int* __restrict__ cell2leaf,
-                                                      const VoxelRecord* __restrict__ rec, PoseConsts pose_arg,
-                                                      const PoseConsts* __restrict__ poses, EvalConsts ec,
-                                                      double* __restrict__ partials) {
-  __shared__ PoseConsts pose_lds;
-  const PoseConsts* P = &pose_arg;
-  if (BATCH) {
-    // stage this pose's constants in LDS once per block
-    const float* src = reinterpret_cast<const float*>(poses + blockIdx.y);
-    float* dst = reinterpret_cast<float*>(&pose_lds);
-    for (int i = threadIdx.x; i < (int)(sizeof(PoseConsts) / 4); i += BLOCK) dst[i] = src[i];
-    __syncthreads();
-    P = &pose_lds;
-  }
-  double acc[NACC];
+// One step of a recursive-halving reduce-scatter over the wave: N values in, N/2
+// out; lanes whose `mask` bit is set keep the upper half.  6 steps turn 32 values
+// per lane into 1 value per lane pair (lane l ends with the wave sum of value l>>1)
+// with 32 cross-lane moves instead of 32*6.
+template <int N>
+__device__ __forceinline__ void rs_step(double* a, int mask, bool upper) {
 #pragma unroll
-  for (int v = 0; v < NACC; ++v) acc[v] = 0.0;
-  const int stride = gridDim.x * BLOCK;
-  for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride)
-    point_body(acc, sx[i], sy[i], sz[i], g, cell2leaf, rec, *P, ec);
-  block_reduce_store(acc, partials + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * EV_WORDS);
+  for (int i = 0; i < N / 2; ++i) {
+    const double send = upper ? a[i] : a[i + N / 2];
+    const double keep = upper ? a[i + N / 2] : a[i];
+    a[i] = keep + __shfl_xor(send, mask);
+  }
 }
 
-// fixed-order sum of the per-block rows: thread (c, v) sums blocks c, c+8, ...
-__global__ void __launch_bounds__(256) k_final_reduce(const double* __restrict__ partials, int nblocks,
-                                                     double* __restrict__ out) {
-  __shared__ double lds[8][EV_WORDS];
-  const double* base = partials + (size_t)blockIdx.x * nblocks * EV_WORDS;
+constexpr int NGROUPS = 32;                 // second-level fan-in of the in-kernel reduction
+constexpr int COUNTERS_PER_POSE = 1 + NGROUPS;
+
+// wave 0, lane 0: publish what this block stored, take a ticket; the block holding
+// the last ticket acquires.  Returns 1 in that block (agent-scope release/acquire,
+// cdna_hip_programming.md Guideline 16).
+__device__ __forceinline__ int ticket_is_last(unsigned int* counter, unsigned int expected) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned int t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int last = (t == expected - 1u) ? 1 : 0;
+  if (last) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  return last;
+}
+
+// thread (c = tid>>5, v = tid&31) adds word v of rows first+c, first+c+8, ... < end,
+// the 8 partial sums are then added in order: a fixed summation tree.
+__device__ __forceinline__ void sum_rows(const double* __restrict__ rows, int first, int end,
+                                         double (*lds_c)[EV_WORDS], double* __restrict__ dst) {
   const int v = threadIdx.x & 31, c = threadIdx.x >> 5;
-  double s = 0.0;
-  for (int b = c; b < nblocks; b += 8) s += base[(size_t)b * EV_WORDS + v];
-  lds[c][v] = s;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int b = first + c;
+  for (; b + 24 < end; b += 32) {
+    s0 += rows[(size_t)b * EV_WORDS + v];
+    s1 += rows[(size_t)(b + 8) * EV_WORDS + v];
+    s2 += rows[(size_t)(b + 16) * EV_WORDS + v];
+    s3 += rows[(size_t)(b + 24) * EV_WORDS + v];
+  }
+  for (; b < end; b += 8) s0 += rows[(size_t)b * EV_WORDS + v];
+  lds_c[c][v] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (threadIdx.x < EV_WORDS) {
     double t = 0.0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += lds[k][threadIdx.x];
-    out[(size_t)blockIdx.x * EV_WORDS + threadIdx.x] = t;
+    for (int k = 0; k < 8; ++k) t += lds_c[k][threadIdx.x];
+    dst[threadIdx.x] = t;
   }
+}
+
+// Block sum of the 32 accumulator words -> one row per block.  The rows are then
+// added INSIDE the same launch by a two-level ticket scheme: blocks form up to 32
+// contiguous groups; the last block of a group to arrive adds that group's rows
+// (fixed order) into a group row, and the last group to finish adds the group
+// rows and writes the evaluation.  No second kernel, no float atomics, and the
+// summation tree does not depend on arrival order: results are bit-reproducible.
+__device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], double* __restrict__ rows,
+                                                    double* __restrict__ group_rows,
+                                                    unsigned int* __restrict__ counters,
+                                                    double* __restrict__ out) {
+  __shared__ double lds_w[BLOCK / 64][EV_WORDS];
+  __shared__ double lds_c[8][EV_WORDS];
+  __shared__ int s_last;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  rs_step<32>(acc, 32, (lane & 32) != 0);
+  rs_step<16>(acc, 16, (lane & 16) != 0);
+  rs_step<8>(acc, 8, (lane & 8) != 0);
+  rs_step<4>(acc, 4, (lane & 4) != 0);
+  rs_step<2>(acc, 2, (lane & 2) != 0);
+  acc[0] += __shfl_xor(acc[0], 1);
+  if ((lane & 1) == 0) lds_w[wave][lane >> 1] = acc[0];
+  __syncthreads();
+  if (threadIdx.x < EV_WORDS) {
+    double sum = 0.0;
+#pragma unroll
+    for (int wv = 0; wv < BLOCK / 64; ++wv) sum += lds_w[wv][threadIdx.x];
+    rows[(size_t)blockIdx.x * EV_WORDS + threadIdx.x] = sum;
+  }
+  const int nb = (int)gridDim.x;
+  const int gsize = (nb + NGROUPS - 1) / NGROUPS;   // blocks per group
+  const int ngroups = (nb + gsize - 1) / gsize;     // <= NGROUPS
+  const int grp = (int)blockIdx.x / gsize;
+  const int first = grp * gsize, end = min(first + gsize, nb);
+  // level 1: the row stores above were issued by wave 0, the wave that takes the ticket
+  if (threadIdx.x == 0) s_last = ticket_is_last(counters + 1 + grp, (unsigned int)(end - first));
+  __syncthreads();
+  if (!s_last) return;
+  sum_rows(rows, first, end, lds_c, group_rows + (size_t)grp * EV_WORDS);
+  // level 2 (group-row stores were issued by wave 0 as well)
+  if (threadIdx.x == 0) s_last = ticket_is_last(counters, (unsigned int)ngroups);
+  __syncthreads();
+  if (!s_last) return;
+  sum_rows(group_rows, 0, ngroups, lds_c, out);
+  if (threadIdx.x <= ngroups)  // leave the tickets at zero for the next launch
+    __hip_atomic_store(counters + threadIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+#ifndef NDT_DERIV_WAVES_PER_SIMD
+#define NDT_DERIV_WAVES_PER_SIMD 4
+#endif
+
+template <bool BATCH>
+__global__ void __launch_bounds__(BLOCK, NDT_DERIV_WAVES_PER_SIMD)
+k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, int n,
+              GridGeom g, const int* __restrict__ cell2leaf, const VoxelRecord* __restrict__ rec,
+              PoseConsts pose_arg, const PoseConsts* __restrict__ poses, EvalConsts ec,
+              double* __restrict__ partials, unsigned int* __restrict__ counters, double* __restrict__ out) {
+  // Pose constants live in LDS: 81 dwords held in SGPRs for the whole kernel would
+  // spill; a one-off copy keeps their live range to this prologue.
+  __shared__ PoseConsts pose_lds;
+  if (BATCH) {
+    const float* src = reinterpret_cast<const float*>(poses + blockIdx.y);
+    float* dst = reinterpret_cast<float*>(&pose_lds);
+    for (int i = threadIdx.x; i < (int)(sizeof(PoseConsts) / 4); i += BLOCK) dst[i] = src[i];
+  } else if (threadIdx.x == 0) {
+    pose_lds = pose_arg;
+  }
+  __syncthreads();
+  const PoseConsts* P = &pose_lds;
+  // exactly one source point per thread: the 32 accumulator words are then only live
+  // from the per-point expansion to the block reduction, not across the pair loop
+  double acc[EV_WORDS];
+#pragma unroll
+  for (int v = 0; v < EV_WORDS; ++v) acc[v] = 0.0;
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i < n) point_body(acc, sx[i], sy[i], sz[i], g, cell2leaf, rec, *P, ec);
+  double* base = partials + (size_t)blockIdx.y * (gridDim.x + NGROUPS) * EV_WORDS;
+  block_reduce_finish(acc, base + (size_t)NGROUPS * EV_WORDS, base, counters + blockIdx.y * COUNTERS_PER_POSE,
+                      out + (size_t)blockIdx.y * EV_WORDS);
 }
 
 __global__ void __launch_bounds__(256) k_transform(const float* __restrict__ sx, const float* __restrict__ sy,
@@ -266,29 +344,30 @@ __global__ void __launch_bounds__(256) k_transform(const float* __restrict__ sx,
 
 }  // namespace
 
+size_t derivs_partials_words(size_t n_src, int K) {
+  return (size_t)K * ((size_t)derivs_grid_blocks(n_src) + NGROUPS) * EV_WORDS;
+}
+int derivs_counters_per_pose() { return COUNTERS_PER_POSE; }
+
 int derivs_grid_blocks(size_t n_src) {
-  size_t blocks = (n_src + BLOCK - 1) / BLOCK;
+  size_t blocks = (n_src + BLOCK - 1) / BLOCK;  // one point per thread
   if (blocks < 1) blocks = 1;
-  if (blocks > 2048) blocks = 2048;
   return (int)blocks;
 }
 
 void launch_derivatives(const float* sx, const float* sy, const float* sz, size_t n_src,
                         const GridGeom& g, const int* cell2leaf, const VoxelRecord* rec,
                         const PoseConsts& pose, const PoseConsts* d_poses, int K,
-                        const EvalConsts& ec, double* d_partials, double* d_out, hipStream_t s,
-                        hipEvent_t ev_mid) {
+                        const EvalConsts& ec, double* d_partials, unsigned int* d_counters,
+                        double* d_out, hipStream_t s) {
   const int blocks = derivs_grid_blocks(n_src);
   if (d_poses) {
     hipLaunchKernelGGL(k_derivatives<true>, dim3(blocks, K), dim3(BLOCK), 0, s, sx, sy, sz,
-                       (int)n_src, g, cell2leaf, rec, pose, d_poses, ec, d_partials);
+                       (int)n_src, g, cell2leaf, rec, pose, d_poses, ec, d_partials, d_counters, d_out);
   } else {
     hipLaunchKernelGGL(k_derivatives<false>, dim3(blocks, 1), dim3(BLOCK), 0, s, sx, sy, sz,
-                       (int)n_src, g, cell2leaf, rec, pose, d_poses, ec, d_partials);
-    K = 1;
+                       (int)n_src, g, cell2leaf, rec, pose, d_poses, ec, d_partials, d_counters, d_out);
   }
-  if (ev_mid) (void)hipEventRecord(ev_mid, s);
-  hipLaunchKernelGGL(k_final_reduce, dim3(K), dim3(256), 0, s, d_partials, blocks, d_out);
 }
 
 void launch_transform(const float* sx, const float* sy, const float* sz, size_t n,

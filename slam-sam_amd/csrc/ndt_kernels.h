@@ -6,9 +6,11 @@
 namespace ndt {
 
 // ---- target voxel-grid build (ndt_target.hip) ------------------------------
-// d_bounds: 8 ints = ordered-int encoded {min x,y,z, max x,y,z}, #finite, pad
-void launch_bounds(const float* x, const float* y, const float* z, size_t n,
-                   int* d_bounds, hipStream_t s);
+// rows: bounds_rows(n) x 8 ints = ordered-int encoded {min x,y,z, max x,y,z}, #finite, 0
+// per block (device-visible memory); fold_bounds() merges them on the host.
+int bounds_rows(size_t n);
+void launch_bounds(const float* x, const float* y, const float* z, size_t n, int* rows, hipStream_t s);
+void fold_bounds(const int* rows, int nrows, int out[8]);
 float decode_ordered(int enc);
 
 void launch_cell_keys(const float* x, const float* y, const float* z, size_t n,
@@ -35,16 +37,18 @@ void launch_finalize_leaves(const float* x, const float* y, const float* z,
 
 // ---- derivative evaluation (ndt_derivs.hip) ---------------------------------
 int derivs_grid_blocks(size_t n_src);
-// d_partials: K * blocks * EV_WORDS doubles; d_out: K * EV_WORDS doubles
-// (device memory or device-mapped pinned host memory).  If d_poses is null the
-// single pose `pose` is passed as a kernel argument.
-// ev_mid (optional) is recorded between the accumulation kernel and the final
-// reduction so the dominant kernel can be timed on its own.
+size_t derivs_partials_words(size_t n_src, int K);  // doubles needed in d_partials
+int derivs_counters_per_pose();                     // ticket words per pose in d_counters
+// d_partials: derivs_partials_words() doubles; d_counters: K * derivs_counters_per_pose()
+// zero-initialised ticket words (left at zero again by every launch); d_out: K * EV_WORDS doubles (device
+// memory or device-mapped pinned host memory).  If d_poses is null the single pose
+// `pose` is passed as a kernel argument.  One launch: the last block to finish adds
+// the per-block rows in fixed order.
 void launch_derivatives(const float* sx, const float* sy, const float* sz, size_t n_src,
                         const GridGeom& g, const int* cell2leaf, const VoxelRecord* rec,
                         const PoseConsts& pose, const PoseConsts* d_poses, int K,
-                        const EvalConsts& ec, double* d_partials, double* d_out, hipStream_t s,
-                        hipEvent_t ev_mid = nullptr);
+                        const EvalConsts& ec, double* d_partials, unsigned int* d_counters,
+                        double* d_out, hipStream_t s);
 
 void launch_transform(const float* sx, const float* sy, const float* sz, size_t n,
                       const PoseConsts& pose, float* out_xyz, hipStream_t s);

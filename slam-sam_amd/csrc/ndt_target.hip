@@ -36,16 +36,16 @@ __device__ __forceinline__ bool finite3(float a, float b, float c) {
   return isfinite(a) && isfinite(b) && isfinite(c);
 }
 
-__global__ void k_bounds_init(int* b) {
-  int t = threadIdx.x;
-  if (t < 3) b[t] = INT_MAX;
-  else if (t < 6) b[t] = INT_MIN;
-  else if (t < 8) b[t] = 0;
-}
+constexpr int BOUNDS_BLOCKS = 512;
 
-// ref: pcl::getMinMax3D at voxel_grid_covariance_impl.hpp:103 (non-finite skipped)
+// ref: pcl::getMinMax3D at voxel_grid_covariance_impl.hpp:103 (non-finite skipped).
+// One row of 8 ints per block {min xyz, max xyz, #finite, 0} written straight into
+// device-mapped pinned host memory; the host (which needs the bounds anyway to size
+// the grid) folds the <= 512 rows.  No atomics: every block contending on the same
+// 7 words cost 0.65 ms for 1M points.
 __global__ void __launch_bounds__(256) k_bounds(const float* __restrict__ x, const float* __restrict__ y,
-                                               const float* __restrict__ z, size_t n, int* bounds) {
+                                               const float* __restrict__ z, size_t n, int* __restrict__ rows) {
+  __shared__ int lds[4][8];
   int mn[3] = {INT_MAX, INT_MAX, INT_MAX};
   int mx[3] = {INT_MIN, INT_MIN, INT_MIN};
   int cnt = 0;
@@ -68,13 +68,21 @@ __global__ void __launch_bounds__(256) k_bounds(const float* __restrict__ x, con
     }
     cnt += __shfl_xor(cnt, off);
   }
-  if ((threadIdx.x & 63) == 0 && cnt > 0) {
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      atomicMin(&bounds[a], mn[a]);
-      atomicMax(&bounds[3 + a], mx[a]);
+    for (int a = 0; a < 3; ++a) { lds[wave][a] = mn[a]; lds[wave][3 + a] = mx[a]; }
+    lds[wave][6] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    const int t = threadIdx.x;
+    int v = lds[0][t];
+    for (int w = 1; w < 4; ++w) {
+      int o = lds[w][t];
+      v = t < 3 ? min(v, o) : (t < 6 ? max(v, o) : v + o);
     }
-    atomicAdd(&bounds[6], cnt);
+    rows[blockIdx.x * 8 + t] = t == 7 ? 0 : v;
   }
 }
 
@@ -102,31 +110,50 @@ __global__ void __launch_bounds__(256) k_cell_keys(const float* __restrict__ x, 
   vals[i] = (uint32_t)i;
 }
 
+// Runs of equal cell key in the sorted array.  Each run TAIL finds its head: inside
+// the wave through a ballot of head flags (no memory traffic), and only for runs
+// that began in an earlier wave by a backward gallop + bisection.  Runs with at
+// least min_pts points get a leaf slot (ref: voxel_grid_covariance_impl.hpp:270-273).
 __global__ void __launch_bounds__(256) k_find_runs(const uint32_t* __restrict__ keys, int n, int ncells,
                                                   int min_pts, int* nleaf, int* __restrict__ leaf_start,
                                                   int* __restrict__ leaf_cnt) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n) return;
-  uint32_t key = keys[s];
-  if (key >= (uint32_t)ncells) return;
-  if (s > 0 && keys[s - 1] == key) return;  // not a run head
-  // gallop, then bisect, for the first position whose key differs
-  int lo = s, hi, step = 1;
-  for (;;) {
-    int nx = lo + step;
-    if (nx >= n) { hi = n; break; }
-    if (keys[nx] != key) { hi = nx; break; }
-    lo = nx;
-    step <<= 1;
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const uint32_t sentinel = 0xFFFFFFFFu;
+  const uint32_t key = s < n ? keys[s] : sentinel;
+  uint32_t prev = __shfl_up(key, 1), next = __shfl_down(key, 1);
+  if (lane == 0) prev = s > 0 && s - 1 < n ? keys[s - 1] : sentinel;
+  if (lane == 63) next = s + 1 < n ? keys[s + 1] : sentinel;
+  const bool valid = s < n && key < (uint32_t)ncells;
+  const bool head = valid && (s == 0 || prev != key);
+  const bool tail = valid && (s == n - 1 || next != key);
+  const unsigned long long heads = __ballot(head);
+  if (!tail) return;
+  int start;
+  const unsigned long long below = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+  if (below) {
+    start = s - (lane - (63 - __clzll((long long)below)));
+  } else {
+    // the run began before this wave: keys[wave_base] == key; walk back
+    int hi = s - lane;  // known to hold key
+    int step = 1, lo;
+    for (;;) {
+      int nx = hi - step;
+      if (nx < 0) { lo = -1; break; }
+      if (keys[nx] != key) { lo = nx; break; }
+      hi = nx;
+      step <<= 1;
+    }
+    while (hi - lo > 1) {  // keys[lo] != key (or lo == -1), keys[hi] == key
+      int mid = (lo + hi) >> 1;
+      if (keys[mid] == key) hi = mid; else lo = mid;
+    }
+    start = hi;
   }
-  while (hi - lo > 1) {
-    int mid = (lo + hi) >> 1;
-    if (keys[mid] == key) lo = mid; else hi = mid;
-  }
-  int cnt = hi - s;
-  if (cnt < min_pts) return;  // ref: voxel_grid_covariance_impl.hpp:270-273
-  int slot = atomicAdd(nleaf, 1);
-  leaf_start[slot] = s;
+  const int cnt = s - start + 1;
+  if (cnt < min_pts) return;
+  const int slot = atomicAdd(nleaf, 1);
+  leaf_start[slot] = start;
   leaf_cnt[slot] = cnt;
 }
 
@@ -310,13 +337,28 @@ float decode_ordered(int enc) {
   return f;
 }
 
-void launch_bounds(const float* x, const float* y, const float* z, size_t n, int* d_bounds,
-                   hipStream_t s) {
-  hipLaunchKernelGGL(k_bounds_init, dim3(1), dim3(64), 0, s, d_bounds);
-  if (n == 0) return;
+int bounds_rows(size_t n) {
   size_t blocks = (n + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(k_bounds, dim3((unsigned)blocks), dim3(256), 0, s, x, y, z, n, d_bounds);
+  if (blocks > (size_t)BOUNDS_BLOCKS) blocks = BOUNDS_BLOCKS;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+void launch_bounds(const float* x, const float* y, const float* z, size_t n, int* rows, hipStream_t s) {
+  hipLaunchKernelGGL(k_bounds, dim3((unsigned)bounds_rows(n)), dim3(256), 0, s, x, y, z, n, rows);
+}
+
+void fold_bounds(const int* rows, int nrows, int out[8]) {
+  for (int a = 0; a < 3; ++a) { out[a] = INT_MAX; out[3 + a] = INT_MIN; }
+  out[6] = out[7] = 0;
+  for (int r = 0; r < nrows; ++r) {
+    const int* p = rows + 8 * r;
+    for (int a = 0; a < 3; ++a) {
+      out[a] = p[a] < out[a] ? p[a] : out[a];
+      out[3 + a] = p[3 + a] > out[3 + a] ? p[3 + a] : out[3 + a];
+    }
+    out[6] += p[6];
+  }
 }
 
 void launch_cell_keys(const float* x, const float* y, const float* z, size_t n, const GridGeom& g,
