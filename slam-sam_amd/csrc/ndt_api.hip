@@ -97,6 +97,8 @@ struct ndt_handle {
   PinBuf<float> stage;               // host->device upload staging
   PinBuf<double> result;             // evaluation results (K * EV_WORDS)
   PinBuf<int> small;                 // bounds / counters read-back
+  PinBuf<unsigned long long> flag;   // completion word the derivative kernel writes
+  unsigned long long eval_seq = 0;
   DevBuf<double> partials, dres;
   DevBuf<unsigned int> counters;     // per-pose tickets of the in-kernel final reduction
   size_t counters_zeroed = 0;
@@ -286,6 +288,25 @@ int ready_for_eval(ndt_handle* h) {
   return NDT_OK;
 }
 
+// Wait for the derivative kernel's completion word in pinned host memory.  Polling it
+// sees the result ~4 us sooner than hipStreamSynchronize (measured: 7.7 vs 11.5 us launch +
+// completion round trip on MI355X); falls back to the stream if the word never arrives.
+int wait_flag(ndt_handle* h, unsigned long long seq) {
+  volatile unsigned long long* f = h->flag.h;
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned int spins = 0;
+  while (__atomic_load_n(f, __ATOMIC_ACQUIRE) != seq) {
+    if ((++spins & 0xFFFF) == 0 &&
+        std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+      if (__atomic_load_n(f, __ATOMIC_ACQUIRE) != seq)
+        return fail(h, NDT_ERR_HIP, "derivative kernel finished without publishing its result");
+      break;
+    }
+  }
+  return NDT_OK;
+}
+
 // one global evaluation at (p, T): local kernel + cross-rank sum
 int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, Eval* out) {
   hipStream_t s = h->stream;
@@ -294,6 +315,10 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
   const EvalConsts ec = make_eval_consts(h, need_h);
   HIP_TRY(h, h->partials.ensure(derivs_partials_words(h->n_src, 1)));
   HIP_TRY(h, h->result.ensure(EV_WORDS));
+  if (!h->flag.h) {
+    HIP_TRY(h, h->flag.ensure(8));
+    h->flag.h[0] = 0;
+  }
   const bool dev_out = h->red.wants_device_buffer();
   if (dev_out) HIP_TRY(h, h->dres.ensure(EV_WORDS));
   {
@@ -301,16 +326,23 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
     if (rc) return rc;
   }
   double* d_out = dev_out ? h->dres.p : h->result.d;
+  const bool spin = !dev_out && !h->timing;
+  const unsigned long long seq = ++h->eval_seq;
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, s));
   launch_derivatives(h->sx.p, h->sy.p, h->sz.p, h->n_src, h->geom, h->cell2leaf.p, h->rec.p, pc,
-                     nullptr, 1, ec, h->partials.p, h->counters.p, d_out, s);
+                     nullptr, 1, ec, h->partials.p, h->counters.p, d_out, s, spin ? h->flag.d : nullptr, seq);
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, s));
   if (dev_out) {
     int rc = h->red.allreduce_device(h->dres.p, EV_WORDS, s, &h->err);
     if (rc) return rc;
     HIP_TRY(h, hipMemcpyAsync(h->result.h, h->dres.p, EV_WORDS * sizeof(double), hipMemcpyDeviceToHost, s));
   }
-  HIP_TRY(h, hipStreamSynchronize(s));
+  if (spin) {
+    int rc = wait_flag(h, seq);
+    if (rc) return rc;
+  } else {
+    HIP_TRY(h, hipStreamSynchronize(s));
+  }
   h->tm.n_eval_launches++;
   if (h->timing) {
     float ms = 0;
@@ -414,7 +446,7 @@ int ndt_destroy(ndt_handle* h) {
   h->cell2leaf.release(); h->rec.release(); h->stats.release();
   h->sx.release(); h->sy.release(); h->sz.release();
   h->stage.release(); h->result.release(); h->small.release(); h->partials.release();
-  h->dres.release(); h->dposes.release(); h->hposes.release(); h->counters.release();
+  h->dres.release(); h->dposes.release(); h->hposes.release(); h->counters.release(); h->flag.release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->ev2) (void)hipEventDestroy(h->ev2);
@@ -550,7 +582,7 @@ int ndt_align(ndt_handle* h, const float guess[16], ndt_result* out) {
   const double dev_ms0 = h->tm.ms_eval_kernel_total;
   EvalFn fn = [h](const double* p, const float* T, bool need_h, Eval* e) { return evaluate(h, p, T, need_h, e); };
   const int64_t n_total = h->n_src_global >= 0 ? h->n_src_global : (int64_t)h->n_src;
-  rc = newton_align(h->prm, n_total, guess, fn, out);
+  rc = newton_align(h->prm, n_total, guess, fn, out, /*hessian_in_trials=*/true);
   out->ms_device = h->tm.ms_eval_kernel_total - dev_ms0;
   return rc;
 }

@@ -25,7 +25,7 @@ namespace ndt {
 
 namespace {
 
-constexpr int BLOCK = 256;
+constexpr int BLOCK = 512;  // 8 waves: fewer partial rows for the in-kernel final sum
 
 // ref: voxel_grid_covariance_impl.hpp:46-71 (f32 bounds) +
 // voxel_grid_covariance.h:297-300 (index).  -1 = outside the grid.
@@ -88,8 +88,13 @@ __device__ __forceinline__ float dot3f(const float* m, float x, float y, float z
 
 // Per-POINT expansion of the pair sums into the 6-gradient / 21 Hessian words:
 // g = J^T w,  H = J^T S J (+ w . d2x'/dp_i dp_j), J = [I | A(x)] (ref :339-396, :449-494).
+struct AngleTables {
+  float jang[24];  // 8x3
+  float hang[45];  // 15x3
+};
+
 __device__ __forceinline__ void expand_point(double acc[EV_WORDS], const PairAcc& a, float x, float y,
-                                             float z, const PoseConsts& P, const EvalConsts& ec) {
+                                             float z, const AngleTables& P, const EvalConsts& ec) {
 #pragma clang fp contract(fast)
   acc[EV_SCORE] += a.score;
   acc[EV_NVTL] += a.best;
@@ -147,10 +152,20 @@ __device__ __forceinline__ void expand_point(double acc[EV_WORDS], const PairAcc
   H[15] += R33; H[16] += R34; H[17] += R35; H[18] += R44; H[19] += R45; H[20] += R55;
 }
 
-__device__ __forceinline__ void point_body(double acc[EV_WORDS], float x, float y, float z,
-                                           const GridGeom& g, const int* __restrict__ cell2leaf,
-                                           const VoxelRecord* __restrict__ rec, const PoseConsts& P,
-                                           const EvalConsts& ec) {
+struct RigidRT {
+  float R[9];
+  float t[3];
+};
+
+// Phase 1 of a point: transform, neighbour lookup, pair sums.  Needs only R|t.
+__device__ __forceinline__ void point_pairs(PairAcc& a, float x, float y, float z, const GridGeom& g,
+                                            const int* __restrict__ cell2leaf,
+                                            const VoxelRecord* __restrict__ rec, const RigidRT& P,
+                                            const EvalConsts& ec) {
+  a.w[0] = a.w[1] = a.w[2] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) a.S[k] = 0.0;
+  a.score = 0.0; a.best = 0.0; a.npairs = 0;
   // x' = r0*x + (r1*y + (r2*z + t)), f32, unfused (transformPointCloud, ref :761)
   float xt = P.R[0] * x + (P.R[1] * y + (P.R[2] * z + P.t[0]));
   float yt = P.R[3] * x + (P.R[4] * y + (P.R[5] * z + P.t[1]));
@@ -176,12 +191,13 @@ __device__ __forceinline__ void point_body(double acc[EV_WORDS], float x, float 
   int slot[7];
 #pragma unroll
   for (int k = 0; k < 7; ++k) slot[k] = cell[k] >= 0 ? cell2leaf[cell[k]] : -1;
-
-  PairAcc a;
-  a.w[0] = a.w[1] = a.w[2] = 0.0;
+#if defined(NDT_ABL) && NDT_ABL == 1  // ablation: grid loads kept, no records / pair math
 #pragma unroll
-  for (int k = 0; k < 6; ++k) a.S[k] = 0.0;
-  a.score = 0.0; a.best = 0.0; a.npairs = 0;
+  for (int k = 0; k < 7; ++k) slot[k] = slot[k] == 0x7fffffff ? 0 : -1;
+#elif defined(NDT_ABL) && NDT_ABL == 2  // ablation: no grid loads either
+#pragma unroll
+  for (int k = 0; k < 7; ++k) slot[k] = cell[k] == 0x7fffffff ? 0 : -1;
+#endif
 #pragma unroll
   for (int k = 0; k < 7; ++k) {
     if (slot[k] >= 0) {
@@ -189,15 +205,34 @@ __device__ __forceinline__ void point_body(double acc[EV_WORDS], float x, float 
       pair_update(a, r, xt, yt, zt, ec);
     }
   }
-  if (a.npairs == 0) return;  // ref :592
-
-  expand_point(acc, a, x, y, z, P, ec);
 }
 
-// One step of a recursive-halving reduce-scatter over the wave: N values in, N/2
-// out; lanes whose `mask` bit is set keep the upper half.  6 steps turn 32 values
-// per lane into 1 value per lane pair (lane l ends with the wave sum of value l>>1)
-// with 32 cross-lane moves instead of 32*6.
+// Recursive-halving reduce-scatter of 32 f64 words over the wave: after 6 steps lane
+// l holds the wave sum of word l>>1.  The two widest steps use gfx950's
+// v_permlane32_swap / v_permlane16_swap (exchange the upper half of one register with
+// the lower half of another in one instruction, no select needed); the last four
+// (8 -> 1 words) use xor shuffles.  ~100 instructions instead of 6 x 32 shuffles.
+typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
+
+template <bool SWAP32>
+__device__ __forceinline__ double swap_add(double a, double b) {
+  // a: word i, b: word i + N/2.  Returns (word i summed over the exchanged half) in the
+  // lower lanes / even rows and (word i + N/2 ...) in the upper lanes / odd rows.
+  const unsigned long long ua = (unsigned long long)__double_as_longlong(a);
+  const unsigned long long ub = (unsigned long long)__double_as_longlong(b);
+  uint2v lo, hi;
+  if (SWAP32) {
+    lo = __builtin_amdgcn_permlane32_swap((unsigned)ua, (unsigned)ub, false, false);
+    hi = __builtin_amdgcn_permlane32_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+  } else {
+    lo = __builtin_amdgcn_permlane16_swap((unsigned)ua, (unsigned)ub, false, false);
+    hi = __builtin_amdgcn_permlane16_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+  }
+  const double na = __longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0]));
+  const double nb = __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1]));
+  return na + nb;
+}
+
 template <int N>
 __device__ __forceinline__ void rs_step(double* a, int mask, bool upper) {
 #pragma unroll
@@ -208,93 +243,122 @@ __device__ __forceinline__ void rs_step(double* a, int mask, bool upper) {
   }
 }
 
-constexpr int NGROUPS = 32;                 // second-level fan-in of the in-kernel reduction
-constexpr int COUNTERS_PER_POSE = 1 + NGROUPS;
-
-// wave 0, lane 0: publish what this block stored, take a ticket; the block holding
-// the last ticket acquires.  Returns 1 in that block (agent-scope release/acquire,
-// cdna_hip_programming.md Guideline 16).
-__device__ __forceinline__ int ticket_is_last(unsigned int* counter, unsigned int expected) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  const unsigned int t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const int last = (t == expected - 1u) ? 1 : 0;
-  if (last) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  return last;
-}
-
-// thread (c = tid>>5, v = tid&31) adds word v of rows first+c, first+c+8, ... < end,
-// the 8 partial sums are then added in order: a fixed summation tree.
-__device__ __forceinline__ void sum_rows(const double* __restrict__ rows, int first, int end,
-                                         double (*lds_c)[EV_WORDS], double* __restrict__ dst) {
-  const int v = threadIdx.x & 31, c = threadIdx.x >> 5;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  int b = first + c;
-  for (; b + 24 < end; b += 32) {
-    s0 += rows[(size_t)b * EV_WORDS + v];
-    s1 += rows[(size_t)(b + 8) * EV_WORDS + v];
-    s2 += rows[(size_t)(b + 16) * EV_WORDS + v];
-    s3 += rows[(size_t)(b + 24) * EV_WORDS + v];
-  }
-  for (; b < end; b += 8) s0 += rows[(size_t)b * EV_WORDS + v];
-  lds_c[c][v] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
-  if (threadIdx.x < EV_WORDS) {
-    double t = 0.0;
+__device__ __forceinline__ void wave_reduce_scatter32(double* acc, int lane) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += lds_c[k][threadIdx.x];
-    dst[threadIdx.x] = t;
-  }
-}
-
-// Block sum of the 32 accumulator words -> one row per block.  The rows are then
-// added INSIDE the same launch by a two-level ticket scheme: blocks form up to 32
-// contiguous groups; the last block of a group to arrive adds that group's rows
-// (fixed order) into a group row, and the last group to finish adds the group
-// rows and writes the evaluation.  No second kernel, no float atomics, and the
-// summation tree does not depend on arrival order: results are bit-reproducible.
-__device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], double* __restrict__ rows,
-                                                    double* __restrict__ group_rows,
-                                                    unsigned int* __restrict__ counters,
-                                                    double* __restrict__ out) {
-  __shared__ double lds_w[BLOCK / 64][EV_WORDS];
-  __shared__ double lds_c[8][EV_WORDS];
-  __shared__ int s_last;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  rs_step<32>(acc, 32, (lane & 32) != 0);
-  rs_step<16>(acc, 16, (lane & 16) != 0);
+  for (int i = 0; i < 16; ++i) acc[i] = swap_add<true>(acc[i], acc[i + 16]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = swap_add<false>(acc[i], acc[i + 8]);
   rs_step<8>(acc, 8, (lane & 8) != 0);
   rs_step<4>(acc, 4, (lane & 4) != 0);
   rs_step<2>(acc, 2, (lane & 2) != 0);
   acc[0] += __shfl_xor(acc[0], 1);
+}
+
+constexpr int NGROUPS = 32;          // second-level fan-in (only for grids above SINGLE_LEVEL_MAX rows)
+constexpr int SINGLE_LEVEL_MAX = 2048;  // rows one block adds directly
+constexpr int COUNTERS_PER_POSE = 1 + NGROUPS;
+constexpr int NWAVES = BLOCK / 64;
+constexpr int NCOLS = BLOCK / 32;    // row-parallel lanes of the final sum
+
+// Cross-block hand-off without cache-wide fences (cdna_hip_programming.md Guideline 16,
+// "every store sc1 ... every load sc1" form): rows are written with agent-scope
+// write-through stores, the storing wave drains them (vmcnt(0)) and only then takes
+// its ticket; the block that draws the last ticket reads the rows with agent-scope
+// loads (which bypass the per-CU L1).  A release/acquire fence pair here costs a full
+// L2 write-back + L1 invalidate per block and dominated the kernel.
+__device__ __forceinline__ void store_agent(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double load_agent(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// wave 0, lane 0, after wave 0 stored the block's row: drain, take a ticket.
+__device__ __forceinline__ int ticket_is_last(unsigned int* counter, unsigned int expected) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned int t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return (t == expected - 1u) ? 1 : 0;
+}
+
+// Fixed-order sum of rows [first, end): thread (c = tid>>5, v = tid&31) takes word v of
+// rows first+c, first+c+NCOLS, ...; 16 loads are issued before the first add so one
+// memory round trip covers 16*NCOLS rows.  The NCOLS column sums are then added in order.
+__device__ __forceinline__ void sum_rows(const double* __restrict__ rows, int first, int end,
+                                         double (*lds_c)[EV_WORDS], double* __restrict__ dst, bool dst_agent) {
+  const int v = threadIdx.x & 31, c = threadIdx.x >> 5;
+  double s = 0.0;
+  for (int b0 = first + c; b0 < end; b0 += 16 * NCOLS) {
+    double t[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int b = b0 + k * NCOLS;
+      t[k] = b < end ? load_agent(rows + (size_t)b * EV_WORDS + v) : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += t[k];
+  }
+  lds_c[c][v] = s;
+  __syncthreads();
+  if (threadIdx.x < EV_WORDS) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < NCOLS; ++k) t += lds_c[k][threadIdx.x];
+    if (dst_agent) store_agent(dst + threadIdx.x, t); else dst[threadIdx.x] = t;
+  }
+}
+
+// Block sum of the 32 accumulator words -> one row per block; the rows are added INSIDE
+// the same launch: the block that draws the last ticket adds all rows in fixed order and
+// writes the evaluation (grids above 2048 rows go through 32 group rows first).  No second
+// kernel, no float atomics, and the summation tree does not depend on arrival order:
+// results are bit-reproducible.  If `flag` is set the finished evaluation is followed by
+// a system-scope store of `seq` so the host can spin on pinned memory instead of waiting
+// for the stream.
+__device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], double* __restrict__ rows,
+                                                    double* __restrict__ group_rows,
+                                                    unsigned int* __restrict__ counters,
+                                                    double* __restrict__ out,
+                                                    unsigned long long* flag, unsigned long long seq) {
+  __shared__ double lds_w[NWAVES][EV_WORDS];
+  __shared__ double lds_c[NCOLS][EV_WORDS];
+  __shared__ int s_last;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  wave_reduce_scatter32(acc, lane);
   if ((lane & 1) == 0) lds_w[wave][lane >> 1] = acc[0];
   __syncthreads();
   if (threadIdx.x < EV_WORDS) {
     double sum = 0.0;
 #pragma unroll
-    for (int wv = 0; wv < BLOCK / 64; ++wv) sum += lds_w[wv][threadIdx.x];
-    rows[(size_t)blockIdx.x * EV_WORDS + threadIdx.x] = sum;
+    for (int wv = 0; wv < NWAVES; ++wv) sum += lds_w[wv][threadIdx.x];
+    store_agent(rows + (size_t)blockIdx.x * EV_WORDS + threadIdx.x, sum);
   }
   const int nb = (int)gridDim.x;
-  const int gsize = (nb + NGROUPS - 1) / NGROUPS;   // blocks per group
-  const int ngroups = (nb + gsize - 1) / gsize;     // <= NGROUPS
-  const int grp = (int)blockIdx.x / gsize;
-  const int first = grp * gsize, end = min(first + gsize, nb);
-  // level 1: the row stores above were issued by wave 0, the wave that takes the ticket
-  if (threadIdx.x == 0) s_last = ticket_is_last(counters + 1 + grp, (unsigned int)(end - first));
+  int ngroups = 1;
+  if (nb > SINGLE_LEVEL_MAX) {
+    const int gsize = (nb + NGROUPS - 1) / NGROUPS;  // blocks per group
+    ngroups = (nb + gsize - 1) / gsize;              // <= NGROUPS
+    const int grp = (int)blockIdx.x / gsize;
+    const int first = grp * gsize, end = min(first + gsize, nb);
+    // the row stores above were issued by wave 0, the wave that takes the ticket
+    if (threadIdx.x == 0) s_last = ticket_is_last(counters + 1 + grp, (unsigned int)(end - first));
+    __syncthreads();
+    if (!s_last) return;
+    sum_rows(rows, first, end, lds_c, group_rows + (size_t)grp * EV_WORDS, true);
+    __syncthreads();
+    rows = group_rows;
+  }
+  const int nrows = nb > SINGLE_LEVEL_MAX ? ngroups : nb;
+  if (threadIdx.x == 0) s_last = ticket_is_last(counters, (unsigned int)(nb > SINGLE_LEVEL_MAX ? ngroups : nb));
   __syncthreads();
   if (!s_last) return;
-  sum_rows(rows, first, end, lds_c, group_rows + (size_t)grp * EV_WORDS);
-  // level 2 (group-row stores were issued by wave 0 as well)
-  if (threadIdx.x == 0) s_last = ticket_is_last(counters, (unsigned int)ngroups);
-  __syncthreads();
-  if (!s_last) return;
-  sum_rows(group_rows, 0, ngroups, lds_c, out);
+  sum_rows(rows, 0, nrows, lds_c, out, false);
   if (threadIdx.x <= ngroups)  // leave the tickets at zero for the next launch
     __hip_atomic_store(counters + threadIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (flag != nullptr && threadIdx.x == 0) {
+    // `out` was stored by wave 0 (threads < 32): drain, then publish to the host
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 #ifndef NDT_DERIV_WAVES_PER_SIMD
@@ -306,29 +370,52 @@ __global__ void __launch_bounds__(BLOCK, NDT_DERIV_WAVES_PER_SIMD)
 k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, int n,
               GridGeom g, const int* __restrict__ cell2leaf, const VoxelRecord* __restrict__ rec,
               PoseConsts pose_arg, const PoseConsts* __restrict__ poses, EvalConsts ec,
-              double* __restrict__ partials, unsigned int* __restrict__ counters, double* __restrict__ out) {
-  // Pose constants live in LDS: 81 dwords held in SGPRs for the whole kernel would
-  // spill; a one-off copy keeps their live range to this prologue.
-  __shared__ PoseConsts pose_lds;
+              double* __restrict__ partials, unsigned int* __restrict__ counters, double* __restrict__ out,
+              unsigned long long* flag, unsigned long long seq) {
+  // R|t (12 dwords) stay in scalar registers; the 69 angle-table words are only needed
+  // after the pair loop, so they are parked in LDS (81 live SGPRs would spill) and the
+  // barrier that publishes them sits behind the memory-latency part of the kernel.
+  __shared__ AngleTables tab;
+  RigidRT rt;
   if (BATCH) {
-    const float* src = reinterpret_cast<const float*>(poses + blockIdx.y);
-    float* dst = reinterpret_cast<float*>(&pose_lds);
-    for (int i = threadIdx.x; i < (int)(sizeof(PoseConsts) / 4); i += BLOCK) dst[i] = src[i];
-  } else if (threadIdx.x == 0) {
-    pose_lds = pose_arg;
+    const PoseConsts& pg = poses[blockIdx.y];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) rt.R[k] = pg.R[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rt.t[k] = pg.t[k];
+    const float* src = pg.jang;  // jang[24] and hang[45] are contiguous
+    float* dst = tab.jang;
+    for (int k = threadIdx.x; k < 69; k += BLOCK) dst[k] = src[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) rt.R[k] = pose_arg.R[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rt.t[k] = pose_arg.t[k];
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int k = 0; k < 24; ++k) tab.jang[k] = pose_arg.jang[k];
+#pragma unroll
+      for (int k = 0; k < 45; ++k) tab.hang[k] = pose_arg.hang[k];
+    }
   }
-  __syncthreads();
-  const PoseConsts* P = &pose_lds;
-  // exactly one source point per thread: the 32 accumulator words are then only live
-  // from the per-point expansion to the block reduction, not across the pair loop
+  // exactly one source point per thread: the 32 accumulator words are only live from the
+  // per-point expansion to the block reduction, not across the pair loop
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  float x = 0.0f, y = 0.0f, z = 0.0f;
+  PairAcc a;
+  a.npairs = 0;
+  if (i < n) {
+    x = sx[i]; y = sy[i]; z = sz[i];
+    point_pairs(a, x, y, z, g, cell2leaf, rec, rt, ec);
+  }
+  __syncthreads();  // angle tables visible
   double acc[EV_WORDS];
 #pragma unroll
   for (int v = 0; v < EV_WORDS; ++v) acc[v] = 0.0;
-  const int i = blockIdx.x * BLOCK + threadIdx.x;
-  if (i < n) point_body(acc, sx[i], sy[i], sz[i], g, cell2leaf, rec, *P, ec);
+  if (a.npairs > 0) expand_point(acc, a, x, y, z, tab, ec);  // ref :592: no neighbour, no term
   double* base = partials + (size_t)blockIdx.y * (gridDim.x + NGROUPS) * EV_WORDS;
   block_reduce_finish(acc, base + (size_t)NGROUPS * EV_WORDS, base, counters + blockIdx.y * COUNTERS_PER_POSE,
-                      out + (size_t)blockIdx.y * EV_WORDS);
+                      out + (size_t)blockIdx.y * EV_WORDS, BATCH ? nullptr : flag, seq);
 }
 
 __global__ void __launch_bounds__(256) k_transform(const float* __restrict__ sx, const float* __restrict__ sy,
@@ -359,14 +446,17 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
                         const GridGeom& g, const int* cell2leaf, const VoxelRecord* rec,
                         const PoseConsts& pose, const PoseConsts* d_poses, int K,
                         const EvalConsts& ec, double* d_partials, unsigned int* d_counters,
-                        double* d_out, hipStream_t s) {
+                        double* d_out, hipStream_t s, unsigned long long* d_flag,
+                        unsigned long long seq) {
   const int blocks = derivs_grid_blocks(n_src);
   if (d_poses) {
     hipLaunchKernelGGL(k_derivatives<true>, dim3(blocks, K), dim3(BLOCK), 0, s, sx, sy, sz,
-                       (int)n_src, g, cell2leaf, rec, pose, d_poses, ec, d_partials, d_counters, d_out);
+                       (int)n_src, g, cell2leaf, rec, pose, d_poses, ec, d_partials, d_counters, d_out,
+                       (unsigned long long*)nullptr, 0ull);
   } else {
     hipLaunchKernelGGL(k_derivatives<false>, dim3(blocks, 1), dim3(BLOCK), 0, s, sx, sy, sz,
-                       (int)n_src, g, cell2leaf, rec, pose, d_poses, ec, d_partials, d_counters, d_out);
+                       (int)n_src, g, cell2leaf, rec, pose, d_poses, ec, d_partials, d_counters, d_out,
+                       d_flag, seq);
   }
 }
 

@@ -43,12 +43,14 @@ int derivs_counters_per_pose();                     // ticket words per pose in 
 // zero-initialised ticket words (left at zero again by every launch); d_out: K * EV_WORDS doubles (device
 // memory or device-mapped pinned host memory).  If d_poses is null the single pose
 // `pose` is passed as a kernel argument.  One launch: the last block to finish adds
-// the per-block rows in fixed order.
+// the per-block rows in fixed order.  d_flag (single-pose path only, device-mapped pinned
+// host memory) receives `seq` after d_out has been written, for host-side spinning.
 void launch_derivatives(const float* sx, const float* sy, const float* sz, size_t n_src,
                         const GridGeom& g, const int* cell2leaf, const VoxelRecord* rec,
                         const PoseConsts& pose, const PoseConsts* d_poses, int K,
                         const EvalConsts& ec, double* d_partials, unsigned int* d_counters,
-                        double* d_out, hipStream_t s);
+                        double* d_out, hipStream_t s, unsigned long long* d_flag = nullptr,
+                        unsigned long long seq = 0);
 
 void launch_transform(const float* sx, const float* sy, const float* sz, size_t n,
                       const PoseConsts& pose, float* out_xyz, hipStream_t s);

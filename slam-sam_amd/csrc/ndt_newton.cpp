@@ -274,7 +274,7 @@ bool shrink(End& l, End& u, double a_t, double f_t, double g_t) {
 
 class Solver {
  public:
-  Solver(const ndt_params& prm, const EvalFn& fn) : prm_(prm), fn_(fn) {}
+  Solver(const ndt_params& prm, const EvalFn& fn, bool h_in_trials) : prm_(prm), fn_(fn), h_in_trials_(h_in_trials) {}
 
   int evaluate(const double p[6], bool need_h) {
     pose_to_matrix(p, T_);
@@ -322,7 +322,7 @@ class Solver {
            !(psi <= 0 && dphi <= -nu * dphi0)) {
       a = open ? next_trial(lo, up, a, psi, dpsi) : next_trial(lo, up, a, phi, dphi);
       a = std::fmax(std::fmin(a, a_max), a_min);
-      rc = probe(false, &phi, &dphi);
+      rc = probe(h_in_trials_, &phi, &dphi);
       if (rc) return rc;
       psi = phi - phi0 - mu * dphi0 * a;
       dpsi = dphi - mu * dphi0;
@@ -334,7 +334,9 @@ class Solver {
       collapsed = open ? shrink(lo, up, a, psi, dpsi) : shrink(lo, up, a, phi, dphi);
       ++trials;
     }
-    if (trials) {  // the trial evaluations skipped the Hessian: get it at the accepted point
+    if (trials && h_in_trials_) {
+      std::memcpy(H, cur_.H, sizeof(double) * 36);  // the last trial IS the accepted point
+    } else if (trials) {  // the trial evaluations skipped the Hessian: get it at the accepted point
       const double s = cur_.score;
       double g[6];
       std::memcpy(g, cur_.g, sizeof(g));
@@ -350,6 +352,7 @@ class Solver {
 
   const ndt_params& prm_;
   const EvalFn& fn_;
+  bool h_in_trials_;
   Eval cur_;
   float T_[16];
   int n_evals_ = 0;
@@ -358,11 +361,11 @@ class Solver {
 }  // namespace
 
 int newton_align(const ndt_params& prm, int64_t n_source_total, const float guess[16],
-                 const EvalFn& fn, ndt_result* out) {
+                 const EvalFn& fn, ndt_result* out, bool hessian_in_trials) {
   const auto t0 = std::chrono::steady_clock::now();
   std::memset(out, 0, sizeof(*out));
   std::memcpy(out->final_transformation, guess, sizeof(float) * 16);
-  Solver sv(prm, fn);
+  Solver sv(prm, fn, hessian_in_trials);
   double p[6];
   matrix_to_pose(guess, p);
   // the first evaluation transforms the source by the guess matrix itself

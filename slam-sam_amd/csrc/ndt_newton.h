@@ -35,7 +35,10 @@ void finish_eval(const ndt_params& prm, const float* reg_pose, const double p[6]
 // fn(pose6, T, need_hessian, out) -> 0 on success
 using EvalFn = std::function<int(const double*, const float*, bool, Eval*)>;
 
+// hessian_in_trials: ask for the Hessian in every line-search trial instead of one extra
+// evaluation at the accepted step (same numbers -- the extra evaluation is at the pose of
+// the last trial -- one launch fewer per Newton iteration that needed trials).
 int newton_align(const ndt_params& prm, int64_t n_source_total, const float guess[16],
-                 const EvalFn& fn, ndt_result* out);
+                 const EvalFn& fn, ndt_result* out, bool hessian_in_trials = false);
 
 }  // namespace ndt
