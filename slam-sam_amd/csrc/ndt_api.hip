@@ -81,7 +81,8 @@ struct ndt_handle {
   DevBuf<uint32_t> keys, vals, keys2, vals2;
   DevBuf<char> sort_tmp;
   DevBuf<int> nleaf;                 // [0] slots, [1] valid
-  DevBuf<int> leaf_start, leaf_cnt;
+  DevBuf<int> leaf_start, leaf_cnt, run_counts, run_offsets;
+  DevBuf<double> leaf_sums;
   DevBuf<int> cell2leaf;
   DevBuf<VoxelRecord> rec;
   DevBuf<LeafStats> stats;
@@ -230,6 +231,9 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
   HIP_TRY(h, h->leaf_cnt.ensure((size_t)max_leaves));
   HIP_TRY(h, h->rec.ensure((size_t)max_leaves));
   HIP_TRY(h, h->stats.ensure((size_t)max_leaves));
+  HIP_TRY(h, h->leaf_sums.ensure((size_t)max_leaves * 9));
+  HIP_TRY(h, h->run_counts.ensure((size_t)runs_blocks(n)));
+  HIP_TRY(h, h->run_offsets.ensure((size_t)runs_blocks(n)));
   const size_t tmp_bytes = sort_temp_bytes(n);
   HIP_TRY(h, h->sort_tmp.ensure(tmp_bytes));
 
@@ -239,10 +243,11 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
   int bits = 1;
   while (bits < 32 && (1ull << bits) <= (unsigned long long)g.ncells) ++bits;  // sentinel = ncells
   HIP_TRY(h, sort_pairs(h->sort_tmp.p, tmp_bytes, h->keys.p, h->keys2.p, h->vals.p, h->vals2.p, n, bits, s));
-  launch_find_runs(h->keys2.p, n, g.ncells, min_pts, h->nleaf.p, h->leaf_start.p, h->leaf_cnt.p, s);
+  launch_find_runs(h->keys2.p, n, g.ncells, min_pts, h->nleaf.p, h->run_counts.p, h->run_offsets.p,
+                   h->leaf_start.p, h->leaf_cnt.p, s);
   FinalizeParams fp{h->prm.eig_inflation_ratio, h->prm.cov_mode};
   launch_finalize_leaves(x, y, z, h->keys2.p, h->vals2.p, h->nleaf.p, h->leaf_start.p, h->leaf_cnt.p,
-                         max_leaves, fp, h->rec.p, h->stats.p, h->cell2leaf.p, s);
+                         max_leaves, fp, h->leaf_sums.p, h->rec.p, h->stats.p, h->cell2leaf.p, s);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemcpyAsync(h->small.h + 8, h->nleaf.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
   HIP_TRY(h, hipEventRecord(h->ev1, s));
@@ -444,6 +449,7 @@ int ndt_destroy(ndt_handle* h) {
   h->keys.release(); h->vals.release(); h->keys2.release(); h->vals2.release();
   h->sort_tmp.release(); h->nleaf.release(); h->leaf_start.release(); h->leaf_cnt.release();
   h->cell2leaf.release(); h->rec.release(); h->stats.release();
+  h->run_counts.release(); h->run_offsets.release(); h->leaf_sums.release();
   h->sx.release(); h->sy.release(); h->sz.release();
   h->stage.release(); h->result.release(); h->small.release(); h->partials.release();
   h->dres.release(); h->dposes.release(); h->hposes.release(); h->counters.release(); h->flag.release();

@@ -332,6 +332,13 @@ __device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], double
     for (int wv = 0; wv < NWAVES; ++wv) sum += lds_w[wv][threadIdx.x];
     store_agent(rows + (size_t)blockIdx.x * EV_WORDS + threadIdx.x, sum);
   }
+#if defined(NDT_ABL) && NDT_ABL == 4  // ablation: no tickets, block 0 publishes
+  if (blockIdx.x == 0 && flag != nullptr && threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  return;
+#endif
   const int nb = (int)gridDim.x;
   int ngroups = 1;
   if (nb > SINGLE_LEVEL_MAX) {
@@ -406,13 +413,19 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
   a.npairs = 0;
   if (i < n) {
     x = sx[i]; y = sy[i]; z = sz[i];
+#if !(defined(NDT_ABL) && NDT_ABL >= 3)
     point_pairs(a, x, y, z, g, cell2leaf, rec, rt, ec);
+#endif
   }
   __syncthreads();  // angle tables visible
   double acc[EV_WORDS];
 #pragma unroll
   for (int v = 0; v < EV_WORDS; ++v) acc[v] = 0.0;
+#if defined(NDT_ABL) && NDT_ABL >= 3  // ablation: launch + reduction only
+  acc[0] = (double)(x + rt.R[0] + tab.jang[3]);
+#else
   if (a.npairs > 0) expand_point(acc, a, x, y, z, tab, ec);  // ref :592: no neighbour, no term
+#endif
   double* base = partials + (size_t)blockIdx.y * (gridDim.x + NGROUPS) * EV_WORDS;
   block_reduce_finish(acc, base + (size_t)NGROUPS * EV_WORDS, base, counters + blockIdx.y * COUNTERS_PER_POSE,
                       out + (size_t)blockIdx.y * EV_WORDS, BATCH ? nullptr : flag, seq);

@@ -21,19 +21,23 @@ hipError_t sort_pairs(void* temp, size_t temp_bytes, const uint32_t* keys_in, ui
                       const uint32_t* vals_in, uint32_t* vals_out, size_t n, int end_bit,
                       hipStream_t s);
 
-// runs of equal cell key with >= min_pts points get a leaf slot
-void launch_find_runs(const uint32_t* keys_sorted, size_t n, int ncells, int min_pts,
-                      int* d_nleaf, int* leaf_start, int* leaf_cnt, hipStream_t s);
+// runs of equal cell key with >= min_pts points get a leaf slot (ascending cell order);
+// block_counts / block_offsets: runs_blocks(n) ints each; d_nleaf[0] receives the total
+int runs_blocks(size_t n);
+void launch_find_runs(const uint32_t* keys_sorted, size_t n, int ncells, int min_pts, int* d_nleaf,
+                      int* block_counts, int* block_offsets, int* leaf_start, int* leaf_cnt,
+                      hipStream_t s);
 
 struct FinalizeParams {
   double eig_ratio;
   int cov_mode;  // 0 svn, 1 pcl (recalled)
 };
+// sums: 9 doubles per leaf slot (scratch)
 void launch_finalize_leaves(const float* x, const float* y, const float* z,
                             const uint32_t* keys_sorted, const uint32_t* vals_sorted,
                             int* d_nleaf /* [0]=slots, [1]=valid */, const int* leaf_start,
-                            const int* leaf_cnt, int max_leaves, FinalizeParams fp, VoxelRecord* rec, LeafStats* stats,
-                            int* cell2leaf, hipStream_t s);
+                            const int* leaf_cnt, int max_leaves, FinalizeParams fp, double* sums,
+                            VoxelRecord* rec, LeafStats* stats, int* cell2leaf, hipStream_t s);
 
 // ---- derivative evaluation (ndt_derivs.hip) ---------------------------------
 int derivs_grid_blocks(size_t n_src);

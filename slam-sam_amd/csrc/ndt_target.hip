@@ -10,10 +10,12 @@
 //   2. cell keys     : one streaming pass (f32 floor, bit-compatible with the ref)
 //   3. stable LSD radix sort of (cell, point index) -- points of one voxel become
 //                      contiguous and stay in input order (deterministic sums)
-//   4. run detection : heads find their run length by galloping search
-//   5. leaf finalise : 8 lanes per voxel gather + reduce in f64, lane 0 does the
-//                      3x3 Jacobi eigen-solve / inflation / inverse and publishes
-//                      an 80-byte VoxelRecord and the dense cell -> leaf index.
+//   4. run detection : run tails find their head through a wave ballot; leaf slots by
+//                      count / scan / emit (ascending cell order, no atomics)
+//   5. leaf sums     : 8 lanes per voxel gather + reduce sum(x), sum(x x^T) in f64
+//   6. leaf finalise : one thread per voxel: 3x3 Jacobi eigen-solve / inflation /
+//                      inverse; publishes an 80-byte VoxelRecord and the dense
+//                      cell -> leaf index.
 // Compiled with -ffp-contract=off: f32 index arithmetic must round as written.
 #include "ndt_kernels.h"
 
@@ -113,12 +115,18 @@ __global__ void __launch_bounds__(256) k_cell_keys(const float* __restrict__ x, 
 // Runs of equal cell key in the sorted array.  Each run TAIL finds its head: inside
 // the wave through a ballot of head flags (no memory traffic), and only for runs
 // that began in an earlier wave by a backward gallop + bisection.  Runs with at
-// least min_pts points get a leaf slot (ref: voxel_grid_covariance_impl.hpp:270-273).
-__global__ void __launch_bounds__(256) k_find_runs(const uint32_t* __restrict__ keys, int n, int ncells,
-                                                  int min_pts, int* nleaf, int* __restrict__ leaf_start,
-                                                  int* __restrict__ leaf_cnt) {
+// least min_pts points become leaves (ref: voxel_grid_covariance_impl.hpp:270-273).
+// Leaf slots are handed out by a count / scan / emit triple instead of a global
+// atomic counter (one contended address served ~90 adds/us and cost 0.1 ms): slots
+// come out in ascending cell order, identically on every run.
+template <bool EMIT>
+__global__ void __launch_bounds__(256) k_runs(const uint32_t* __restrict__ keys, int n, int ncells, int min_pts,
+                                             int* __restrict__ block_counts,
+                                             const int* __restrict__ block_offsets,
+                                             int* __restrict__ leaf_start, int* __restrict__ leaf_cnt) {
+  __shared__ int wave_total[4];
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t sentinel = 0xFFFFFFFFu;
   const uint32_t key = s < n ? keys[s] : sentinel;
   uint32_t prev = __shfl_up(key, 1), next = __shfl_down(key, 1);
@@ -128,33 +136,72 @@ __global__ void __launch_bounds__(256) k_find_runs(const uint32_t* __restrict__ 
   const bool head = valid && (s == 0 || prev != key);
   const bool tail = valid && (s == n - 1 || next != key);
   const unsigned long long heads = __ballot(head);
-  if (!tail) return;
-  int start;
-  const unsigned long long below = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
-  if (below) {
-    start = s - (lane - (63 - __clzll((long long)below)));
-  } else {
-    // the run began before this wave: keys[wave_base] == key; walk back
-    int hi = s - lane;  // known to hold key
-    int step = 1, lo;
-    for (;;) {
-      int nx = hi - step;
-      if (nx < 0) { lo = -1; break; }
-      if (keys[nx] != key) { lo = nx; break; }
-      hi = nx;
-      step <<= 1;
+  int start = s;
+  if (tail) {
+    const unsigned long long below = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+    if (below) {
+      start = s - (lane - (63 - __clzll((long long)below)));
+    } else {
+      // the run began before this wave: keys[wave_base] == key; walk back
+      int hi = s - lane;  // known to hold key
+      int step = 1, lo;
+      for (;;) {
+        int nx = hi - step;
+        if (nx < 0) { lo = -1; break; }
+        if (keys[nx] != key) { lo = nx; break; }
+        hi = nx;
+        step <<= 1;
+      }
+      while (hi - lo > 1) {  // keys[lo] != key (or lo == -1), keys[hi] == key
+        int mid = (lo + hi) >> 1;
+        if (keys[mid] == key) hi = mid; else lo = mid;
+      }
+      start = hi;
     }
-    while (hi - lo > 1) {  // keys[lo] != key (or lo == -1), keys[hi] == key
-      int mid = (lo + hi) >> 1;
-      if (keys[mid] == key) hi = mid; else lo = mid;
-    }
-    start = hi;
   }
   const int cnt = s - start + 1;
-  if (cnt < min_pts) return;
-  const int slot = atomicAdd(nleaf, 1);
+  const bool leaf = tail && cnt >= min_pts;
+  const unsigned long long leaves = __ballot(leaf);
+  if (lane == 0) wave_total[wave] = __popcll(leaves);
+  __syncthreads();
+  if (!EMIT) {
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3];
+    return;
+  }
+  if (!leaf) return;
+  int slot = block_offsets[blockIdx.x] + __popcll(leaves & ((1ull << lane) - 1ull));
+  for (int w = 0; w < wave; ++w) slot += wave_total[w];
   leaf_start[slot] = start;
   leaf_cnt[slot] = cnt;
+}
+
+// exclusive scan of the per-block leaf counts (one block; a few thousand values)
+__global__ void __launch_bounds__(1024) k_scan_counts(const int* __restrict__ counts, int nblocks,
+                                                     int* __restrict__ offsets, int* __restrict__ total) {
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int base = 0; base < nblocks; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < nblocks ? counts[i] : 0;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      int t = __shfl_up(incl, off);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int before = carry;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    if (i < nblocks) offsets[i] = before + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = before + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) total[0] = carry;
 }
 
 // one Jacobi rotation of the symmetric 3x3 A (full storage) in the (P,Q) plane
@@ -194,36 +241,61 @@ __device__ __forceinline__ void jacobi_rot(double A[9], double V[9]) {
   }
 
 constexpr int LANES_PER_LEAF = 8;
+constexpr int SUMS_BLOCKS_MAX = 2048;
 
-// ref: voxel_grid_covariance_impl.hpp:236-239 (sums), :265-343 (finalisation)
-__global__ void __launch_bounds__(256) k_finalize_leaves(
-    const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
-    const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, int* __restrict__ nleaf_p,
-    const int* __restrict__ leaf_start, const int* __restrict__ leaf_cnt, FinalizeParams fp,
-    VoxelRecord* __restrict__ rec, LeafStats* __restrict__ stats, int* __restrict__ cell2leaf) {
-  const int nleaf = *nleaf_p;
-  const int slot = (blockIdx.x * blockDim.x + threadIdx.x) / LANES_PER_LEAF;
+// ref: voxel_grid_covariance_impl.hpp:236-239 -- per-voxel sum(x) and sum(x x^T) in f64.
+// 8 lanes per leaf gather its points (stable sort => ascending input order) and a fixed
+// 3-step xor tree adds the 8 partial sums: deterministic.
+__global__ void __launch_bounds__(256) k_leaf_sums(const float* __restrict__ x, const float* __restrict__ y,
+                                                  const float* __restrict__ z, const uint32_t* __restrict__ vals,
+                                                  const int* __restrict__ nleaf_p,
+                                                  const int* __restrict__ leaf_start,
+                                                  const int* __restrict__ leaf_cnt, double* __restrict__ sums) {
+  const int nleaf = nleaf_p[0];
   const int sub = threadIdx.x & (LANES_PER_LEAF - 1);
-  const bool live = slot < nleaf;
-  int start = 0, cnt = 0;
-  if (live) { start = leaf_start[slot]; cnt = leaf_cnt[slot]; }
-  double s[3] = {0, 0, 0}, ss[6] = {0, 0, 0, 0, 0, 0};
-  for (int j = sub; j < cnt; j += LANES_PER_LEAF) {
-    uint32_t pi = vals[start + j];
-    double a = (double)x[pi], b = (double)y[pi], c = (double)z[pi];
-    s[0] += a; s[1] += b; s[2] += c;
-    ss[0] += a * a; ss[1] += a * b; ss[2] += a * c;
-    ss[3] += b * b; ss[4] += b * c; ss[5] += c * c;
+  const int per_block = 256 / LANES_PER_LEAF;
+  for (int slot = blockIdx.x * per_block + threadIdx.x / LANES_PER_LEAF; slot < nleaf;
+       slot += gridDim.x * per_block) {
+    const int start = leaf_start[slot], cnt = leaf_cnt[slot];
+    double s[3] = {0, 0, 0}, ss[6] = {0, 0, 0, 0, 0, 0};
+    for (int j = sub; j < cnt; j += LANES_PER_LEAF) {
+      const uint32_t pi = vals[start + j];
+      const double a = (double)x[pi], b = (double)y[pi], c = (double)z[pi];
+      s[0] += a; s[1] += b; s[2] += c;
+      ss[0] += a * a; ss[1] += a * b; ss[2] += a * c;
+      ss[3] += b * b; ss[4] += b * c; ss[5] += c * c;
+    }
+#pragma unroll
+    for (int off = 1; off < LANES_PER_LEAF; off <<= 1) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) s[a] += __shfl_xor(s[a], off);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) ss[a] += __shfl_xor(ss[a], off);
+    }
+    // the 8 lanes hold identical sums; lane k writes word k, lane 0 also word 8
+    double* o = sums + (size_t)slot * 9;
+    const double mine = sub == 0 ? s[0] : sub == 1 ? s[1] : sub == 2 ? s[2] : sub == 3 ? ss[0]
+                      : sub == 4 ? ss[1] : sub == 5 ? ss[2] : sub == 6 ? ss[3] : ss[4];
+    o[sub] = mine;
+    if (sub == 0) o[8] = ss[5];
   }
-#pragma unroll
-  for (int off = 1; off < LANES_PER_LEAF; off <<= 1) {
-#pragma unroll
-    for (int a = 0; a < 3; ++a) s[a] += __shfl_xor(s[a], off);
-#pragma unroll
-    for (int a = 0; a < 6; ++a) ss[a] += __shfl_xor(ss[a], off);
-  }
-  if (!live || sub != 0) return;
+}
 
+// ref: voxel_grid_covariance_impl.hpp:265-343 -- one thread per leaf: mean, covariance,
+// eigen-decomposition, eigenvalue inflation, inverse, validity checks.
+__global__ void __launch_bounds__(256) k_leaf_finalize(const uint32_t* __restrict__ keys,
+                                                      int* __restrict__ nleaf_p,
+                                                      const int* __restrict__ leaf_start,
+                                                      const int* __restrict__ leaf_cnt,
+                                                      const double* __restrict__ sums, FinalizeParams fp,
+                                                      VoxelRecord* __restrict__ rec, LeafStats* __restrict__ stats,
+                                                      int* __restrict__ cell2leaf) {
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= nleaf_p[0]) return;
+  const int start = leaf_start[slot], cnt = leaf_cnt[slot];
+  const double* in = sums + (size_t)slot * 9;
+  const double s[3] = {in[0], in[1], in[2]};
+  const double ss[6] = {in[3], in[4], in[5], in[6], in[7], in[8]};
   const int cell = (int)keys[start];
   const double n = (double)cnt;
   double mean[3] = {s[0] / n, s[1] / n, s[2] / n};  // ref :278
@@ -368,39 +440,54 @@ void launch_cell_keys(const float* x, const float* y, const float* z, size_t n, 
   hipLaunchKernelGGL(k_cell_keys, dim3((unsigned)blocks), dim3(256), 0, s, x, y, z, n, g, keys, vals);
 }
 
+// rocPRIM's default switches to a merge sort below 1M items (10 merge passes, ~165 us for the
+// 1M-point map); the onesweep LSD radix sort needs ceil(bits/8) passes over the keys only.
+#ifndef NDT_SORT_MERGE_LIMIT
+#define NDT_SORT_MERGE_LIMIT 16384
+#endif
+using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                              rocprim::default_config, NDT_SORT_MERGE_LIMIT>;
+
 size_t sort_temp_bytes(size_t n) {
   size_t bytes = 0;
   uint32_t* p = nullptr;
-  (void)rocprim::radix_sort_pairs(nullptr, bytes, p, p, p, p, n, 0, 32, (hipStream_t)0);
+  (void)rocprim::radix_sort_pairs<SortConfig>(nullptr, bytes, p, p, p, p, n, 0, 32, (hipStream_t)0);
   return bytes;
 }
 
 hipError_t sort_pairs(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
                       const uint32_t* vals_in, uint32_t* vals_out, size_t n, int end_bit,
                       hipStream_t s) {
-  return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0,
-                                   (unsigned)end_bit, s);
+  return rocprim::radix_sort_pairs<SortConfig>(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out,
+                                               n, 0, (unsigned)end_bit, s);
 }
 
+int runs_blocks(size_t n) { return (int)((n + 255) / 256); }
+
 void launch_find_runs(const uint32_t* keys_sorted, size_t n, int ncells, int min_pts, int* d_nleaf,
-                      int* leaf_start, int* leaf_cnt, hipStream_t s) {
+                      int* block_counts, int* block_offsets, int* leaf_start, int* leaf_cnt,
+                      hipStream_t s) {
   if (n == 0) return;
-  size_t blocks = (n + 255) / 256;
-  hipLaunchKernelGGL(k_find_runs, dim3((unsigned)blocks), dim3(256), 0, s, keys_sorted, (int)n,
-                     ncells, min_pts, d_nleaf, leaf_start, leaf_cnt);
+  const int blocks = runs_blocks(n);
+  hipLaunchKernelGGL(k_runs<false>, dim3(blocks), dim3(256), 0, s, keys_sorted, (int)n, ncells, min_pts,
+                     block_counts, (const int*)nullptr, leaf_start, leaf_cnt);
+  hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, block_counts, blocks, block_offsets, d_nleaf);
+  hipLaunchKernelGGL(k_runs<true>, dim3(blocks), dim3(256), 0, s, keys_sorted, (int)n, ncells, min_pts,
+                     block_counts, block_offsets, leaf_start, leaf_cnt);
 }
 
 void launch_finalize_leaves(const float* x, const float* y, const float* z,
                             const uint32_t* keys_sorted, const uint32_t* vals_sorted,
                             int* d_nleaf, const int* leaf_start, const int* leaf_cnt,
-                            int max_leaves, FinalizeParams fp, VoxelRecord* rec, LeafStats* stats,
-                            int* cell2leaf, hipStream_t s) {
+                            int max_leaves, FinalizeParams fp, double* sums, VoxelRecord* rec,
+                            LeafStats* stats, int* cell2leaf, hipStream_t s) {
   if (max_leaves <= 0) return;
-  size_t threads = (size_t)max_leaves * LANES_PER_LEAF;
-  size_t blocks = (threads + 255) / 256;
-  hipLaunchKernelGGL(k_finalize_leaves, dim3((unsigned)blocks), dim3(256), 0, s, x, y, z,
-                     keys_sorted, vals_sorted, d_nleaf, leaf_start, leaf_cnt, fp, rec, stats,
-                     cell2leaf);
+  size_t blocks = ((size_t)max_leaves * LANES_PER_LEAF + 255) / 256;
+  if (blocks > (size_t)SUMS_BLOCKS_MAX) blocks = SUMS_BLOCKS_MAX;
+  hipLaunchKernelGGL(k_leaf_sums, dim3((unsigned)blocks), dim3(256), 0, s, x, y, z, vals_sorted, d_nleaf,
+                     leaf_start, leaf_cnt, sums);
+  hipLaunchKernelGGL(k_leaf_finalize, dim3((unsigned)((max_leaves + 255) / 256)), dim3(256), 0, s,
+                     keys_sorted, d_nleaf, leaf_start, leaf_cnt, sums, fp, rec, stats, cell2leaf);
 }
 
 }  // namespace ndt
