@@ -1,0 +1,84 @@
+// The reference's ConvergenceComparison.PclOmp test
+// (ref: extern/svn_ndt/test/test_svn_ndt.cpp:138-199) written against the C++ adapter's
+// PCL-free face.  Exit code 0 = pass.  Needs an MI355X; run by tests/test_gpu_cpp_adapter.py.
+#include <cmath>
+#include <cstdio>
+#include <random>
+
+#include "ndt_hip/ndt_hip.hpp"
+
+using PointT = ndt_hip::PointXYZ;
+using Cloud = ndt_hip::PointCloud<PointT>;
+
+static void matmul4(const double* A, const double* B, double* C) {  // column-major
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r) {
+      double s = 0;
+      for (int k = 0; k < 4; ++k) s += A[4 * k + r] * B[4 * c + k];
+      C[4 * c + r] = s;
+    }
+}
+
+int main() {
+  // ground truth Rz(0.2618) Ry(0.0873), t = (0.5, 0, 0.3); guess = gt with a small error
+  const double cz = std::cos(0.2618), sz = std::sin(0.2618), cy = std::cos(0.0873), sy = std::sin(0.0873);
+  double gt[16] = {cz * cy, sz * cy, -sy, 0, -sz, cz, 0, 0, cz * sy, sz * sy, cy, 0, 0.5, 0.0, 0.3, 1};
+  const double a = -0.03;  // small yaw + translation error
+  double d[16] = {std::cos(a), std::sin(a), 0, 0, -std::sin(a), std::cos(a), 0, 0, 0, 0, 1, 0, -0.02, 0.01, -0.03, 1};
+  double guess_d[16];
+  matmul4(gt, d, guess_d);
+
+  auto src = std::make_shared<Cloud>();
+  auto tgt = std::make_shared<Cloud>();
+  std::mt19937 gen(1337);
+  std::normal_distribution<double> noise(0.0, 0.02);
+  for (int plane = 0; plane < 2; ++plane)
+    for (double u = -10.0; u <= 10.0; u += 0.15)
+      for (double v = -10.0; v <= 10.0; v += 0.15) {
+        PointT p{(float)u, plane ? 0.0f : (float)v, plane ? (float)v : 0.0f, 1.0f};
+        src->points.push_back(p);
+        double q[3];
+        for (int r = 0; r < 3; ++r) q[r] = gt[r] * p.x + gt[4 + r] * p.y + gt[8 + r] * p.z + gt[12 + r] + noise(gen);
+        tgt->points.push_back(PointT{(float)q[0], (float)q[1], (float)q[2], 1.0f});
+      }
+
+  ndt_hip::NormalDistributionsTransform<PointT, PointT> ndt;
+  if (ndt.lastStatus() != NDT_OK) { std::printf("FAIL: engine: %s\n", ndt.lastError().c_str()); return 2; }
+  ndt.setResolution(1.0f);
+  ndt.setNeighborhoodSearchMethod(ndt_hip::DIRECT7);
+  ndt.setMaximumIterations(50);
+  ndt.setTransformationEpsilon(1e-4);
+  ndt.setStepSize(0.1);
+  ndt.setNumThreads(20);
+  ndt.setInputTarget(tgt);
+  ndt.setInputSource(src);
+  ndt_hip::Matrix4f guess;
+  for (int i = 0; i < 16; ++i) guess[i] = (float)guess_d[i];
+  Cloud out;
+  ndt.setFillOutputCloud(true);
+  ndt.computeTransformation(out, guess);
+  const bool converged = ndt.hasConverged();
+  const int iters = ndt.getFinalNumIteration();
+  ndt_hip::Matrix4f T = ndt.getFinalTransformation();
+  double terr = 0, tr = 0;
+  for (int r = 0; r < 3; ++r) terr += (T[12 + r] - gt[12 + r]) * (T[12 + r] - gt[12 + r]);
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) tr += T[4 * c + r] * gt[4 * c + r];  // trace(R^T Rgt)
+  const double rerr = std::acos(std::fmin(1.0, std::fmax(-1.0, (tr - 1.0) / 2.0)));
+  auto res = ndt.getResult();
+  const auto& cells = ndt.getTargetCells();
+  std::printf("converged=%d iterations=%d trans_err=%.5f rot_err=%.5f leaves=%zu out=%zu H00=%.3g nvtl=%.3f\n",
+              (int)converged, iters, std::sqrt(terr), rerr, cells.getLeaves().size(), out.size(), res.hessian[0],
+              res.nearest_voxel_transformation_likelihood);
+  bool ok = converged && iters < 50 && std::sqrt(terr) < 0.05 && rerr < 0.035;
+  ok = ok && res.iteration_num == iters && res.hessian[0] < 0.0 && !cells.getLeaves().empty();
+  ok = ok && out.size() == src->size();
+  // failure path: aligning an engine without clouds returns the guess, not converged, no throw
+  ndt_hip::NormalDistributionsTransform<PointT, PointT> empty;
+  Cloud o2;
+  empty.computeTransformation(o2, guess);
+  ok = ok && !empty.hasConverged() && empty.lastStatus() == NDT_ERR_NO_TARGET &&
+       empty.getFinalTransformation() == guess;
+  std::printf(ok ? "PASS\n" : "FAIL\n");
+  return ok ? 0 : 1;
+}
