@@ -790,6 +790,9 @@ int ndt_comm_destroy(ndt_handle* h) {
   return NDT_OK;
 }
 
+// diagnostic builds only (-DNDT_STAMPS): 8 x 100 MHz stamps per block of the last launch
+int ndt_debug_read_stamps(unsigned long long* out, int nblocks) { return derivs_read_stamps(out, nblocks); }
+
 int ndt_enable_kernel_timing(ndt_handle* h, int on) {
   if (!h) return NDT_ERR_INVALID_ARG;
   h->timing = on != 0;

@@ -21,11 +21,13 @@
 // round exactly as written to classify points into the same voxels as the ref.
 #include "ndt_kernels.h"
 
+#include <cstdlib>
+
 namespace ndt {
 
 namespace {
 
-constexpr int BLOCK = 512;  // 8 waves: fewer partial rows for the in-kernel final sum
+constexpr int MAX_BLOCK = 1024;  // block size is chosen per launch (derivs_block_threads), <= 16 waves
 
 // ref: voxel_grid_covariance_impl.hpp:46-71 (f32 bounds) +
 // voxel_grid_covariance.h:297-300 (index).  -1 = outside the grid.
@@ -51,31 +53,41 @@ struct PairAcc {
 };
 
 // ref: svn_ndt_impl.hpp:401-447 (guards, exp, factor); accumulation refactored
+// MODE: 0 = score + gradient only, 1 = full analytic Hessian, 2 = Gauss-Newton Hessian.
+// A template parameter (not a run-time flag) so each pair is one straight-line block and
+// the compiler is free to keep several records in flight.
+template <int MODE>
 __device__ __forceinline__ void pair_update(PairAcc& a, const VoxelRecord& r, float xt, float yt,
-                                            float zt, const EvalConsts& ec) {
+                                            float zt, const EvalConsts& ec, bool present) {
 #pragma clang fp contract(fast)  // f64 accumulation may fuse; only the f32 transform / index math may not
   double x0 = (double)xt - r.mean[0], x1 = (double)yt - r.mean[1], x2 = (double)zt - r.mean[2];
   double v0 = r.icov[0] * x0 + r.icov[1] * x1 + r.icov[2] * x2;
   double v1 = r.icov[1] * x0 + r.icov[3] * x1 + r.icov[4] * x2;
   double v2 = r.icov[2] * x0 + r.icov[4] * x1 + r.icov[5] * x2;
   double q = x0 * v0 + x1 * v1 + x2 * v2;
-  a.npairs += 1;
-  if (!isfinite(q) || q < -1e-9) return;
-  if (q < 0.0) q = 0.0;
-  double earg = ec.d2 * q * 0.5;
-  if (earg > 50.0) return;
-  double e = exp(-earg);
-  double sc = -ec.d1 * e;
+  a.npairs += present ? 1 : 0;
+  // The reference's guards (ref :421-447) as predicates instead of early returns, so the 7
+  // unrolled pairs do not each split the wave three more times:
+  //   q non-finite or < -1e-9 -> no contribution;  d2*q/2 > 50 -> no contribution;
+  //   |d1*d2*e| < 1e-15 -> score only.
+  bool ok = present && isfinite(q) && !(q < -1e-9);
+  q = fmax(q, 0.0);
+  const double earg = ec.d2 * q * 0.5;
+  ok = ok && !(earg > 50.0);
+  const double e = exp(-fmin(earg, 50.0));
+  const double sc = ok ? -ec.d1 * e : 0.0;
   a.score += sc;
   a.best = fmax(a.best, sc);
   double f = ec.d1 * ec.d2 * e;
-  if (!(fabs(f) >= 1e-15)) return;
+  const bool dok = ok && fabs(f) >= 1e-15;
+  f = dok ? f : 0.0;
+  if (!ok) { v0 = 0.0; v1 = 0.0; v2 = 0.0; }  // keeps a NaN/Inf v out of the sums
   a.w[0] += f * v0; a.w[1] += f * v1; a.w[2] += f * v2;
-  if (ec.need_hessian) {
+  if (MODE != 0) {
     a.S[0] += f * r.icov[0]; a.S[1] += f * r.icov[1]; a.S[2] += f * r.icov[2];
     a.S[3] += f * r.icov[3]; a.S[4] += f * r.icov[4]; a.S[5] += f * r.icov[5];
-    if (!ec.gauss_newton) {
-      double fd = f * ec.d2;
+    if (MODE == 1) {
+      const double fd = f * ec.d2;
       a.S[0] -= fd * v0 * v0; a.S[1] -= fd * v0 * v1; a.S[2] -= fd * v0 * v2;
       a.S[3] -= fd * v1 * v1; a.S[4] -= fd * v1 * v2; a.S[5] -= fd * v2 * v2;
     }
@@ -93,13 +105,16 @@ struct AngleTables {
   float hang[45];  // 15x3
 };
 
+template <int MODE>
 __device__ __forceinline__ void expand_point(double acc[EV_WORDS], const PairAcc& a, float x, float y,
-                                             float z, const AngleTables& P, const EvalConsts& ec) {
+                                             float z, const AngleTables& P) {
 #pragma clang fp contract(fast)
-  acc[EV_SCORE] += a.score;
-  acc[EV_NVTL] += a.best;
-  acc[EV_NWITH] += 1.0;
-  acc[EV_NPAIRS] += (double)a.npairs;
+  // Written for every thread: a point without neighbours (ref :592) has w = S = 0 and
+  // contributes exact zeros, so no divergent skip (and no per-path zero-fill) is needed.
+  acc[EV_SCORE] = a.score;
+  acc[EV_NVTL] = a.best;
+  acc[EV_NWITH] = a.npairs > 0 ? 1.0 : 0.0;
+  acc[EV_NPAIRS] = (double)a.npairs;
 
   // point Jacobian, angular block A (3x3) from the ORIGINAL point (ref :339-363)
   double A10 = (double)dot3f(P.jang + 0, x, y, z), A20 = (double)dot3f(P.jang + 3, x, y, z);
@@ -108,13 +123,18 @@ __device__ __forceinline__ void expand_point(double acc[EV_WORDS], const PairAcc
   double A02 = (double)dot3f(P.jang + 15, x, y, z), A12 = (double)dot3f(P.jang + 18, x, y, z);
   double A22 = (double)dot3f(P.jang + 21, x, y, z);
   const double w0 = a.w[0], w1 = a.w[1], w2 = a.w[2];
-  acc[EV_G + 0] += w0;
-  acc[EV_G + 1] += w1;
-  acc[EV_G + 2] += w2;
-  acc[EV_G + 3] += A10 * w1 + A20 * w2;
-  acc[EV_G + 4] += A01 * w0 + A11 * w1 + A21 * w2;
-  acc[EV_G + 5] += A02 * w0 + A12 * w1 + A22 * w2;
-  if (!ec.need_hessian) return;
+  acc[EV_G + 0] = w0;
+  acc[EV_G + 1] = w1;
+  acc[EV_G + 2] = w2;
+  acc[EV_G + 3] = A10 * w1 + A20 * w2;
+  acc[EV_G + 4] = A01 * w0 + A11 * w1 + A21 * w2;
+  acc[EV_G + 5] = A02 * w0 + A12 * w1 + A22 * w2;
+  acc[31] = 0.0;
+  if (MODE == 0) {
+#pragma unroll
+    for (int k = 0; k < 21; ++k) acc[EV_H + k] = 0.0;
+    return;
+  }
 
   const double Sxx = a.S[0], Sxy = a.S[1], Sxz = a.S[2], Syy = a.S[3], Syz = a.S[4], Szz = a.S[5];
   // B = S * A
@@ -126,9 +146,9 @@ __device__ __forceinline__ void expand_point(double acc[EV_WORDS], const PairAcc
          B22 = Sxz * A02 + Syz * A12 + Szz * A22;
   double* H = acc + EV_H;
   // row 0: H00..H05 ; row 1: H11..H15 ; row 2: H22..H25
-  H[0] += Sxx; H[1] += Sxy; H[2] += Sxz; H[3] += B00; H[4] += B01; H[5] += B02;
-  H[6] += Syy; H[7] += Syz; H[8] += B10; H[9] += B11; H[10] += B12;
-  H[11] += Szz; H[12] += B20; H[13] += B21; H[14] += B22;
+  H[0] = Sxx; H[1] = Sxy; H[2] = Sxz; H[3] = B00; H[4] = B01; H[5] = B02;
+  H[6] = Syy; H[7] = Syz; H[8] = B10; H[9] = B11; H[10] = B12;
+  H[11] = Szz; H[12] = B20; H[13] = B21; H[14] = B22;
   // rotational block A^T S A (+ second-derivative term, full Hessian only)
   double R33 = A10 * B10 + A20 * B20;
   double R34 = A10 * B11 + A20 * B21;
@@ -136,7 +156,7 @@ __device__ __forceinline__ void expand_point(double acc[EV_WORDS], const PairAcc
   double R44 = A01 * B01 + A11 * B11 + A21 * B21;
   double R45 = A01 * B02 + A11 * B12 + A21 * B22;
   double R55 = A02 * B02 + A12 * B12 + A22 * B22;
-  if (!ec.gauss_newton) {
+  if (MODE == 1) {
     // ref :369-394 layout of the 15 second-derivative rows; term 3 of :479-489
     const float* h = P.hang;
     R33 += w1 * (double)dot3f(h + 0, x, y, z) + w2 * (double)dot3f(h + 3, x, y, z);
@@ -149,7 +169,7 @@ __device__ __forceinline__ void expand_point(double acc[EV_WORDS], const PairAcc
     R55 += w0 * (double)dot3f(h + 36, x, y, z) + w1 * (double)dot3f(h + 39, x, y, z) +
            w2 * (double)dot3f(h + 42, x, y, z);
   }
-  H[15] += R33; H[16] += R34; H[17] += R35; H[18] += R44; H[19] += R45; H[20] += R55;
+  H[15] = R33; H[16] = R34; H[17] = R35; H[18] = R44; H[19] = R45; H[20] = R55;
 }
 
 struct RigidRT {
@@ -158,6 +178,7 @@ struct RigidRT {
 };
 
 // Phase 1 of a point: transform, neighbour lookup, pair sums.  Needs only R|t.
+template <int MODE>
 __device__ __forceinline__ void point_pairs(PairAcc& a, float x, float y, float z, const GridGeom& g,
                                             const int* __restrict__ cell2leaf,
                                             const VoxelRecord* __restrict__ rec, const RigidRT& P,
@@ -170,7 +191,7 @@ __device__ __forceinline__ void point_pairs(PairAcc& a, float x, float y, float 
   float xt = P.R[0] * x + (P.R[1] * y + (P.R[2] * z + P.t[0]));
   float yt = P.R[3] * x + (P.R[4] * y + (P.R[5] * z + P.t[1]));
   float zt = P.R[6] * x + (P.R[7] * y + (P.R[8] * z + P.t[2]));
-  if (!(isfinite(xt) && isfinite(yt) && isfinite(zt))) return;  // ref :573
+  const bool finite = isfinite(xt) && isfinite(yt) && isfinite(zt);  // ref :573: such points are skipped
 
   // ref: voxel_grid_covariance_impl.hpp:560-600 -- neighbours are found by
   // offsetting the POINT by +-leaf in f32 and re-classifying it.
@@ -190,7 +211,7 @@ __device__ __forceinline__ void point_pairs(PairAcc& a, float x, float y, float 
   }
   int slot[7];
 #pragma unroll
-  for (int k = 0; k < 7; ++k) slot[k] = cell[k] >= 0 ? cell2leaf[cell[k]] : -1;
+  for (int k = 0; k < 7; ++k) slot[k] = (finite && cell[k] >= 0) ? cell2leaf[cell[k]] : -1;
 #if defined(NDT_ABL) && NDT_ABL == 1  // ablation: grid loads kept, no records / pair math
 #pragma unroll
   for (int k = 0; k < 7; ++k) slot[k] = slot[k] == 0x7fffffff ? 0 : -1;
@@ -198,13 +219,31 @@ __device__ __forceinline__ void point_pairs(PairAcc& a, float x, float y, float 
 #pragma unroll
   for (int k = 0; k < 7; ++k) slot[k] = cell[k] == 0x7fffffff ? 0 : -1;
 #endif
-#pragma unroll
-  for (int k = 0; k < 7; ++k) {
-    if (slot[k] >= 0) {
-      VoxelRecord r = rec[slot[k]];
-      pair_update(a, r, xt, yt, zt, ec);
-    }
-  }
+  // Fully predicated: an absent neighbour reads record 0 (a wave-wide broadcast) and is
+  // masked out, so the unrolled pairs carry no exec-mask splits and no accumulator merges.
+  // Records are fetched in two batches (4 + 3) so a point pays two L2 round trips for its
+  // neighbours instead of seven, within a 128-VGPR budget.
+  // Software-pipelined by hand: four records in flight, each further one requested as soon as
+  // one has been consumed.  The scheduling fences keep the compiler from sinking the loads
+  // back to their first use (it otherwise serialises seven L2 round trips per point).
+  const VoxelRecord r0 = rec[slot[0] >= 0 ? slot[0] : 0];
+  const VoxelRecord r1 = rec[slot[1] >= 0 ? slot[1] : 0];
+  const VoxelRecord r2 = rec[slot[2] >= 0 ? slot[2] : 0];
+  const VoxelRecord r3 = rec[slot[3] >= 0 ? slot[3] : 0];
+  __builtin_amdgcn_sched_barrier(0);
+  pair_update<MODE>(a, r0, xt, yt, zt, ec, slot[0] >= 0);
+  const VoxelRecord r4 = rec[slot[4] >= 0 ? slot[4] : 0];
+  __builtin_amdgcn_sched_barrier(0);
+  pair_update<MODE>(a, r1, xt, yt, zt, ec, slot[1] >= 0);
+  const VoxelRecord r5 = rec[slot[5] >= 0 ? slot[5] : 0];
+  __builtin_amdgcn_sched_barrier(0);
+  pair_update<MODE>(a, r2, xt, yt, zt, ec, slot[2] >= 0);
+  const VoxelRecord r6 = rec[slot[6] >= 0 ? slot[6] : 0];
+  __builtin_amdgcn_sched_barrier(0);
+  pair_update<MODE>(a, r3, xt, yt, zt, ec, slot[3] >= 0);
+  pair_update<MODE>(a, r4, xt, yt, zt, ec, slot[4] >= 0);
+  pair_update<MODE>(a, r5, xt, yt, zt, ec, slot[5] >= 0);
+  pair_update<MODE>(a, r6, xt, yt, zt, ec, slot[6] >= 0);
 }
 
 // Recursive-halving reduce-scatter of 32 f64 words over the wave: after 6 steps lane
@@ -254,11 +293,26 @@ __device__ __forceinline__ void wave_reduce_scatter32(double* acc, int lane) {
   acc[0] += __shfl_xor(acc[0], 1);
 }
 
+#ifdef NDT_STAMPS
+// diagnostic build only: 100 MHz wall-clock stamps of wave 0 / lane 0 of every block,
+// written to a side buffer no other code reads (cdna_hip_programming.md section 7)
+__device__ unsigned long long g_stamps[4096 * 8];
+#define NDT_STAMP(k)                                                                   \
+  do {                                                                                 \
+    if (threadIdx.x == 0 && blockIdx.x < 4096 && blockIdx.y == 0) {                    \
+      __builtin_amdgcn_s_waitcnt(0);                                                   \
+      g_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime();               \
+    }                                                                                  \
+  } while (0)
+#else
+#define NDT_STAMP(k) do {} while (0)
+#endif
+
 constexpr int NGROUPS = 32;          // second-level fan-in (only for grids above SINGLE_LEVEL_MAX rows)
 constexpr int SINGLE_LEVEL_MAX = 2048;  // rows one block adds directly
 constexpr int COUNTERS_PER_POSE = 1 + NGROUPS;
-constexpr int NWAVES = BLOCK / 64;
-constexpr int NCOLS = BLOCK / 32;    // row-parallel lanes of the final sum
+constexpr int MAX_WAVES = MAX_BLOCK / 64;
+constexpr int MAX_COLS = MAX_BLOCK / 32;  // row-parallel lanes of the final sum
 
 // Cross-block hand-off without cache-wide fences (cdna_hip_programming.md Guideline 16,
 // "every store sc1 ... every load sc1" form): rows are written with agent-scope
@@ -281,28 +335,28 @@ __device__ __forceinline__ int ticket_is_last(unsigned int* counter, unsigned in
 }
 
 // Fixed-order sum of rows [first, end): thread (c = tid>>5, v = tid&31) takes word v of
-// rows first+c, first+c+NCOLS, ...; 16 loads are issued before the first add so one
-// memory round trip covers 16*NCOLS rows.  The NCOLS column sums are then added in order.
+// rows first+c, first+c+ncols, ... (ncols = blockDim/32); 32 loads are issued before the
+// first add so one memory round trip covers 32*ncols rows.  The column sums are then added in order.
 __device__ __forceinline__ void sum_rows(const double* __restrict__ rows, int first, int end,
                                          double (*lds_c)[EV_WORDS], double* __restrict__ dst, bool dst_agent) {
   const int v = threadIdx.x & 31, c = threadIdx.x >> 5;
+  const int ncols = (int)blockDim.x >> 5;
   double s = 0.0;
-  for (int b0 = first + c; b0 < end; b0 += 16 * NCOLS) {
-    double t[16];
+  for (int b0 = first + c; b0 < end; b0 += 32 * ncols) {
+    double t[32];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int b = b0 + k * NCOLS;
+    for (int k = 0; k < 32; ++k) {
+      const int b = b0 + k * ncols;
       t[k] = b < end ? load_agent(rows + (size_t)b * EV_WORDS + v) : 0.0;
     }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) s += t[k];
+    for (int k = 0; k < 32; ++k) s += t[k];
   }
   lds_c[c][v] = s;
   __syncthreads();
   if (threadIdx.x < EV_WORDS) {
     double t = 0.0;
-#pragma unroll
-    for (int k = 0; k < NCOLS; ++k) t += lds_c[k][threadIdx.x];
+    for (int k = 0; k < ncols; ++k) t += lds_c[k][threadIdx.x];
     if (dst_agent) store_agent(dst + threadIdx.x, t); else dst[threadIdx.x] = t;
   }
 }
@@ -319,8 +373,8 @@ __device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], double
                                                     unsigned int* __restrict__ counters,
                                                     double* __restrict__ out,
                                                     unsigned long long* flag, unsigned long long seq) {
-  __shared__ double lds_w[NWAVES][EV_WORDS];
-  __shared__ double lds_c[NCOLS][EV_WORDS];
+  __shared__ double lds_w[MAX_WAVES][EV_WORDS];
+  __shared__ double lds_c[MAX_COLS][EV_WORDS];
   __shared__ int s_last;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   wave_reduce_scatter32(acc, lane);
@@ -328,10 +382,11 @@ __device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], double
   __syncthreads();
   if (threadIdx.x < EV_WORDS) {
     double sum = 0.0;
-#pragma unroll
-    for (int wv = 0; wv < NWAVES; ++wv) sum += lds_w[wv][threadIdx.x];
+    const int nwaves = (int)blockDim.x >> 6;
+    for (int wv = 0; wv < nwaves; ++wv) sum += lds_w[wv][threadIdx.x];
     store_agent(rows + (size_t)blockIdx.x * EV_WORDS + threadIdx.x, sum);
   }
+  NDT_STAMP(4);
 #if defined(NDT_ABL) && NDT_ABL == 4  // ablation: no tickets, block 0 publishes
   if (blockIdx.x == 0 && flag != nullptr && threadIdx.x == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -356,9 +411,11 @@ __device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], double
   }
   const int nrows = nb > SINGLE_LEVEL_MAX ? ngroups : nb;
   if (threadIdx.x == 0) s_last = ticket_is_last(counters, (unsigned int)(nb > SINGLE_LEVEL_MAX ? ngroups : nb));
+  NDT_STAMP(5);
   __syncthreads();
   if (!s_last) return;
   sum_rows(rows, 0, nrows, lds_c, out, false);
+  NDT_STAMP(6);
   if (threadIdx.x <= ngroups)  // leave the tickets at zero for the next launch
     __hip_atomic_store(counters + threadIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (flag != nullptr && threadIdx.x == 0) {
@@ -366,14 +423,11 @@ __device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], double
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+  NDT_STAMP(7);
 }
 
-#ifndef NDT_DERIV_WAVES_PER_SIMD
-#define NDT_DERIV_WAVES_PER_SIMD 4
-#endif
-
-template <bool BATCH>
-__global__ void __launch_bounds__(BLOCK, NDT_DERIV_WAVES_PER_SIMD)
+template <bool BATCH, int MODE>
+__global__ void __launch_bounds__(MAX_BLOCK)
 k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, int n,
               GridGeom g, const int* __restrict__ cell2leaf, const VoxelRecord* __restrict__ rec,
               PoseConsts pose_arg, const PoseConsts* __restrict__ poses, EvalConsts ec,
@@ -382,6 +436,7 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
   // R|t (12 dwords) stay in scalar registers; the 69 angle-table words are only needed
   // after the pair loop, so they are parked in LDS (81 live SGPRs would spill) and the
   // barrier that publishes them sits behind the memory-latency part of the kernel.
+  NDT_STAMP(0);
   __shared__ AngleTables tab;
   RigidRT rt;
   if (BATCH) {
@@ -392,7 +447,7 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
     for (int k = 0; k < 3; ++k) rt.t[k] = pg.t[k];
     const float* src = pg.jang;  // jang[24] and hang[45] are contiguous
     float* dst = tab.jang;
-    for (int k = threadIdx.x; k < 69; k += BLOCK) dst[k] = src[k];
+    for (int k = threadIdx.x; k < 69; k += (int)blockDim.x) dst[k] = src[k];
   } else {
 #pragma unroll
     for (int k = 0; k < 9; ++k) rt.R[k] = pose_arg.R[k];
@@ -407,25 +462,32 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
   }
   // exactly one source point per thread: the 32 accumulator words are only live from the
   // per-point expansion to the block reduction, not across the pair loop
-  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  const int i = blockIdx.x * (int)blockDim.x + threadIdx.x;
   float x = 0.0f, y = 0.0f, z = 0.0f;
   PairAcc a;
-  a.npairs = 0;
+  a.w[0] = a.w[1] = a.w[2] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) a.S[k] = 0.0;
+  a.score = 0.0; a.best = 0.0; a.npairs = 0;
   if (i < n) {
     x = sx[i]; y = sy[i]; z = sz[i];
+    NDT_STAMP(1);
 #if !(defined(NDT_ABL) && NDT_ABL >= 3)
-    point_pairs(a, x, y, z, g, cell2leaf, rec, rt, ec);
+    point_pairs<MODE>(a, x, y, z, g, cell2leaf, rec, rt, ec);
 #endif
   }
+  NDT_STAMP(2);
   __syncthreads();  // angle tables visible
   double acc[EV_WORDS];
+#if defined(NDT_ABL) && NDT_ABL >= 3  // ablation: launch + reduction only
 #pragma unroll
   for (int v = 0; v < EV_WORDS; ++v) acc[v] = 0.0;
-#if defined(NDT_ABL) && NDT_ABL >= 3  // ablation: launch + reduction only
   acc[0] = (double)(x + rt.R[0] + tab.jang[3]);
 #else
-  if (a.npairs > 0) expand_point(acc, a, x, y, z, tab, ec);  // ref :592: no neighbour, no term
+  if (a.npairs == 0) { x = 0.0f; y = 0.0f; z = 0.0f; }  // a skipped (e.g. non-finite) point must expand to exact zeros
+  expand_point<MODE>(acc, a, x, y, z, tab);
 #endif
+  NDT_STAMP(3);
   double* base = partials + (size_t)blockIdx.y * (gridDim.x + NGROUPS) * EV_WORDS;
   block_reduce_finish(acc, base + (size_t)NGROUPS * EV_WORDS, base, counters + blockIdx.y * COUNTERS_PER_POSE,
                       out + (size_t)blockIdx.y * EV_WORDS, BATCH ? nullptr : flag, seq);
@@ -449,8 +511,33 @@ size_t derivs_partials_words(size_t n_src, int K) {
 }
 int derivs_counters_per_pose() { return COUNTERS_PER_POSE; }
 
+int derivs_read_stamps(unsigned long long* out, int nblocks) {
+#ifdef NDT_STAMPS
+  if (nblocks > 4096) nblocks = 4096;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8 * nblocks) == hipSuccess ? nblocks : -1;
+#else
+  (void)out; (void)nblocks;
+  return 0;
+#endif
+}
+
+// Threads per block.  512 (8 waves) measured best on MI355X from 50k to 4M points: with
+// 126 VGPRs two such blocks fill a CU (4 waves/SIMD); smaller blocks multiply the partial
+// rows of the in-kernel final sum, larger ones make every wave wait on wider barriers
+// (sweep 128..832 in profiles/r01_block_sweep.txt).  NDT_DERIV_BLOCK overrides it for tuning.
+int derivs_block_threads(size_t n_src) {
+  (void)n_src;
+  static const int forced = [] {
+    const char* e = getenv("NDT_DERIV_BLOCK");  // multiple of 64, 64..1024
+    int v = e ? atoi(e) : 0;
+    return (v >= 64 && v <= MAX_BLOCK && v % 64 == 0) ? v : 0;
+  }();
+  return forced ? forced : 512;
+}
+
 int derivs_grid_blocks(size_t n_src) {
-  size_t blocks = (n_src + BLOCK - 1) / BLOCK;  // one point per thread
+  const size_t bt = (size_t)derivs_block_threads(n_src);
+  size_t blocks = (n_src + bt - 1) / bt;  // one point per thread
   if (blocks < 1) blocks = 1;
   return (int)blocks;
 }
@@ -462,15 +549,21 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
                         double* d_out, hipStream_t s, unsigned long long* d_flag,
                         unsigned long long seq) {
   const int blocks = derivs_grid_blocks(n_src);
+  const int threads = derivs_block_threads(n_src);
+  const int mode = !ec.need_hessian ? 0 : (ec.gauss_newton ? 2 : 1);
+#define NDT_LAUNCH(B, M, GY, FLAG, SEQ)                                                              \
+  hipLaunchKernelGGL((k_derivatives<B, M>), dim3(blocks, GY), dim3(threads), 0, s, sx, sy, sz, (int)n_src, \
+                     g, cell2leaf, rec, pose, d_poses, ec, d_partials, d_counters, d_out, FLAG, SEQ)
   if (d_poses) {
-    hipLaunchKernelGGL(k_derivatives<true>, dim3(blocks, K), dim3(BLOCK), 0, s, sx, sy, sz,
-                       (int)n_src, g, cell2leaf, rec, pose, d_poses, ec, d_partials, d_counters, d_out,
-                       (unsigned long long*)nullptr, 0ull);
+    if (mode == 0) NDT_LAUNCH(true, 0, K, (unsigned long long*)nullptr, 0ull);
+    else if (mode == 1) NDT_LAUNCH(true, 1, K, (unsigned long long*)nullptr, 0ull);
+    else NDT_LAUNCH(true, 2, K, (unsigned long long*)nullptr, 0ull);
   } else {
-    hipLaunchKernelGGL(k_derivatives<false>, dim3(blocks, 1), dim3(BLOCK), 0, s, sx, sy, sz,
-                       (int)n_src, g, cell2leaf, rec, pose, d_poses, ec, d_partials, d_counters, d_out,
-                       d_flag, seq);
+    if (mode == 0) NDT_LAUNCH(false, 0, 1, d_flag, seq);
+    else if (mode == 1) NDT_LAUNCH(false, 1, 1, d_flag, seq);
+    else NDT_LAUNCH(false, 2, 1, d_flag, seq);
   }
+#undef NDT_LAUNCH
 }
 
 void launch_transform(const float* sx, const float* sy, const float* sz, size_t n,

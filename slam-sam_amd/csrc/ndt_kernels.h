@@ -41,8 +41,10 @@ void launch_finalize_leaves(const float* x, const float* y, const float* z,
 
 // ---- derivative evaluation (ndt_derivs.hip) ---------------------------------
 int derivs_grid_blocks(size_t n_src);
+int derivs_block_threads(size_t n_src);
 size_t derivs_partials_words(size_t n_src, int K);  // doubles needed in d_partials
-int derivs_counters_per_pose();                     // ticket words per pose in d_counters
+int derivs_counters_per_pose();
+int derivs_read_stamps(unsigned long long* out, int nblocks);  // diagnostic builds (-DNDT_STAMPS) only                     // ticket words per pose in d_counters
 // d_partials: derivs_partials_words() doubles; d_counters: K * derivs_counters_per_pose()
 // zero-initialised ticket words (left at zero again by every launch); d_out: K * EV_WORDS doubles (device
 // memory or device-mapped pinned host memory).  If d_poses is null the single pose
