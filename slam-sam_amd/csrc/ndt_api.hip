@@ -83,6 +83,7 @@ struct ndt_handle {
   DevBuf<int> nleaf;                 // [0] slots, [1] valid
   DevBuf<int> leaf_start, leaf_cnt, run_counts, run_offsets;
   DevBuf<double> leaf_sums;
+  DevBuf<float> xyz4;                // packed float4 copy of the target for the gather
   DevBuf<int> cell2leaf;
   DevBuf<VoxelRecord> rec;
   DevBuf<LeafStats> stats;
@@ -223,6 +224,7 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
   const int max_leaves = (int)(n / (size_t)min_pts) + 1;
   HIP_TRY(h, h->cell2leaf.ensure((size_t)g.ncells));
   HIP_TRY(h, h->keys.ensure(n));
+  HIP_TRY(h, h->xyz4.ensure(4 * n));
   HIP_TRY(h, h->vals.ensure(n));
   HIP_TRY(h, h->keys2.ensure(n));
   HIP_TRY(h, h->vals2.ensure(n));
@@ -239,14 +241,14 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
 
   HIP_TRY(h, hipMemsetAsync(h->cell2leaf.p, 0xFF, (size_t)g.ncells * sizeof(int), s));
   HIP_TRY(h, hipMemsetAsync(h->nleaf.p, 0, 2 * sizeof(int), s));
-  launch_cell_keys(x, y, z, n, g, h->keys.p, h->vals.p, s);
+  launch_cell_keys(x, y, z, n, g, h->keys.p, h->vals.p, h->xyz4.p, s);
   int bits = 1;
   while (bits < 32 && (1ull << bits) <= (unsigned long long)g.ncells) ++bits;  // sentinel = ncells
   HIP_TRY(h, sort_pairs(h->sort_tmp.p, tmp_bytes, h->keys.p, h->keys2.p, h->vals.p, h->vals2.p, n, bits, s));
   launch_find_runs(h->keys2.p, n, g.ncells, min_pts, h->nleaf.p, h->run_counts.p, h->run_offsets.p,
                    h->leaf_start.p, h->leaf_cnt.p, s);
   FinalizeParams fp{h->prm.eig_inflation_ratio, h->prm.cov_mode};
-  launch_finalize_leaves(x, y, z, h->keys2.p, h->vals2.p, h->nleaf.p, h->leaf_start.p, h->leaf_cnt.p,
+  launch_finalize_leaves(h->xyz4.p, h->keys2.p, h->vals2.p, h->nleaf.p, h->leaf_start.p, h->leaf_cnt.p,
                          max_leaves, fp, h->leaf_sums.p, h->rec.p, h->stats.p, h->cell2leaf.p, s);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemcpyAsync(h->small.h + 8, h->nleaf.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -449,7 +451,7 @@ int ndt_destroy(ndt_handle* h) {
   h->keys.release(); h->vals.release(); h->keys2.release(); h->vals2.release();
   h->sort_tmp.release(); h->nleaf.release(); h->leaf_start.release(); h->leaf_cnt.release();
   h->cell2leaf.release(); h->rec.release(); h->stats.release();
-  h->run_counts.release(); h->run_offsets.release(); h->leaf_sums.release();
+  h->run_counts.release(); h->run_offsets.release(); h->leaf_sums.release(); h->xyz4.release();
   h->sx.release(); h->sy.release(); h->sz.release();
   h->stage.release(); h->result.release(); h->small.release(); h->partials.release();
   h->dres.release(); h->dposes.release(); h->hposes.release(); h->counters.release(); h->flag.release();

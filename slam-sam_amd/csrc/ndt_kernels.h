@@ -13,8 +13,9 @@ void launch_bounds(const float* x, const float* y, const float* z, size_t n, int
 void fold_bounds(const int* rows, int nrows, int out[8]);
 float decode_ordered(int enc);
 
+// xyz4: n x 4 floats (16-byte aligned), packed copy of the cloud for the per-voxel gather
 void launch_cell_keys(const float* x, const float* y, const float* z, size_t n,
-                      const GridGeom& g, uint32_t* keys, uint32_t* vals, hipStream_t s);
+                      const GridGeom& g, uint32_t* keys, uint32_t* vals, float* xyz4, hipStream_t s);
 
 size_t sort_temp_bytes(size_t n);
 hipError_t sort_pairs(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
@@ -33,7 +34,7 @@ struct FinalizeParams {
   int cov_mode;  // 0 svn, 1 pcl (recalled)
 };
 // sums: 9 doubles per leaf slot (scratch)
-void launch_finalize_leaves(const float* x, const float* y, const float* z,
+void launch_finalize_leaves(const float* xyz4,
                             const uint32_t* keys_sorted, const uint32_t* vals_sorted,
                             int* d_nleaf /* [0]=slots, [1]=valid */, const int* leaf_start,
                             const int* leaf_cnt, int max_leaves, FinalizeParams fp, double* sums,

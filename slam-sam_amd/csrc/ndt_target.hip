@@ -99,10 +99,13 @@ __device__ __forceinline__ int cell_of(float px, float py, float pz, const GridG
 
 __global__ void __launch_bounds__(256) k_cell_keys(const float* __restrict__ x, const float* __restrict__ y,
                                                   const float* __restrict__ z, size_t n, GridGeom g,
-                                                  uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+                                                  uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                  float4* __restrict__ xyz4) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float a = x[i], b = y[i], c = z[i];
+  // packed copy for the per-voxel gather: one 16-byte line per point instead of three
+  xyz4[i] = make_float4(a, b, c, 0.0f);
   uint32_t key = (uint32_t)g.ncells;  // sentinel sorts behind every real cell
   if (finite3(a, b, c)) {
     int idx = cell_of(a, b, c, g);
@@ -246,8 +249,7 @@ constexpr int SUMS_BLOCKS_MAX = 2048;
 // ref: voxel_grid_covariance_impl.hpp:236-239 -- per-voxel sum(x) and sum(x x^T) in f64.
 // 8 lanes per leaf gather its points (stable sort => ascending input order) and a fixed
 // 3-step xor tree adds the 8 partial sums: deterministic.
-__global__ void __launch_bounds__(256) k_leaf_sums(const float* __restrict__ x, const float* __restrict__ y,
-                                                  const float* __restrict__ z, const uint32_t* __restrict__ vals,
+__global__ void __launch_bounds__(256) k_leaf_sums(const float4* __restrict__ xyz4, const uint32_t* __restrict__ vals,
                                                   const int* __restrict__ nleaf_p,
                                                   const int* __restrict__ leaf_start,
                                                   const int* __restrict__ leaf_cnt, double* __restrict__ sums) {
@@ -258,12 +260,25 @@ __global__ void __launch_bounds__(256) k_leaf_sums(const float* __restrict__ x, 
        slot += gridDim.x * per_block) {
     const int start = leaf_start[slot], cnt = leaf_cnt[slot];
     double s[3] = {0, 0, 0}, ss[6] = {0, 0, 0, 0, 0, 0};
-    for (int j = sub; j < cnt; j += LANES_PER_LEAF) {
-      const uint32_t pi = vals[start + j];
-      const double a = (double)x[pi], b = (double)y[pi], c = (double)z[pi];
-      s[0] += a; s[1] += b; s[2] += c;
-      ss[0] += a * a; ss[1] += a * b; ss[2] += a * c;
-      ss[3] += b * b; ss[4] += b * c; ss[5] += c * c;
+    // four gathers in flight per lane (index load -> point load is a dependent pair);
+    // the adds stay in point order, masked lanes add exact zeros
+    for (int j0 = sub; j0 < cnt; j0 += 4 * LANES_PER_LEAF) {
+      float4 p[4];
+      bool live[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = j0 + u * LANES_PER_LEAF;
+        live[u] = j < cnt;
+        p[u] = xyz4[vals[start + (live[u] ? j : 0)]];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double a = live[u] ? (double)p[u].x : 0.0, b = live[u] ? (double)p[u].y : 0.0,
+                     c = live[u] ? (double)p[u].z : 0.0;
+        s[0] += a; s[1] += b; s[2] += c;
+        ss[0] += a * a; ss[1] += a * b; ss[2] += a * c;
+        ss[3] += b * b; ss[4] += b * c; ss[5] += c * c;
+      }
     }
 #pragma unroll
     for (int off = 1; off < LANES_PER_LEAF; off <<= 1) {
@@ -434,10 +449,11 @@ void fold_bounds(const int* rows, int nrows, int out[8]) {
 }
 
 void launch_cell_keys(const float* x, const float* y, const float* z, size_t n, const GridGeom& g,
-                      uint32_t* keys, uint32_t* vals, hipStream_t s) {
+                      uint32_t* keys, uint32_t* vals, float* xyz4, hipStream_t s) {
   if (n == 0) return;
   size_t blocks = (n + 255) / 256;
-  hipLaunchKernelGGL(k_cell_keys, dim3((unsigned)blocks), dim3(256), 0, s, x, y, z, n, g, keys, vals);
+  hipLaunchKernelGGL(k_cell_keys, dim3((unsigned)blocks), dim3(256), 0, s, x, y, z, n, g, keys, vals,
+                     reinterpret_cast<float4*>(xyz4));
 }
 
 // rocPRIM's default switches to a merge sort below 1M items (10 merge passes, ~165 us for the
@@ -476,7 +492,7 @@ void launch_find_runs(const uint32_t* keys_sorted, size_t n, int ncells, int min
                      block_counts, block_offsets, leaf_start, leaf_cnt);
 }
 
-void launch_finalize_leaves(const float* x, const float* y, const float* z,
+void launch_finalize_leaves(const float* xyz4,
                             const uint32_t* keys_sorted, const uint32_t* vals_sorted,
                             int* d_nleaf, const int* leaf_start, const int* leaf_cnt,
                             int max_leaves, FinalizeParams fp, double* sums, VoxelRecord* rec,
@@ -484,7 +500,8 @@ void launch_finalize_leaves(const float* x, const float* y, const float* z,
   if (max_leaves <= 0) return;
   size_t blocks = ((size_t)max_leaves * LANES_PER_LEAF + 255) / 256;
   if (blocks > (size_t)SUMS_BLOCKS_MAX) blocks = SUMS_BLOCKS_MAX;
-  hipLaunchKernelGGL(k_leaf_sums, dim3((unsigned)blocks), dim3(256), 0, s, x, y, z, vals_sorted, d_nleaf,
+  hipLaunchKernelGGL(k_leaf_sums, dim3((unsigned)blocks), dim3(256), 0, s,
+                     reinterpret_cast<const float4*>(xyz4), vals_sorted, d_nleaf,
                      leaf_start, leaf_cnt, sums);
   hipLaunchKernelGGL(k_leaf_finalize, dim3((unsigned)((max_leaves + 255) / 256)), dim3(256), 0, s,
                      keys_sorted, d_nleaf, leaf_start, leaf_cnt, sums, fp, rec, stats, cell2leaf);
