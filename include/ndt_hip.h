@@ -222,6 +222,40 @@ int ndt_comm_destroy(ndt_handle* h);
  * caller after sharding, defaults to the local count */
 int ndt_set_global_source_size(ndt_handle* h, int64_t n_total);
 
+/* ---- SVN-NDT (svn_ndt::SvnNormalDistributionsTransform::align) ------------- */
+/* Stein Variational Newton over K pose particles (ref: extern/svn_ndt/include/svn_ndt.h:
+ * 100-182, svn_ndt_impl.hpp:675-964; driver: run/pipeline_lo_svn.cpp:301-319,387-388).
+ * Stage 1 (NDT derivatives of every particle) is one batched kernel launch; stages 2-3
+ * run on the host.  The engine's ndt_params select the svn defaults through
+ * hessian_mode = NDT_HESSIAN_GAUSS_NEWTON and add_ridge = 1 (svn_ndt.h:314,
+ * svn_ndt_impl.hpp:650-653).  Poses are 4x4 double, column-major; covariance 6x6 row-major
+ * in GTSAM tangent order [rot, trans] (svn_ndt.h:46). */
+typedef struct ndt_svn_params {
+  int particle_count;      /* setParticleCount (30) */
+  int max_iterations;      /* setMaxIterations (50) */
+  double kernel_bandwidth; /* setKernelBandwidth (1.0) */
+  double step_size;        /* setStepSize (1.0) */
+  double stop_threshold;   /* setEarlyStopThreshold (1e-4) */
+} ndt_svn_params;
+
+typedef struct ndt_svn_result {  /* svn_ndt::SvnNdtResult (svn_ndt.h:40-51) */
+  double final_pose[16];
+  double final_covariance[36];
+  int converged;
+  int iterations;
+  double last_mean_update;   /* |Log(mean_prev^-1 mean)| of the last iteration */
+  double ms_total, ms_stage1, ms_stage2, ms_stage3;
+} ndt_svn_result;
+
+void ndt_svn_default_params(ndt_svn_params* p);
+/* prior.retract(sigma * N(0,1)) for K particles (ref :708-716); the reference seeds from the
+ * wall clock, here the seed is explicit.  particles16: K x 16 doubles. */
+int ndt_svn_sample_particles(const double prior16[16], int K, uint64_t seed, double* particles16);
+/* particles16 (K x 16): initial particles in, final particles out.  The source / target
+ * clouds are those of the handle (ndt_set_target / ndt_set_source). */
+int ndt_svn_align(ndt_handle* h, const ndt_svn_params* p, const double prior16[16],
+                  double* particles16, ndt_svn_result* out);
+
 /* ---- instrumentation ------------------------------------------------------ */
 typedef struct ndt_timing {
   double ms_last_eval_kernel;   /* HIP-event time of the last derivative kernel */

@@ -1057,3 +1057,326 @@ extern "C" size_t oracle_two_plane_fixture(float* src, float* tgt, double gt16[1
   }
   return n;
 }
+
+// ---------------------------------------------------------------------------
+// SVN-NDT outer loop, ref: extern/svn_ndt/include/svn_ndt_impl.hpp:675-964
+// ---------------------------------------------------------------------------
+namespace {
+
+struct P3 {  // gtsam::Pose3 stand-in: row-major R, t
+  double R[9];
+  double t[3];
+};
+
+P3 p3_from16(const double T[16]) {
+  P3 p;
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) p.R[3 * i + j] = T[4 * j + i];
+    p.t[i] = T[12 + i];
+  }
+  return p;
+}
+void p3_to16(const P3& p, double T[16]) {
+  for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) T[4 * j + i] = p.R[3 * i + j];
+    T[12 + i] = p.t[i];
+  }
+}
+P3 p3_compose(const P3& a, const P3& b) {
+  P3 c;
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) {
+      double s = 0;
+      for (int k = 0; k < 3; ++k) s += a.R[3 * i + k] * b.R[3 * k + j];
+      c.R[3 * i + j] = s;
+    }
+    c.t[i] = a.R[3 * i] * b.t[0] + a.R[3 * i + 1] * b.t[1] + a.R[3 * i + 2] * b.t[2] + a.t[i];
+  }
+  return c;
+}
+P3 p3_between(const P3& a, const P3& b) {  // a^-1 * b
+  P3 inv;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) inv.R[3 * i + j] = a.R[3 * j + i];
+  for (int i = 0; i < 3; ++i)
+    inv.t[i] = -(inv.R[3 * i] * a.t[0] + inv.R[3 * i + 1] * a.t[1] + inv.R[3 * i + 2] * a.t[2]);
+  return p3_compose(inv, b);
+}
+// gtsam::Pose3::Expmap, xi = [omega, v]
+P3 p3_expmap(const double xi[6]) {
+  P3 p;
+  so3_exp(xi, p.R);
+  const double* w = xi;
+  const double* v = xi + 3;
+  double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  if (th2 > 1e-20) {
+    double wv = w[0] * v[0] + w[1] * v[1] + w[2] * v[2];
+    double c[3] = {w[1] * v[2] - w[2] * v[1], w[2] * v[0] - w[0] * v[2], w[0] * v[1] - w[1] * v[0]};
+    for (int i = 0; i < 3; ++i) {
+      double Rc = p.R[3 * i] * c[0] + p.R[3 * i + 1] * c[1] + p.R[3 * i + 2] * c[2];
+      p.t[i] = (c[i] - Rc + w[i] * wv) / th2;
+    }
+  } else {
+    for (int i = 0; i < 3; ++i) p.t[i] = v[i];
+  }
+  return p;
+}
+// gtsam::SO3 / Pose3 Logmap
+void p3_logmap(const P3& p, double xi[6]) {
+  const double* R = p.R;
+  double tr = R[0] + R[4] + R[8];
+  double w[3];
+  if (tr + 1.0 < 1e-10) {  // rotation by ~pi
+    const double PI = 3.14159265358979323846;
+    if (std::fabs(R[8] + 1.0) > 1e-5) {
+      double k = PI / std::sqrt(2.0 + 2.0 * R[8]);
+      w[0] = k * R[2]; w[1] = k * R[5]; w[2] = k * (1.0 + R[8]);
+    } else if (std::fabs(R[4] + 1.0) > 1e-5) {
+      double k = PI / std::sqrt(2.0 + 2.0 * R[4]);
+      w[0] = k * R[1]; w[1] = k * (1.0 + R[4]); w[2] = k * R[7];
+    } else {
+      double k = PI / std::sqrt(2.0 + 2.0 * R[0]);
+      w[0] = k * (1.0 + R[0]); w[1] = k * R[3]; w[2] = k * R[6];
+    }
+  } else {
+    double mag;
+    double tr3 = tr - 3.0;
+    if (tr3 < -1e-6) {
+      double th = std::acos(std::fmin(1.0, std::fmax(-1.0, (tr - 1.0) / 2.0)));
+      mag = th / (2.0 * std::sin(th));
+    } else {
+      mag = 0.5 - tr3 / 12.0 + tr3 * tr3 / 60.0;
+    }
+    w[0] = mag * (R[7] - R[5]); w[1] = mag * (R[2] - R[6]); w[2] = mag * (R[3] - R[1]);
+  }
+  double th = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  xi[0] = w[0]; xi[1] = w[1]; xi[2] = w[2];
+  if (th < 1e-10) {
+    xi[3] = p.t[0]; xi[4] = p.t[1]; xi[5] = p.t[2];
+    return;
+  }
+  double W[3] = {w[0] / th, w[1] / th, w[2] / th};
+  double Tan = std::tan(0.5 * th);
+  auto cross = [](const double a[3], const double b[3], double o[3]) {
+    o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+  };
+  double WT[3], WWT[3];
+  cross(W, p.t, WT);
+  cross(W, WT, WWT);
+  for (int i = 0; i < 3; ++i) xi[3 + i] = p.t[i] - (0.5 * th) * WT[i] + (1.0 - th / (2.0 * Tan)) * WWT[i];
+}
+
+// Solve A x = b (6x6) by LU with partial pivoting; false if singular / non-finite.
+// (the reference uses Eigen::LDLT, ref :834-839)
+bool solve6_lu(const double Ain[36], const double bin[6], double x[6]) {
+  double A[36], b[6];
+  std::memcpy(A, Ain, sizeof(A));
+  std::memcpy(b, bin, sizeof(b));
+  for (int c = 0; c < 6; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < 6; ++r)
+      if (std::fabs(A[6 * r + c]) > std::fabs(A[6 * piv + c])) piv = r;
+    if (!(std::fabs(A[6 * piv + c]) > 0) || !std::isfinite(A[6 * piv + c])) return false;
+    if (piv != c) {
+      for (int k = 0; k < 6; ++k) std::swap(A[6 * c + k], A[6 * piv + k]);
+      std::swap(b[c], b[piv]);
+    }
+    for (int r = c + 1; r < 6; ++r) {
+      double f = A[6 * r + c] / A[6 * c + c];
+      for (int k = c; k < 6; ++k) A[6 * r + k] -= f * A[6 * c + k];
+      b[r] -= f * b[c];
+    }
+  }
+  for (int r = 5; r >= 0; --r) {
+    double s = b[r];
+    for (int k = r + 1; k < 6; ++k) s -= A[6 * r + k] * x[k];
+    x[r] = s / A[6 * r + r];
+  }
+  for (int i = 0; i < 6; ++i)
+    if (!std::isfinite(x[i])) return false;
+  return true;
+}
+
+// symmetric 6x6 eigen-decomposition (Jacobi): A = Q diag(ev) Q^T, Q row-major
+void sym_eig6(const double Ain[36], double ev[6], double Q[36]) {
+  double A[36];
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) A[6 * i + j] = 0.5 * (Ain[6 * i + j] + Ain[6 * j + i]);
+  for (int i = 0; i < 36; ++i) Q[i] = (i % 7 == 0) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 100; ++sweep) {
+    double off = 0, dg = 0;
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 6; ++j) (i == j ? dg : off) += A[6 * i + j] * A[6 * i + j];
+    if (off <= 1e-30 * dg || off == 0.0) break;
+    for (int p = 0; p < 5; ++p)
+      for (int q = p + 1; q < 6; ++q) {
+        if (A[6 * p + q] == 0.0) continue;
+        double th = (A[6 * q + q] - A[6 * p + p]) / (2.0 * A[6 * p + q]);
+        double t = (th >= 0 ? 1.0 : -1.0) / (std::fabs(th) + std::sqrt(th * th + 1.0));
+        double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 6; ++k) {
+          double u = A[6 * k + p], v = A[6 * k + q];
+          A[6 * k + p] = c * u - s * v; A[6 * k + q] = s * u + c * v;
+        }
+        for (int k = 0; k < 6; ++k) {
+          double u = A[6 * p + k], v = A[6 * q + k];
+          A[6 * p + k] = c * u - s * v; A[6 * q + k] = s * u + c * v;
+        }
+        for (int k = 0; k < 6; ++k) {
+          double u = Q[6 * k + p], v = Q[6 * k + q];
+          Q[6 * k + p] = c * u - s * v; Q[6 * k + q] = s * u + c * v;
+        }
+      }
+  }
+  for (int i = 0; i < 6; ++i) ev[i] = A[7 * i];
+}
+
+}  // namespace
+
+extern "C" void oracle_se3_expmap(const double xi[6], double T16[16]) { p3_to16(p3_expmap(xi), T16); }
+extern "C" void oracle_se3_logmap(const double T16[16], double xi[6]) { p3_logmap(p3_from16(T16), xi); }
+
+extern "C" void oracle_svn_sample_particles(const double prior16[16], int K, uint64_t seed,
+                                            double* particles) {
+  const double sig[6] = {0.01, 0.01, 0.02, 0.05, 0.05, 0.05};  // ref :709
+  std::mt19937_64 gen(seed);
+  std::normal_distribution<double> nd(0.0, 1.0);
+  const P3 prior = p3_from16(prior16);
+  for (int k = 0; k < K; ++k) {
+    double xi[6];
+    for (int i = 0; i < 6; ++i) xi[i] = sig[i] * nd(gen);
+    p3_to16(p3_compose(prior, p3_expmap(xi)), particles + 16 * (size_t)k);  // prior.retract(sample), ref :715
+  }
+}
+
+extern "C" void oracle_svn_align(const oracle_grid* g, const float* src, size_t n, size_t stride,
+                                 const double prior16[16], double* particles16,
+                                 const oracle_params* prm, const oracle_svn_params* svn,
+                                 oracle_svn_result* out) {
+  std::memset(out, 0, sizeof(*out));
+  const int K = svn->particle_count;
+  const P3 prior = p3_from16(prior16);
+  p3_to16(prior, out->final_pose);
+  for (int i = 0; i < 6; ++i) out->final_covariance[7 * i] = 1.0;
+  if (K <= 0 || n == 0 || g->leaves.empty()) return;  // ref :682-702: prior, identity covariance
+
+  std::vector<P3> part(K);
+  for (int k = 0; k < K; ++k) part[k] = p3_from16(particles16 + 16 * (size_t)k);
+  std::vector<oracle_derivs> D(K);
+  std::vector<double> upd(6 * (size_t)K);
+  P3 mean_cur = prior, mean_last = prior;
+
+  for (int iter = 0; iter < svn->max_iterations; ++iter) {
+    mean_last = mean_cur;
+    // Stage 1 (ref :758-781)
+    for (int k = 0; k < K; ++k) {
+      double T64[16];
+      p3_to16(part[k], T64);
+      float T[16];
+      for (int i = 0; i < 16; ++i) T[i] = static_cast<float>(T64[i]);
+      const double* R = part[k].R;
+      // gtsam Rot3::rpy(): R = Rz(yaw) Ry(pitch) Rx(roll); fed as is into the Rx*Ry*Rz tables (:765-767)
+      double p6[6] = {part[k].t[0], part[k].t[1], part[k].t[2], std::atan2(R[7], R[8]),
+                      std::atan2(-R[6], std::sqrt(R[7] * R[7] + R[8] * R[8])), std::atan2(R[3], R[0])};
+      oracle_derivatives(g, src, n, stride, T, p6, prm, 1, &D[k]);
+    }
+    // Stage 2 (ref :789-839), GTSAM order [rot, trans]
+    for (int k = 0; k < K; ++k) {
+      double phi[6] = {0, 0, 0, 0, 0, 0}, Ht[36];
+      std::memset(Ht, 0, sizeof(Ht));
+      for (int l = 0; l < K; ++l) {
+        double d[6];
+        p3_logmap(p3_between(part[l], part[k]), d);
+        double sq = 0;
+        for (int i = 0; i < 6; ++i) sq += d[i] * d[i];
+        double kv, kg[6];
+        if (svn->kernel_bandwidth <= 1e-12) {  // ref :218-220, :233-235
+          kv = (sq < 1e-18) ? 1.0 : 0.0;
+          for (int i = 0; i < 6; ++i) kg[i] = 0.0;
+        } else {
+          kv = std::exp(-sq / svn->kernel_bandwidth);
+          for (int i = 0; i < 6; ++i) kg[i] = kv * (-2.0 / svn->kernel_bandwidth) * d[i];
+        }
+        bool fin = std::isfinite(kv);
+        for (int i = 0; i < 6; ++i) fin = fin && std::isfinite(kg[i]);
+        if (!fin) continue;
+        double gl[6], Hl[36];
+        for (int i = 0; i < 3; ++i) { gl[i] = D[l].gradient[3 + i]; gl[3 + i] = D[l].gradient[i]; }
+        for (int i = 0; i < 6; ++i)
+          for (int j = 0; j < 6; ++j) Hl[6 * i + j] = D[l].hessian[6 * ((i + 3) % 6) + ((j + 3) % 6)];
+        bool gfin = true, hfin = true;
+        for (int i = 0; i < 6; ++i) gfin = gfin && std::isfinite(gl[i]);
+        for (int i = 0; i < 36; ++i) hfin = hfin && std::isfinite(Hl[i]);
+        for (int i = 0; i < 6; ++i) phi[i] += (gfin ? kv * gl[i] : 0.0) + kg[i];
+        for (int i = 0; i < 6; ++i)
+          for (int j = 0; j < 6; ++j) Ht[6 * i + j] += (hfin ? kv * kv * Hl[6 * i + j] : 0.0) + kg[i] * kg[j];
+      }
+      for (int i = 0; i < 6; ++i) phi[i] /= static_cast<double>(K);
+      for (int i = 0; i < 36; ++i) Ht[i] /= static_cast<double>(K);
+      for (int i = 0; i < 6; ++i) Ht[7 * i] += 1e-6;
+      double rhs[6], u[6];
+      for (int i = 0; i < 6; ++i) rhs[i] = -phi[i];
+      bool ok = solve6_lu(Ht, rhs, u);
+      for (int i = 0; i < 6; ++i) upd[6 * (size_t)k + i] = ok ? u[i] : 0.0;
+    }
+    // Stage 3 (ref :848-855)
+    for (int k = 0; k < K; ++k) {
+      double sc[6];
+      bool fin = true;
+      for (int i = 0; i < 6; ++i) { sc[i] = svn->step_size * upd[6 * (size_t)k + i]; fin = fin && std::isfinite(sc[i]); }
+      if (!fin) continue;
+      part[k] = p3_compose(part[k], p3_expmap(sc));
+    }
+    // mean in the prior's tangent space (ref :865-870), convergence on its update (:877,:893)
+    double mxi[6] = {0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < K; ++k) {
+      double d[6];
+      p3_logmap(p3_between(prior, part[k]), d);
+      for (int i = 0; i < 6; ++i) mxi[i] += d[i];
+    }
+    for (int i = 0; i < 6; ++i) mxi[i] /= static_cast<double>(K);
+    mean_cur = p3_compose(prior, p3_expmap(mxi));
+    out->iterations = iter + 1;
+    double d[6], nrm = 0;
+    p3_logmap(p3_between(mean_last, mean_cur), d);
+    for (int i = 0; i < 6; ++i) nrm += d[i] * d[i];
+    nrm = std::sqrt(nrm);
+    if (out->n_logged < 128) out->log_mean_update[out->n_logged++] = nrm;
+    if (nrm < svn->stop_threshold) { out->converged = 1; break; }
+  }
+  p3_to16(mean_cur, out->final_pose);
+  // sample covariance in the tangent space at the mean (ref :908-930), eigenvalue floor 1e-9 (:932-949)
+  double C[36];
+  std::memset(C, 0, sizeof(C));
+  if (K > 1) {
+    std::vector<double> tv(6 * (size_t)K);
+    double m[6] = {0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < K; ++k) {
+      p3_logmap(p3_between(mean_cur, part[k]), &tv[6 * (size_t)k]);
+      for (int i = 0; i < 6; ++i) m[i] += tv[6 * (size_t)k + i];
+    }
+    for (int i = 0; i < 6; ++i) m[i] /= static_cast<double>(K);
+    for (int k = 0; k < K; ++k)
+      for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) C[6 * i + j] += (tv[6 * (size_t)k + i] - m[i]) * (tv[6 * (size_t)k + j] - m[j]);
+    for (int i = 0; i < 36; ++i) C[i] /= static_cast<double>(K - 1);
+  } else {
+    const double sig[6] = {0.01, 0.01, 0.02, 0.05, 0.05, 0.05};
+    for (int i = 0; i < 6; ++i) C[7 * i] = 1e-6 * sig[i] * sig[i];
+  }
+  double ev[6], Q[36];
+  sym_eig6(C, ev, Q);
+  bool clamp = false;
+  for (int i = 0; i < 6; ++i)
+    if (ev[i] < 1e-9) { ev[i] = 1e-9; clamp = true; }
+  if (clamp)
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 6; ++j) {
+        double s = 0;
+        for (int k = 0; k < 6; ++k) s += Q[6 * i + k] * ev[k] * Q[6 * j + k];
+        C[6 * i + j] = s;
+      }
+  std::memcpy(out->final_covariance, C, sizeof(C));
+  for (int k = 0; k < K; ++k) p3_to16(part[k], particles16 + 16 * (size_t)k);
+}

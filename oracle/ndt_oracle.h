@@ -147,6 +147,42 @@ void oracle_align(const oracle_grid* g, const float* src_xyz, size_t n,
 size_t oracle_two_plane_fixture(float* src_xyz, float* tgt_xyz, double gt16[16],
                                 double guess16[16]);
 
+/* ---- SVN-NDT outer loop (ref: extern/svn_ndt/include/svn_ndt_impl.hpp:675-964) ----------
+ * Stein Variational Newton over K pose particles; Stage 1 = oracle_derivatives per particle
+ * (Gauss-Newton Hessian + 1e-6 ridge by default, svn_ndt.h:314), Stage 2 = RBF-kernel mix and
+ * a 6x6 solve per particle in GTSAM tangent order [rot, trans], Stage 3 = retraction.  GTSAM's
+ * Pose3 Expmap / Logmap / between / rpy are restated from their published formulas; retract is
+ * taken as the full exponential map (GTSAM_POSE3_EXPMAP, the default since GTSAM 4.1).
+ * The reference seeds its particle sampler from the wall clock (:712); here the initial
+ * particles are an input so runs are reproducible. */
+typedef struct oracle_svn_params {
+  int particle_count;      /* K_ (svn_ndt.h default 30) */
+  int max_iterations;      /* max_iter_ (50) */
+  double kernel_bandwidth; /* kernel_h_ (1.0) */
+  double step_size;        /* step_size_ (1.0) */
+  double stop_threshold;   /* stop_thresh_ (1e-4) */
+} oracle_svn_params;
+
+typedef struct oracle_svn_result {
+  double final_pose[16];        /* column-major 4x4 */
+  double final_covariance[36];  /* row-major, GTSAM order [rot, trans] */
+  int converged;
+  int iterations;
+  int n_logged;                 /* iterations logged below (<= 128) */
+  double log_mean_update[128];  /* |Log(mean_prev^-1 mean_cur)| per iteration */
+} oracle_svn_result;
+
+/* particles: K x 16 doubles (column-major poses), updated in place to the final particles */
+void oracle_svn_align(const oracle_grid* g, const float* src_xyz, size_t n, size_t stride_bytes,
+                      const double prior16[16], double* particles, const oracle_params* prm,
+                      const oracle_svn_params* svn, oracle_svn_result* out);
+/* prior.retract(sigma .* N(0,1)) for K particles with sigmas (0.01,0.01,0.02,0.05,0.05,0.05)
+ * in GTSAM order (ref :708-716), std::mt19937_64(seed) + std::normal_distribution */
+void oracle_svn_sample_particles(const double prior16[16], int K, uint64_t seed, double* particles);
+/* SE(3) helpers exported for tests: xi = [omega, v] (GTSAM order) */
+void oracle_se3_expmap(const double xi[6], double T16[16]);
+void oracle_se3_logmap(const double T16[16], double xi[6]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -246,3 +246,73 @@ def two_plane_fixture():
     got = lib().oracle_two_plane_fixture(_fp(src), _fp(tgt), _dp(gt), _dp(guess))
     assert got == n, got
     return src, tgt, gt.reshape(4, 4).T.copy(), guess.reshape(4, 4).T.copy()
+
+
+# ---- SVN-NDT outer loop (ref: extern/svn_ndt/include/svn_ndt_impl.hpp:675-964) -------------
+class SvnParams(C.Structure):
+    _fields_ = [("particle_count", C.c_int), ("max_iterations", C.c_int),
+                ("kernel_bandwidth", C.c_double), ("step_size", C.c_double),
+                ("stop_threshold", C.c_double)]
+
+
+class SvnResult(C.Structure):
+    _fields_ = [("final_pose", C.c_double * 16), ("final_covariance", C.c_double * 36),
+                ("converged", C.c_int), ("iterations", C.c_int), ("n_logged", C.c_int),
+                ("log_mean_update", C.c_double * 128)]
+
+
+def _svn_protos():
+    L = lib()
+    if not getattr(L, "_svn_ready", False):
+        dp = C.POINTER(C.c_double)
+        L.oracle_svn_align.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, dp, dp,
+                                       C.POINTER(Params), C.POINTER(SvnParams), C.POINTER(SvnResult)]
+        L.oracle_svn_sample_particles.argtypes = [dp, C.c_int, C.c_uint64, dp]
+        L.oracle_se3_expmap.argtypes = [dp, dp]
+        L.oracle_se3_logmap.argtypes = [dp, dp]
+        L._svn_ready = True
+    return L
+
+
+def _pose16(T):
+    return np.ascontiguousarray(np.asarray(T, dtype=np.float64).T).ravel()
+
+
+def svn_sample_particles(prior, K, seed):
+    """K x 4 x 4 poses: prior.retract(sigma * N(0,1)), sigmas as svn_ndt_impl.hpp:709."""
+    L = _svn_protos()
+    out = np.zeros(16 * K)
+    L.oracle_svn_sample_particles(_dp(_pose16(prior)), K, seed, _dp(out))
+    return out.reshape(K, 4, 4).transpose(0, 2, 1).copy()
+
+
+def svn_align(grid, src, prior, particles, params, K=None, max_iterations=50, kernel_bandwidth=1.0,
+              step_size=1.0, stop_threshold=1e-4):
+    L = _svn_protos()
+    src = _xyz(src)
+    particles = np.asarray(particles, dtype=np.float64)
+    K = len(particles) if K is None else K
+    part = np.ascontiguousarray(particles.transpose(0, 2, 1)).ravel().copy()
+    sp = SvnParams(K, max_iterations, kernel_bandwidth, step_size, stop_threshold)
+    r = SvnResult()
+    L.oracle_svn_align(grid.h, src.ctypes.data, len(src), 12, _dp(_pose16(prior)), _dp(part),
+                       C.byref(params), C.byref(sp), C.byref(r))
+    return dict(pose=np.array(r.final_pose[:]).reshape(4, 4).T.copy(),
+                covariance=np.array(r.final_covariance[:]).reshape(6, 6), converged=bool(r.converged),
+                iterations=r.iterations, log_mean_update=np.array(r.log_mean_update[:r.n_logged]),
+                particles=part.reshape(K, 4, 4).transpose(0, 2, 1).copy())
+
+
+def se3_expmap(xi):
+    L = _svn_protos()
+    xi = np.ascontiguousarray(xi, dtype=np.float64)
+    T = np.zeros(16)
+    L.oracle_se3_expmap(_dp(xi), _dp(T))
+    return T.reshape(4, 4).T.copy()
+
+
+def se3_logmap(T):
+    L = _svn_protos()
+    xi = np.zeros(6)
+    L.oracle_se3_logmap(_dp(_pose16(T)), _dp(xi))
+    return xi

@@ -84,6 +84,19 @@ class Timing(C.Structure):
     ]
 
 
+class SvnParams(C.Structure):
+    _fields_ = [("particle_count", C.c_int), ("max_iterations", C.c_int),
+                ("kernel_bandwidth", C.c_double), ("step_size", C.c_double),
+                ("stop_threshold", C.c_double)]
+
+
+class SvnResult(C.Structure):
+    _fields_ = [("final_pose", C.c_double * 16), ("final_covariance", C.c_double * 36),
+                ("converged", C.c_int), ("iterations", C.c_int), ("last_mean_update", C.c_double),
+                ("ms_total", C.c_double), ("ms_stage1", C.c_double), ("ms_stage2", C.c_double),
+                ("ms_stage3", C.c_double)]
+
+
 EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float), C.c_int,
                       C.POINTER(C.c_double))
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
@@ -98,6 +111,7 @@ ABI_SYMBOLS = [
     "ndt_export_leaves", "ndt_newton_align", "ndt_shard_range", "ndt_comm_unique_id",
     "ndt_comm_init_rccl", "ndt_comm_init_shm", "ndt_comm_init_hook", "ndt_comm_destroy",
     "ndt_set_global_source_size", "ndt_enable_kernel_timing", "ndt_get_timing",
+    "ndt_svn_default_params", "ndt_svn_sample_particles", "ndt_svn_align",
 ]
 
 _lib = None
@@ -150,6 +164,10 @@ def lib():
         L.ndt_set_global_source_size.argtypes = [vp, C.c_int64]
         L.ndt_enable_kernel_timing.argtypes = [vp, C.c_int]
         L.ndt_get_timing.argtypes = [vp, C.POINTER(Timing)]
+        L.ndt_svn_default_params.restype = None
+        L.ndt_svn_default_params.argtypes = [C.POINTER(SvnParams)]
+        L.ndt_svn_sample_particles.argtypes = [dp, C.c_int, C.c_uint64, dp]
+        L.ndt_svn_align.argtypes = [vp, C.POINTER(SvnParams), dp, dp, C.POINTER(SvnResult)]
         _lib = L
     return _lib
 
@@ -452,3 +470,58 @@ def pack_eval(score, gradient, hessian, nvtl_sum=0.0, n_with=0, n_pairs=0):
             k += 1
     w[28], w[29], w[30] = nvtl_sum, n_with, n_pairs
     return w
+
+
+def _pose16d(T):
+    return np.ascontiguousarray(np.asarray(T, dtype=np.float64).T).ravel()
+
+
+def svn_sample_particles(prior, K, seed=0):
+    """K x 4 x 4 initial particles around `prior` (ref: svn_ndt_impl.hpp:708-716, seed explicit)."""
+    out = np.zeros(16 * K)
+    rc = lib().ndt_svn_sample_particles(_dp(_pose16d(prior)), K, seed, _dp(out))
+    if rc != 0:
+        raise NdtError(rc, "ndt_svn_sample_particles")
+    return out.reshape(K, 4, 4).transpose(0, 2, 1).copy()
+
+
+class SvnNormalDistributionsTransform(NormalDistributionsTransform):
+    """svn_ndt::SvnNormalDistributionsTransform-shaped engine (ref: extern/svn_ndt/include/
+    svn_ndt.h:100-182; driver run/pipeline_lo_svn.cpp:301-319,387-388): K pose particles,
+    Stage 1 as one batched kernel launch."""
+
+    def __init__(self, device_id=-1, **params):
+        base = dict(hessian_mode=HESSIAN_GAUSS_NEWTON, add_ridge=1)  # svn_ndt.h:314, impl :650-653
+        base.update(params)
+        super().__init__(device_id=device_id, **base)
+        self._sp = SvnParams()
+        lib().ndt_svn_default_params(C.byref(self._sp))
+
+    def setParticleCount(self, k): self._sp.particle_count = int(k)
+    def setMaxIterations(self, n): self._sp.max_iterations = int(n)
+    def setKernelBandwidth(self, h): self._sp.kernel_bandwidth = float(h)
+    def setStepSize(self, s): self._sp.step_size = float(s)
+    def setEarlyStopThreshold(self, t): self._sp.stop_threshold = float(t)
+    def setUseGaussNewtonHessian(self, on):
+        self._p.hessian_mode = HESSIAN_GAUSS_NEWTON if on else HESSIAN_FULL
+        self._push()
+
+    def align(self, source_cloud, prior_pose, particles=None, seed=0):
+        """SvnNdtResult as a dict: final_pose, final_covariance ([rot, trans] order), converged,
+        iterations (+ the final particles and stage timings)."""
+        self.setInputSource(source_cloud)
+        K = self._sp.particle_count
+        if particles is None:
+            particles = svn_sample_particles(prior_pose, K, seed)
+        part = np.ascontiguousarray(np.asarray(particles, dtype=np.float64).transpose(0, 2, 1)).ravel().copy()
+        if len(part) != 16 * K:
+            raise ValueError("need %d particles" % K)
+        r = SvnResult()
+        self._check(lib().ndt_svn_align(self._h, C.byref(self._sp), _dp(_pose16d(prior_pose)), _dp(part),
+                                        C.byref(r)))
+        return dict(final_pose=np.array(r.final_pose[:]).reshape(4, 4).T.copy(),
+                    final_covariance=np.array(r.final_covariance[:]).reshape(6, 6),
+                    converged=bool(r.converged), iterations=r.iterations,
+                    last_mean_update=r.last_mean_update, ms_total=r.ms_total, ms_stage1=r.ms_stage1,
+                    ms_stage2=r.ms_stage2, ms_stage3=r.ms_stage3,
+                    particles=part.reshape(K, 4, 4).transpose(0, 2, 1).copy())
