@@ -169,6 +169,19 @@ int ndt_set_source(ndt_handle* h, const float* xyz, size_t n, size_t stride_byte
 int ndt_set_source_soa(ndt_handle* h, const float* x, const float* y, const float* z, size_t n);
 int ndt_set_source_device(ndt_handle* h, const float* dx, const float* dy, const float* dz, size_t n);
 
+/* Device-resident keyframe archive + sliding-window target assembly.  The drivers keep every
+ * keyframe's body-frame scan (pointsArchive, ref: run/pipeline.cpp:784) and rebuild the NDT
+ * target per keyframe as the sum of <= 5 archived scans, each moved by its current pose
+ * (ref: run/pipeline_ligo_tc.cpp:519-529; one scan in run/pipeline.cpp:554-557).  Here the
+ * scans stay in HBM; only ids and 4x4 double poses cross the boundary per keyframe. */
+int ndt_keyframe_put(ndt_handle* h, int64_t id, const float* xyz, size_t n, size_t stride_bytes);
+int ndt_keyframe_erase(ndt_handle* h, int64_t id);
+int64_t ndt_keyframe_count(const ndt_handle* h);
+/* target = concat_k transform(archive[ids[k]], poses16[k]) (f64 transform, rounded to f32 once,
+ * as pcl::transformPointCloud with a double matrix), then the voxel-grid build */
+int ndt_set_target_from_keyframes(ndt_handle* h, const int64_t* ids, const double* poses16,
+                                  int n_keyframes);
+
 /* setRegularizationPose (ref: run/pipeline_ligo_tc.cpp:531) */
 int ndt_set_regularization_pose(ndt_handle* h, const float pose_colmajor[16]);
 int ndt_clear_regularization_pose(ndt_handle* h);

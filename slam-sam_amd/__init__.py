@@ -112,6 +112,7 @@ ABI_SYMBOLS = [
     "ndt_comm_init_rccl", "ndt_comm_init_shm", "ndt_comm_init_hook", "ndt_comm_destroy",
     "ndt_set_global_source_size", "ndt_enable_kernel_timing", "ndt_get_timing",
     "ndt_svn_default_params", "ndt_svn_sample_particles", "ndt_svn_align",
+    "ndt_keyframe_put", "ndt_keyframe_erase", "ndt_keyframe_count", "ndt_set_target_from_keyframes",
 ]
 
 _lib = None
@@ -164,6 +165,11 @@ def lib():
         L.ndt_set_global_source_size.argtypes = [vp, C.c_int64]
         L.ndt_enable_kernel_timing.argtypes = [vp, C.c_int]
         L.ndt_get_timing.argtypes = [vp, C.POINTER(Timing)]
+        L.ndt_keyframe_put.argtypes = [vp, C.c_int64, vp, C.c_size_t, C.c_size_t]
+        L.ndt_keyframe_erase.argtypes = [vp, C.c_int64]
+        L.ndt_keyframe_count.restype = C.c_int64
+        L.ndt_keyframe_count.argtypes = [vp]
+        L.ndt_set_target_from_keyframes.argtypes = [vp, C.POINTER(C.c_int64), dp, C.c_int]
         L.ndt_svn_default_params.restype = None
         L.ndt_svn_default_params.argtypes = [C.POINTER(SvnParams)]
         L.ndt_svn_sample_particles.argtypes = [dp, C.c_int, C.c_uint64, dp]
@@ -319,6 +325,23 @@ class NormalDistributionsTransform:
     def setInputSourceDevice(self, dx, dy, dz, n):
         self._check(lib().ndt_set_source_device(self._h, dx, dy, dz, n))
         self._n_src = int(n)
+
+    # --- device-resident keyframe archive (ref: run/pipeline.cpp:784, run/pipeline_ligo_tc.cpp:519-529) ---
+    def putKeyframe(self, kf_id, cloud):
+        a = self._xyz(cloud)
+        self._check(lib().ndt_keyframe_put(self._h, int(kf_id), a.ctypes.data, len(a), a.strides[0]))
+
+    def eraseKeyframe(self, kf_id):
+        self._check(lib().ndt_keyframe_erase(self._h, int(kf_id)))
+
+    def keyframeCount(self):
+        return int(lib().ndt_keyframe_count(self._h))
+
+    def setInputTargetFromKeyframes(self, ids, poses):
+        """target = sum of archived scans, each moved by its 4x4 double pose, built on the device."""
+        ids_a = (C.c_int64 * len(ids))(*[int(i) for i in ids])
+        p = np.ascontiguousarray(np.stack([np.asarray(T, dtype=np.float64).T for T in poses])).ravel()
+        self._check(lib().ndt_set_target_from_keyframes(self._h, ids_a, _dp(p), len(ids)))
 
     def setGlobalSourceSize(self, n):
         self._check(lib().ndt_set_global_source_size(self._h, int(n)))

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/ndt_hip.h"
@@ -106,6 +107,13 @@ struct ndt_handle {
   size_t counters_zeroed = 0;
   DevBuf<PoseConsts> dposes;
   PinBuf<PoseConsts> hposes;
+
+  // device-resident keyframe archive (pointsArchive of the drivers, ref: run/pipeline.cpp:784)
+  struct Keyframe {
+    DevBuf<float> x, y, z;
+    size_t n = 0;
+  };
+  std::unordered_map<int64_t, Keyframe> keyframes;
 
   bool have_reg = false;
   float reg_pose[16];
@@ -452,6 +460,8 @@ int ndt_destroy(ndt_handle* h) {
   h->sort_tmp.release(); h->nleaf.release(); h->leaf_start.release(); h->leaf_cnt.release();
   h->cell2leaf.release(); h->rec.release(); h->stats.release();
   h->run_counts.release(); h->run_offsets.release(); h->leaf_sums.release(); h->xyz4.release();
+  for (auto& kv : h->keyframes) { kv.second.x.release(); kv.second.y.release(); kv.second.z.release(); }
+  h->keyframes.clear();
   h->sx.release(); h->sy.release(); h->sz.release();
   h->stage.release(); h->result.release(); h->small.release(); h->partials.release();
   h->dres.release(); h->dposes.release(); h->hposes.release(); h->counters.release(); h->flag.release();
@@ -555,6 +565,53 @@ int ndt_set_source_device(ndt_handle* h, const float* dx, const float* dy, const
   }
   h->n_src = n;
   return NDT_OK;
+}
+
+int ndt_keyframe_put(ndt_handle* h, int64_t id, const float* xyz, size_t n, size_t stride_bytes) {
+  if (!h || (!xyz && n) || stride_bytes < 12 || stride_bytes % 4) return NDT_ERR_INVALID_ARG;
+  int rc = bind_device(h);
+  if (rc) return rc;
+  ndt_handle::Keyframe& kf = h->keyframes[id];
+  rc = upload_soa(h, xyz, nullptr, nullptr, nullptr, n, stride_bytes, kf.x, kf.y, kf.z);
+  if (rc) return rc;
+  kf.n = n;
+  return NDT_OK;
+}
+
+int ndt_keyframe_erase(ndt_handle* h, int64_t id) {
+  if (!h) return NDT_ERR_INVALID_ARG;
+  auto it = h->keyframes.find(id);
+  if (it == h->keyframes.end()) return NDT_ERR_INVALID_ARG;
+  (void)hipSetDevice(h->device);
+  it->second.x.release(); it->second.y.release(); it->second.z.release();
+  h->keyframes.erase(it);
+  return NDT_OK;
+}
+
+int64_t ndt_keyframe_count(const ndt_handle* h) { return h ? (int64_t)h->keyframes.size() : NDT_ERR_INVALID_ARG; }
+
+int ndt_set_target_from_keyframes(ndt_handle* h, const int64_t* ids, const double* poses16, int n_keyframes) {
+  if (!h || !ids || !poses16 || n_keyframes <= 0) return NDT_ERR_INVALID_ARG;
+  int rc = bind_device(h);
+  if (rc) return rc;
+  size_t total = 0;
+  for (int k = 0; k < n_keyframes; ++k) {
+    auto it = h->keyframes.find(ids[k]);
+    if (it == h->keyframes.end()) return fail(h, NDT_ERR_INVALID_ARG, "unknown keyframe id");
+    total += it->second.n;
+  }
+  HIP_TRY(h, h->tx.ensure(total));
+  HIP_TRY(h, h->ty.ensure(total));
+  HIP_TRY(h, h->tz.ensure(total));
+  size_t off = 0;
+  for (int k = 0; k < n_keyframes; ++k) {  // appended in the caller's order, like `target += cloud`
+    const ndt_handle::Keyframe& kf = h->keyframes[ids[k]];
+    launch_transform_append(kf.x.p, kf.y.p, kf.z.p, kf.n, poses16 + 16 * (size_t)k, h->tx.p + off, h->ty.p + off,
+                            h->tz.p + off, h->stream);
+    off += kf.n;
+  }
+  HIP_TRY(h, hipGetLastError());
+  return build_grid(h, h->tx.p, h->ty.p, h->tz.p, total);
 }
 
 int ndt_set_global_source_size(ndt_handle* h, int64_t n_total) {

@@ -309,7 +309,7 @@ __device__ unsigned long long g_stamps[4096 * 8];
 #endif
 
 constexpr int NGROUPS = 32;          // second-level fan-in (only for grids above SINGLE_LEVEL_MAX rows)
-constexpr int SINGLE_LEVEL_MAX = 2048;  // rows one block adds directly
+constexpr int SINGLE_LEVEL_MAX_DEFAULT = 2048;  // rows one block adds directly
 constexpr int COUNTERS_PER_POSE = 1 + NGROUPS;
 constexpr int MAX_WAVES = MAX_BLOCK / 64;
 constexpr int MAX_COLS = MAX_BLOCK / 32;  // row-parallel lanes of the final sum
@@ -372,7 +372,8 @@ __device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], double
                                                     double* __restrict__ group_rows,
                                                     unsigned int* __restrict__ counters,
                                                     double* __restrict__ out,
-                                                    unsigned long long* flag, unsigned long long seq) {
+                                                    unsigned long long* flag, unsigned long long seq,
+                                                    int single_level_max) {
   __shared__ double lds_w[MAX_WAVES][EV_WORDS];
   __shared__ double lds_c[MAX_COLS][EV_WORDS];
   __shared__ int s_last;
@@ -396,7 +397,7 @@ __device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], double
 #endif
   const int nb = (int)gridDim.x;
   int ngroups = 1;
-  if (nb > SINGLE_LEVEL_MAX) {
+  if (nb > single_level_max) {
     const int gsize = (nb + NGROUPS - 1) / NGROUPS;  // blocks per group
     ngroups = (nb + gsize - 1) / gsize;              // <= NGROUPS
     const int grp = (int)blockIdx.x / gsize;
@@ -409,8 +410,8 @@ __device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], double
     __syncthreads();
     rows = group_rows;
   }
-  const int nrows = nb > SINGLE_LEVEL_MAX ? ngroups : nb;
-  if (threadIdx.x == 0) s_last = ticket_is_last(counters, (unsigned int)(nb > SINGLE_LEVEL_MAX ? ngroups : nb));
+  const int nrows = nb > single_level_max ? ngroups : nb;
+  if (threadIdx.x == 0) s_last = ticket_is_last(counters, (unsigned int)nrows);
   NDT_STAMP(5);
   __syncthreads();
   if (!s_last) return;
@@ -490,7 +491,7 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
   NDT_STAMP(3);
   double* base = partials + (size_t)blockIdx.y * (gridDim.x + NGROUPS) * EV_WORDS;
   block_reduce_finish(acc, base + (size_t)NGROUPS * EV_WORDS, base, counters + blockIdx.y * COUNTERS_PER_POSE,
-                      out + (size_t)blockIdx.y * EV_WORDS, BATCH ? nullptr : flag, seq);
+                      out + (size_t)blockIdx.y * EV_WORDS, BATCH ? nullptr : flag, seq, ec.single_level_max);
 }
 
 __global__ void __launch_bounds__(256) k_transform(const float* __restrict__ sx, const float* __restrict__ sy,
@@ -551,9 +552,16 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
   const int blocks = derivs_grid_blocks(n_src);
   const int threads = derivs_block_threads(n_src);
   const int mode = !ec.need_hessian ? 0 : (ec.gauss_newton ? 2 : 1);
+  EvalConsts ecl = ec;
+  static const int slm = [] {
+    const char* e = getenv("NDT_DERIV_SINGLE_LEVEL_MAX");  // tuning knob
+    int v = e ? atoi(e) : 0;
+    return v > 0 ? v : SINGLE_LEVEL_MAX_DEFAULT;
+  }();
+  ecl.single_level_max = slm;
 #define NDT_LAUNCH(B, M, GY, FLAG, SEQ)                                                              \
   hipLaunchKernelGGL((k_derivatives<B, M>), dim3(blocks, GY), dim3(threads), 0, s, sx, sy, sz, (int)n_src, \
-                     g, cell2leaf, rec, pose, d_poses, ec, d_partials, d_counters, d_out, FLAG, SEQ)
+                     g, cell2leaf, rec, pose, d_poses, ecl, d_partials, d_counters, d_out, FLAG, SEQ)
   if (d_poses) {
     if (mode == 0) NDT_LAUNCH(true, 0, K, (unsigned long long*)nullptr, 0ull);
     else if (mode == 1) NDT_LAUNCH(true, 1, K, (unsigned long long*)nullptr, 0ull);

@@ -58,6 +58,7 @@ struct EvalConsts {
   int direct7;     // 1: centre + 6 face neighbours, 0: centre only
   int need_hessian;
   int gauss_newton;
+  int single_level_max;  // grids with more rows than this take the two-level final sum
 };
 
 // layout of one evaluation (matches NDT_EVAL_WORDS in include/ndt_hip.h)

@@ -40,6 +40,11 @@ void launch_finalize_leaves(const float* xyz4,
                             const int* leaf_cnt, int max_leaves, FinalizeParams fp, double* sums,
                             VoxelRecord* rec, LeafStats* stats, int* cell2leaf, hipStream_t s);
 
+// out[i] = (float)(R x + t) in f64 (sliding-window target assembly); out arrays hold n floats
+void launch_transform_append(const float* x, const float* y, const float* z, size_t n,
+                             const double pose_colmajor[16], float* ox, float* oy, float* oz,
+                             hipStream_t s);
+
 // ---- derivative evaluation (ndt_derivs.hip) ---------------------------------
 int derivs_grid_blocks(size_t n_src);
 int derivs_block_threads(size_t n_src);

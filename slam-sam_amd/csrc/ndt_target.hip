@@ -415,7 +415,42 @@ __global__ void __launch_bounds__(256) k_leaf_finalize(const uint32_t* __restric
   }
 }
 
+// Sliding-window target assembly: one archived body-frame scan moved into the
+// map frame by its current pose and appended to the target arrays.  The reference does this
+// on the host with a DOUBLE 4x4 (gtsam Pose3::matrix()) through pcl::transformPointCloud
+// (ref: run/pipeline_ligo_tc.cpp:519-526, run/pipeline.cpp:554-556): f64 products summed
+// left to right, rounded to f32 once.
+struct Affine64 {
+  double R[9];
+  double t[3];
+};
+
+__global__ void __launch_bounds__(256) k_transform_append(const float* __restrict__ x, const float* __restrict__ y,
+                                                         const float* __restrict__ z, size_t n, Affine64 T,
+                                                         float* __restrict__ ox, float* __restrict__ oy,
+                                                         float* __restrict__ oz) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double a = (double)x[i], b = (double)y[i], c = (double)z[i];
+  ox[i] = (float)(T.R[0] * a + T.R[1] * b + T.R[2] * c + T.t[0]);
+  oy[i] = (float)(T.R[3] * a + T.R[4] * b + T.R[5] * c + T.t[1]);
+  oz[i] = (float)(T.R[6] * a + T.R[7] * b + T.R[8] * c + T.t[2]);
+}
+
 }  // namespace
+
+void launch_transform_append(const float* x, const float* y, const float* z, size_t n,
+                             const double pose_colmajor[16], float* ox, float* oy, float* oz,
+                             hipStream_t s) {
+  if (n == 0) return;
+  Affine64 T;
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) T.R[3 * i + j] = pose_colmajor[4 * j + i];
+    T.t[i] = pose_colmajor[12 + i];
+  }
+  hipLaunchKernelGGL(k_transform_append, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, z, n, T,
+                     ox, oy, oz);
+}
 
 float decode_ordered(int enc) {
   int i = enc >= 0 ? enc : enc ^ 0x7fffffff;
