@@ -54,8 +54,9 @@ typedef enum ndt_status {
 
 /* same order as pclomp::NeighborSearchMethod (ref: run/pipeline.cpp:471-480) */
 typedef enum ndt_search_method {
-  NDT_KDTREE = 0,   /* not implemented yet: NDT_ERR_UNSUPPORTED */
-  NDT_DIRECT26 = 1, /* not implemented yet: NDT_ERR_UNSUPPORTED */
+  NDT_KDTREE = 0,   /* radius search (radius = resolution) over voxel centroids
+                       (ref: voxel_grid_covariance_impl.hpp:505-554), done as a 27-cell scan */
+  NDT_DIRECT26 = 1, /* not implemented: upstream-only mode with no statement in the reference tree */
   NDT_DIRECT7 = 2,
   NDT_DIRECT1 = 3
 } ndt_search_method;

@@ -384,8 +384,39 @@ static int64_t leaf_rank_at(const oracle_grid* g, float x, float y, float z) {
 
 // ref: voxel_grid_covariance_impl.hpp:560-600 (DIRECT7: centre, +x, -x, +y, -y,
 // +z, -z, found by offsetting the POINT by the leaf size in f32) and :604-615.
+// ref: voxel_grid_covariance_impl.hpp:505-554 (radiusSearch over the centroid cloud of
+// :386-435); FLANN's L2_Simple accumulates (dx^2 + dy^2) + dz^2 in f32 and keeps dist < r^2.
+static int kd_neighbors(const oracle_grid* g, const float p[3], int64_t out_rank[27]) {
+  if (!g->built) return 0;
+  const float r2 = static_cast<float>(static_cast<double>(g->leaf) * static_cast<double>(g->leaf));
+  const int c[3] = {cell_coord(p[0], g->inv_leaf, g->min_b[0]), cell_coord(p[1], g->inv_leaf, g->min_b[1]),
+                    cell_coord(p[2], g->inv_leaf, g->min_b[2])};
+  struct Hit { float d; int64_t r; };
+  Hit hits[27];
+  int n = 0;
+  for (int dz = -1; dz <= 1; ++dz)
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int i0 = c[0] + dx, i1 = c[1] + dy, i2 = c[2] + dz;
+        if (i0 < 0 || i1 < 0 || i2 < 0 || i0 >= g->div_b[0] || i1 >= g->div_b[1] || i2 >= g->div_b[2]) continue;
+        const int64_t idx = static_cast<int64_t>(i0 * g->divb_mul[0] + i1 * g->divb_mul[1] + i2 * g->divb_mul[2]);
+        auto it = g->cell2rank.find(idx);
+        if (it == g->cell2rank.end()) continue;
+        const oracle_leaf& L = g->leaves[it->second];
+        const float ex = p[0] - static_cast<float>(L.mean[0]), ey = p[1] - static_cast<float>(L.mean[1]),
+                    ez = p[2] - static_cast<float>(L.mean[2]);
+        float d = 0.0f;
+        d += ex * ex; d += ey * ey; d += ez * ez;
+        if (d < r2) hits[n++] = Hit{d, it->second};
+      }
+  std::sort(hits, hits + n, [](const Hit& a, const Hit& b) { return a.d < b.d || (a.d == b.d && a.r < b.r); });
+  for (int k = 0; k < n; ++k) out_rank[k] = hits[k].r;
+  return n;
+}
+
 extern "C" int oracle_grid_neighbors(const oracle_grid* g, const float p[3], int method,
-                                     int64_t out_rank[7]) {
+                                     int64_t out_rank[27]) {
+  if (method == ORACLE_KDTREE) return kd_neighbors(g, p, out_rank);
   int n = 0;
   int64_t r = leaf_rank_at(g, p[0], p[1], p[2]);
   if (r >= 0) out_rank[n++] = r;
@@ -706,7 +737,7 @@ extern "C" void oracle_derivatives(const oracle_grid* g, const float* src, size_
       for (int a = 0; a < 3; ++a)
         xt[a] = T[a] * x[0] + (T[4 + a] * x[1] + (T[8 + a] * x[2] + T[12 + a]));
       if (!finite3(xt)) continue;  // ref :573
-      int64_t nb[7];
+      int64_t nb[27];
       int nn = oracle_grid_neighbors(g, xt, prm->search_method, nb);
       if (nn == 0) continue;  // ref :592
       point_derivatives(x, jang, hang, need_hp, pd);

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-enum { ORACLE_DIRECT1 = 1, ORACLE_DIRECT7 = 7 };
+enum { ORACLE_DIRECT1 = 1, ORACLE_DIRECT7 = 7, ORACLE_KDTREE = 27 };
 enum { ORACLE_HESSIAN_FULL = 0, ORACLE_HESSIAN_GAUSS_NEWTON = 1 };
 /* covariance normalisation: vendored svn code uses /n then *n/(n-1)
  * (voxel_grid_covariance_impl.hpp:287-291); upstream PCL/pclomp is recalled
@@ -86,10 +86,14 @@ void oracle_grid_get_info(const oracle_grid* g, oracle_grid_info* out);
 void oracle_grid_export(const oracle_grid* g, int64_t* cell, int32_t* count,
                         double* mean3, double* cov9, double* icov9,
                         double* evecs9, double* evals3);
-/* neighbourhood of one point: writes up to 7 leaf ranks (index into the
- * exported order), returns the count */
+/* neighbourhood of one point: writes up to 27 leaf ranks (index into the exported order),
+ * returns the count.  ORACLE_KDTREE = radius search (radius = leaf size) over the f32
+ * centroids of the valid leaves (ref: voxel_grid_covariance_impl.hpp:505-554, centroids
+ * :386-435, radius svn_ndt_impl.hpp:579): a centroid within one leaf size of the point can
+ * only sit in the 3x3x3 cells around it, so those 27 cells are scanned instead of a kd-tree;
+ * FLANN's test `dist^2 < radius^2` in f32 is kept. */
 int oracle_grid_neighbors(const oracle_grid* g, const float p[3], int method,
-                          int64_t out_rank[7]);
+                          int64_t out_rank[27]);
 
 /* Gauss constants (svn_ndt_impl.hpp:80-131): out = {d1, d2, d3} */
 void oracle_gauss_constants(double resolution, double outlier_ratio, double out[3]);

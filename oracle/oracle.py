@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libndt_oracle.so")
 
-DIRECT1, DIRECT7 = 1, 7
+DIRECT1, DIRECT7, KDTREE = 1, 7, 27
 HESSIAN_FULL, HESSIAN_GAUSS_NEWTON = 0, 1
 COV_SVN, COV_PCL_RECALLED = 0, 1
 PAIR_SVN, PAIR_PCLOMP_RECALLED = 0, 1
@@ -175,7 +175,7 @@ class Grid:
 
     def neighbors(self, p, method=DIRECT7):
         p = np.asarray(p, dtype=np.float32)
-        out = (C.c_int64 * 7)()
+        out = (C.c_int64 * 27)()
         n = lib().oracle_grid_neighbors(self.h, _fp(p), method, out)
         return list(out[:n])
 

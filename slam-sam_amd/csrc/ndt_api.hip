@@ -146,8 +146,8 @@ int bind_device(ndt_handle* h) {
 
 bool params_valid(const ndt_params* p, std::string* why) {
   if (!(p->resolution > 1e-6f)) { *why = "resolution must be positive"; return false; }
-  if (p->search_method != NDT_DIRECT7 && p->search_method != NDT_DIRECT1) {
-    *why = "search method not implemented (DIRECT7 / DIRECT1 only)";
+  if (p->search_method != NDT_DIRECT7 && p->search_method != NDT_DIRECT1 && p->search_method != NDT_KDTREE) {
+    *why = "search method not implemented (KDTREE / DIRECT7 / DIRECT1; pclomp's DIRECT26 has no in-tree statement)";
     return false;
   }
   if (!(p->outlier_ratio >= 0.0 && p->outlier_ratio < 1.0)) { *why = "outlier_ratio must be in [0,1)"; return false; }
@@ -284,6 +284,8 @@ EvalConsts make_eval_consts(const ndt_handle* h, bool need_h) {
   EvalConsts ec{};
   gauss_constants((double)h->prm.resolution, h->prm.outlier_ratio, &ec.d1, &ec.d2);
   ec.direct7 = h->prm.search_method == NDT_DIRECT7 ? 1 : 0;
+  ec.kdtree = h->prm.search_method == NDT_KDTREE ? 1 : 0;
+  ec.kd_radius2 = (float)((double)h->prm.resolution * (double)h->prm.resolution);
   ec.need_hessian = need_h ? 1 : 0;
   ec.gauss_newton = h->prm.hessian_mode == NDT_HESSIAN_GAUSS_NEWTON ? 1 : 0;
   return ec;

@@ -246,6 +246,56 @@ __device__ __forceinline__ void point_pairs(PairAcc& a, float x, float y, float 
   pair_update<MODE>(a, r6, xt, yt, zt, ec, slot[6] >= 0);
 }
 
+// FLANN's L2_Simple in f32, accumulated x, y, z, strict `<` (ref: radiusSearch,
+// voxel_grid_covariance_impl.hpp:505-554; centroids are the f32-rounded leaf means, :420-422).
+// Deliberately outside the FMA-contracted regions.
+__device__ __forceinline__ bool kd_within(const VoxelRecord& r, float xt, float yt, float zt, float r2) {
+  const float ex = xt - (float)r.mean[0], ey = yt - (float)r.mean[1], ez = zt - (float)r.mean[2];
+  float d = ex * ex;
+  d = d + ey * ey;
+  d = d + ez * ez;
+  return d < r2;
+}
+
+// KDTREE neighbourhood: every valid voxel whose centroid lies within one leaf size of the
+// point.  Such a centroid can only be in the 3x3x3 cells around the point's cell, so the
+// kd-tree becomes 27 index probes + a distance test; one z-layer (9 cells) at a time.
+template <int MODE>
+__device__ __forceinline__ void point_pairs_kd(PairAcc& a, float x, float y, float z, const GridGeom& g,
+                                               const int* __restrict__ cell2leaf,
+                                               const VoxelRecord* __restrict__ rec, const RigidRT& P,
+                                               const EvalConsts& ec) {
+  a.w[0] = a.w[1] = a.w[2] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) a.S[k] = 0.0;
+  a.score = 0.0; a.best = 0.0; a.npairs = 0;
+  const float xt = P.R[0] * x + (P.R[1] * y + (P.R[2] * z + P.t[0]));
+  const float yt = P.R[3] * x + (P.R[4] * y + (P.R[5] * z + P.t[1]));
+  const float zt = P.R[6] * x + (P.R[7] * y + (P.R[8] * z + P.t[2]));
+  const bool finite = isfinite(xt) && isfinite(yt) && isfinite(zt);
+  // the point's own (possibly out-of-box) cell, same f32 arithmetic as the grid build
+  const int i0 = finite ? (int)(floorf(xt * g.inv_leaf) - (float)g.min_b[0]) : -4;
+  const int i1 = finite ? (int)(floorf(yt * g.inv_leaf) - (float)g.min_b[1]) : -4;
+  const int i2 = finite ? (int)(floorf(zt * g.inv_leaf) - (float)g.min_b[2]) : -4;
+  for (int dz = -1; dz <= 1; ++dz) {
+    const int c2 = i2 + dz;
+    const bool zok = c2 >= 0 && c2 < g.div_b[2];
+    int slot[9];
+#pragma unroll
+    for (int n = 0; n < 9; ++n) {
+      const int c0 = i0 + (n % 3) - 1, c1 = i1 + (n / 3) - 1;
+      const bool ok = zok && c0 >= 0 && c0 < g.div_b[0] && c1 >= 0 && c1 < g.div_b[1];
+      slot[n] = ok ? cell2leaf[c0 + c1 * g.mul1 + c2 * g.mul2] : -1;
+    }
+#pragma unroll
+    for (int n = 0; n < 9; ++n) {
+      const VoxelRecord r = rec[slot[n] >= 0 ? slot[n] : 0];
+      const bool present = slot[n] >= 0 && kd_within(r, xt, yt, zt, ec.kd_radius2);
+      pair_update<MODE>(a, r, xt, yt, zt, ec, present);
+    }
+  }
+}
+
 // Recursive-halving reduce-scatter of 32 f64 words over the wave: after 6 steps lane
 // l holds the wave sum of word l>>1.  The two widest steps use gfx950's
 // v_permlane32_swap / v_permlane16_swap (exchange the upper half of one register with
@@ -427,7 +477,7 @@ __device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], double
   NDT_STAMP(7);
 }
 
-template <bool BATCH, int MODE>
+template <bool BATCH, int MODE, bool KD>
 __global__ void __launch_bounds__(MAX_BLOCK)
 k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, int n,
               GridGeom g, const int* __restrict__ cell2leaf, const VoxelRecord* __restrict__ rec,
@@ -474,7 +524,8 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
     x = sx[i]; y = sy[i]; z = sz[i];
     NDT_STAMP(1);
 #if !(defined(NDT_ABL) && NDT_ABL >= 3)
-    point_pairs<MODE>(a, x, y, z, g, cell2leaf, rec, rt, ec);
+    if (KD) point_pairs_kd<MODE>(a, x, y, z, g, cell2leaf, rec, rt, ec);
+    else point_pairs<MODE>(a, x, y, z, g, cell2leaf, rec, rt, ec);
 #endif
   }
   NDT_STAMP(2);
@@ -559,18 +610,25 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
     return v > 0 ? v : SINGLE_LEVEL_MAX_DEFAULT;
   }();
   ecl.single_level_max = slm;
-#define NDT_LAUNCH(B, M, GY, FLAG, SEQ)                                                              \
-  hipLaunchKernelGGL((k_derivatives<B, M>), dim3(blocks, GY), dim3(threads), 0, s, sx, sy, sz, (int)n_src, \
-                     g, cell2leaf, rec, pose, d_poses, ecl, d_partials, d_counters, d_out, FLAG, SEQ)
+#define NDT_LAUNCH(B, M, KD, GY, FLAG, SEQ)                                                         \
+  hipLaunchKernelGGL((k_derivatives<B, M, KD>), dim3(blocks, GY), dim3(threads), 0, s, sx, sy, sz,     \
+                     (int)n_src, g, cell2leaf, rec, pose, d_poses, ecl, d_partials, d_counters, d_out, \
+                     FLAG, SEQ)
+#define NDT_LAUNCH_MODE(B, KD, GY, FLAG, SEQ)                \
+  do {                                                        \
+    if (mode == 0) NDT_LAUNCH(B, 0, KD, GY, FLAG, SEQ);       \
+    else if (mode == 1) NDT_LAUNCH(B, 1, KD, GY, FLAG, SEQ);  \
+    else NDT_LAUNCH(B, 2, KD, GY, FLAG, SEQ);                 \
+  } while (0)
+  unsigned long long* const no_flag = nullptr;
   if (d_poses) {
-    if (mode == 0) NDT_LAUNCH(true, 0, K, (unsigned long long*)nullptr, 0ull);
-    else if (mode == 1) NDT_LAUNCH(true, 1, K, (unsigned long long*)nullptr, 0ull);
-    else NDT_LAUNCH(true, 2, K, (unsigned long long*)nullptr, 0ull);
+    if (ec.kdtree) NDT_LAUNCH_MODE(true, true, K, no_flag, 0ull);
+    else NDT_LAUNCH_MODE(true, false, K, no_flag, 0ull);
   } else {
-    if (mode == 0) NDT_LAUNCH(false, 0, 1, d_flag, seq);
-    else if (mode == 1) NDT_LAUNCH(false, 1, 1, d_flag, seq);
-    else NDT_LAUNCH(false, 2, 1, d_flag, seq);
+    if (ec.kdtree) NDT_LAUNCH_MODE(false, true, 1, d_flag, seq);
+    else NDT_LAUNCH_MODE(false, false, 1, d_flag, seq);
   }
+#undef NDT_LAUNCH_MODE
 #undef NDT_LAUNCH
 }
 

@@ -55,7 +55,9 @@ struct PoseConsts {
 
 struct EvalConsts {
   double d1, d2;   // Gauss constants (ref: svn_ndt_impl.hpp:80-131)
-  int direct7;     // 1: centre + 6 face neighbours, 0: centre only
+  int direct7;     // 1: centre + 6 face neighbours, 0: centre only (ignored in KDTREE mode)
+  int kdtree;      // 1: radius search over voxel centroids (27-cell scan)
+  float kd_radius2;  // (float)(radius^2), radius = leaf size (ref: svn_ndt_impl.hpp:579)
   int need_hessian;
   int gauss_newton;
   int single_level_max;  // grids with more rows than this take the two-level final sum

@@ -58,7 +58,7 @@ def test_invalid_arguments_are_rejected(pkg):
     h = C.c_void_p()
     bad = pkg.default_params(resolution=0.0)
     assert L.ndt_create(C.byref(bad), C.byref(h)) == -1
-    bad = pkg.default_params(search_method=pkg.KDTREE)
+    bad = pkg.default_params(search_method=pkg.DIRECT26)  # upstream-only mode, no in-tree statement
     assert L.ndt_create(C.byref(bad), C.byref(h)) == -1
     assert L.ndt_align(None, None, None) == -1
     assert L.ndt_get_grid_info(None, None) == -1

@@ -197,6 +197,27 @@ def test_parameter_variants(pkg, O, S):
         ndt.close()
 
 
+def test_kdtree_search_mode(pkg, O, S, c2):
+    """setNeighborhoodSearchMethod(KDTREE) (ref: run/pipeline.cpp:475-476): radius search over the
+    voxel centroids, on the GPU as a 27-cell scan; neighbour sets must match the oracle exactly."""
+    for cfg, res in ((S.config_c1(), 1.0), (c2, 1.0)):
+        grid = O.Grid(cfg["target"], O.default_params(resolution=res, search_method=O.KDTREE, step_size=0.1,
+                                                      trans_epsilon=1e-4, max_iterations=35, num_threads=8))
+        ndt = make_ndt(pkg, resolution=res, max_iterations=35)
+        ndt.setNeighborhoodSearchMethod(pkg.KDTREE)
+        ndt.setInputTarget(cfg["target"])
+        ndt.setInputSource(cfg["source"])
+        p0 = O.matrix_to_pose(cfg["guess"])
+        poses = np.stack([p0, O.matrix_to_pose(cfg["gt"]), O.matrix_to_pose(S.pose_matrix(400, 0, 0, 0, 0, 0))])
+        for p, e in zip(poses, ndt.evalDerivatives(poses)):
+            assert_derivs_match(e, grid.derivatives(cfg["source"], p))
+        T = ndt.align(cfg["guess"])
+        ref = grid.align(cfg["source"], cfg["guess"])
+        dt, dr = S.pose_error(T, ref["T"])
+        assert dt < ALIGN_TOL_M and dr < ALIGN_TOL_RAD
+        ndt.close()
+
+
 def test_regularization_and_fixed_step(pkg, O, S):
     cfg = S.config_c1()
     reg_pose = cfg["gt"] @ S.pose_matrix(0.05, 0.0, 0.0, 0, 0, 0)

@@ -270,3 +270,22 @@ def test_no_overlap_gives_zero_score(O, S):
     assert d["n_pairs"] == 0 and d["score"] == 0.0 and not d["gradient"].any()
     r = grid.align(src, far)
     assert r["iterations"] == 0  # zero Newton step: loop exits at once
+
+
+def test_kdtree_radius_search_matches_brute_force(O, S):
+    """KDTREE mode (ref: voxel_grid_covariance_impl.hpp:505-554): the oracle's 27-cell scan must
+    return exactly the leaves whose f32 centroid is within one leaf size (f32 distance, strict <)."""
+    cfg = S.config_c1()
+    for res in (1.0, 0.7):
+        prm = O.default_params(resolution=res, search_method=O.KDTREE)
+        grid = O.Grid(cfg["target"], prm)
+        cent = grid.export()["mean"].astype(np.float32)
+        r2 = np.float32(np.float64(np.float32(res)) ** 2)
+        xt = S.transform(cfg["guess"], cfg["source"])
+        pts = np.concatenate([xt[::41], xt[:50] + np.float32(30.0)])  # incl. points outside the grid box
+        for p in pts:
+            d = (p[None] - cent) ** 2
+            d2 = (d[:, 0] + d[:, 1]) + d[:, 2]
+            assert sorted(grid.neighbors(p, O.KDTREE)) == np.nonzero(d2 < r2)[0].tolist()
+    r = grid.align(cfg["source"], cfg["guess"])
+    assert r["converged"] and S.pose_error(r["T"], cfg["gt"])[0] < 0.05
