@@ -289,4 +289,85 @@ class NormalDistributionsTransform
 #endif
 };
 
+// ---------------------------------------------------------------------------------------------
+// svn_ndt::SvnNormalDistributionsTransform-shaped adapter (ref: extern/svn_ndt/include/svn_ndt.h:
+// 100-182; driver run/pipeline_lo_svn.cpp:301-319,387-388).  Poses cross as 4x4 double,
+// column-major (gtsam::Pose3::matrix().data()); build a gtsam::Pose3 from SvnNdtResult::final_pose
+// on the caller's side.  Stage 1 of every SVN iteration is one batched kernel launch.
+struct SvnNdtResult {
+  std::array<double, 16> final_pose{};        // column-major 4x4
+  std::array<double, 36> final_covariance{};  // row-major, GTSAM tangent order [rot, trans]
+  bool converged = false;
+  int iterations = 0;
+};
+
+template <typename PointSource, typename PointTarget>
+class SvnNormalDistributionsTransform {
+ public:
+  SvnNormalDistributionsTransform() {
+    ndt_default_params(&prm_);
+    prm_.hessian_mode = NDT_HESSIAN_GAUSS_NEWTON;  // svn_ndt.h:314
+    prm_.add_ridge = 1;                            // svn_ndt_impl.hpp:650-653
+    status_ = ndt_create(&prm_, &h_);
+    ndt_svn_default_params(&svn_);
+  }
+  ~SvnNormalDistributionsTransform() { ndt_destroy(h_); }
+  SvnNormalDistributionsTransform(const SvnNormalDistributionsTransform&) = delete;
+  SvnNormalDistributionsTransform& operator=(const SvnNormalDistributionsTransform&) = delete;
+
+  void setResolution(float r) { prm_.resolution = r; push(); }
+  void setMinPointPerVoxel(int n) { prm_.min_points_per_voxel = n; push(); }
+  void setOutlierRatio(double o) { prm_.outlier_ratio = o; push(); }
+  void setNeighborhoodSearchMethod(NeighborSearchMethod m) { prm_.search_method = (int)m; push(); }
+  void setUseGaussNewtonHessian(bool on) { prm_.hessian_mode = on ? NDT_HESSIAN_GAUSS_NEWTON : NDT_HESSIAN_FULL; push(); }
+  void setNumThreads(int n) { prm_.num_threads = n; push(); }
+  void setParticleCount(int k) { svn_.particle_count = k; }
+  void setMaxIterations(int n) { svn_.max_iterations = n; }
+  void setKernelBandwidth(double h) { svn_.kernel_bandwidth = h; }
+  void setStepSize(double s) { svn_.step_size = s; }
+  void setEarlyStopThreshold(double t) { svn_.stop_threshold = t; }
+  void setParticleSeed(uint64_t seed) { seed_ = seed; }  // the reference seeds from the wall clock
+
+  template <class CloudPtr>
+  void setInputTarget(const CloudPtr& cloud) {
+    if (!h_) return;
+    status_ = (cloud && !cloud->points.empty())
+                  ? ndt_set_target(h_, &cloud->points[0].x, cloud->points.size(), sizeof(cloud->points[0]))
+                  : ndt_set_target(h_, nullptr, 0, 12);
+  }
+
+  // align(source_cloud, prior_mean): prior_pose = gtsam::Pose3::matrix().data()
+  template <class Cloud>
+  SvnNdtResult align(const Cloud& source, const double prior_pose_colmajor[16]) {
+    SvnNdtResult r;
+    std::memcpy(r.final_pose.data(), prior_pose_colmajor, sizeof(double) * 16);
+    for (int i = 0; i < 6; ++i) r.final_covariance[7 * i] = 1.0;  // failure convention, ref :682-702
+    if (!h_) { status_ = NDT_ERR_NO_DEVICE; return r; }
+    status_ = source.points.empty() ? ndt_set_source(h_, nullptr, 0, 12)
+                                    : ndt_set_source(h_, &source.points[0].x, source.points.size(), sizeof(source.points[0]));
+    if (status_ != NDT_OK || svn_.particle_count <= 0) return r;
+    std::vector<double> particles(16 * (size_t)svn_.particle_count);
+    ndt_svn_sample_particles(prior_pose_colmajor, svn_.particle_count, seed_++, particles.data());
+    ndt_svn_result out;
+    status_ = ndt_svn_align(h_, &svn_, prior_pose_colmajor, particles.data(), &out);
+    if (status_ != NDT_OK) return r;
+    std::memcpy(r.final_pose.data(), out.final_pose, sizeof(double) * 16);
+    std::memcpy(r.final_covariance.data(), out.final_covariance, sizeof(double) * 36);
+    r.converged = out.converged != 0;
+    r.iterations = out.iterations;
+    return r;
+  }
+
+  int lastStatus() const { return status_; }
+  std::string lastError() const { return h_ ? ndt_last_error(h_) : "no engine (ndt_create failed: GPU required)"; }
+
+ private:
+  void push() { if (h_) status_ = ndt_set_params(h_, &prm_); }
+  ndt_params prm_{};
+  ndt_svn_params svn_{};
+  ndt_handle* h_ = nullptr;
+  int status_ = NDT_OK;
+  uint64_t seed_ = 1;
+};
+
 }  // namespace ndt_hip

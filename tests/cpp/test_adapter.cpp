@@ -79,6 +79,24 @@ int main() {
   empty.computeTransformation(o2, guess);
   ok = ok && !empty.hasConverged() && empty.lastStatus() == NDT_ERR_NO_TARGET &&
        empty.getFinalTransformation() == guess;
+  // svn_ndt-shaped adapter: K = 8 particles, Gauss-Newton Hessian, one launch per iteration
+  ndt_hip::SvnNormalDistributionsTransform<PointT, PointT> svn;
+  svn.setResolution(1.0f);
+  svn.setMinPointPerVoxel(3);
+  svn.setNeighborhoodSearchMethod(ndt_hip::DIRECT7);
+  svn.setParticleCount(8);
+  svn.setMaxIterations(100);
+  svn.setKernelBandwidth(1.0);
+  svn.setEarlyStopThreshold(1e-4);
+  svn.setStepSize(1.0);
+  svn.setParticleSeed(2);
+  svn.setInputTarget(tgt);
+  ndt_hip::SvnNdtResult sr = svn.align(*src, guess_d);
+  double serr = 0;
+  for (int r = 0; r < 3; ++r) serr += (sr.final_pose[12 + r] - gt[12 + r]) * (sr.final_pose[12 + r] - gt[12 + r]);
+  std::printf("svn: converged=%d iterations=%d trans_err=%.5f cov00=%.3g\n", (int)sr.converged, sr.iterations,
+              std::sqrt(serr), sr.final_covariance[0]);
+  ok = ok && sr.iterations > 0 && std::sqrt(serr) < 0.1 && sr.final_covariance[0] > 0.0;
   std::printf(ok ? "PASS\n" : "FAIL\n");
   return ok ? 0 : 1;
 }
