@@ -114,16 +114,28 @@ def main():
     reduce_mode = "none"
     if world > 1:
         reduce_mode = os.environ.get("NDT_BENCH_REDUCE", "rccl")
+        if reduce_mode not in ("rccl", "shm"):
+            raise SystemExit("NDT_BENCH_REDUCE must be rccl or shm")
         if reduce_mode == "rccl":
+            # RCCL communicator of the engine itself (its id travels through torch.distributed)
             box = [pkg.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
-            ndt.commInitRccl(box[0], rank, world)
-        elif reduce_mode == "shm":
+            ok = torch.ones(1, dtype=torch.int32, device=dev)
+            try:
+                ndt.commInitRccl(box[0], rank, world)
+            except pkg.NdtError as e:
+                print("rank %d: RCCL communicator failed (%s)" % (rank, e), file=sys.stderr, flush=True)
+                ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                # transport fallback only (the compute path is unchanged): host-side sum through
+                # POSIX shared memory; reported as such in config.reduce
+                ndt.commDestroy()
+                reduce_mode = "shm (rccl init failed)"
+        if reduce_mode != "rccl":
             box = ["/ndt_bench_%d" % os.getpid() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
             ndt.commInitShm(box[0], rank, world)
-        else:
-            raise SystemExit("NDT_BENCH_REDUCE must be rccl or shm")
         ndt.setGlobalSourceSize(n_src_total)
 
     def step():
