@@ -92,11 +92,19 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    # rehearsal knob for a 1-GPU box: every rank on device 0, gloo rendezvous, shm reducer
+    rehearsal = os.environ.get("NDT_BENCH_SINGLE_DEVICE", "0") == "1"
+    if rehearsal:
+        local_rank = 0
+        os.environ["NDT_BENCH_REDUCE"] = "shm"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     pkg = ge.load_package()
     S = pkg.synth
@@ -168,7 +176,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -190,7 +198,8 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic_k_derivatives.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            # measured on the full 200k-point launch; a shard touches its share of it
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch") * (c / float(n_src_total))
         except Exception:
             traffic = None
 

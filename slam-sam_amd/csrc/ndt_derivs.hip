@@ -347,6 +347,7 @@ __device__ __forceinline__ void wave_reduce_scatter32(double* acc, int lane) {
 // diagnostic build only: 100 MHz wall-clock stamps of wave 0 / lane 0 of every block,
 // written to a side buffer no other code reads (cdna_hip_programming.md section 7)
 __device__ unsigned long long g_stamps[4096 * 8];
+__device__ unsigned int g_hwid[4096 * 2];
 #define NDT_STAMP(k)                                                                   \
   do {                                                                                 \
     if (threadIdx.x == 0 && blockIdx.x < 4096 && blockIdx.y == 0) {                    \
@@ -488,6 +489,12 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
   // after the pair loop, so they are parked in LDS (81 live SGPRs would spill) and the
   // barrier that publishes them sits behind the memory-latency part of the kernel.
   NDT_STAMP(0);
+#ifdef NDT_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < 4096 && blockIdx.y == 0) {
+    g_hwid[blockIdx.x * 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+    g_hwid[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); // HW_REG_XCC_ID
+  }
+#endif
   __shared__ AngleTables tab;
   RigidRT rt;
   if (BATCH) {
@@ -566,7 +573,9 @@ int derivs_counters_per_pose() { return COUNTERS_PER_POSE; }
 int derivs_read_stamps(unsigned long long* out, int nblocks) {
 #ifdef NDT_STAMPS
   if (nblocks > 4096) nblocks = 4096;
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8 * nblocks) == hipSuccess ? nblocks : -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8 * nblocks) != hipSuccess) return -1;
+  // hw ids follow the stamps: nblocks x 2 uint32 packed into nblocks uint64
+  return hipMemcpyFromSymbol(out + (size_t)8 * nblocks, HIP_SYMBOL(g_hwid), sizeof(unsigned int) * 2 * nblocks) == hipSuccess ? nblocks : -1;
 #else
   (void)out; (void)nblocks;
   return 0;

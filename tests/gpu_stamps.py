@@ -13,9 +13,11 @@ for n in (1000, 200000):
     ndt.setInputSource(cfg["source"][:n])
     nb = (n + 511) // 512
     for _ in range(5): ndt.align(cfg["gt"])
-    buf = np.zeros((nb, 8), np.uint64)
-    got = L.ndt_debug_read_stamps(buf.ctypes.data, nb)
+    raw = np.zeros(nb * 9, np.uint64)
+    got = L.ndt_debug_read_stamps(raw.ctypes.data, nb)
     assert got == nb, got
+    buf = raw[:nb * 8].reshape(nb, 8)
+    hw = raw[nb * 8:].view(np.uint32).reshape(nb, 2)
     t = buf.astype(np.int64)
     t0 = t[:, 0].min()
     rel = (t - t0) * 0.01  # us
@@ -25,3 +27,14 @@ for n in (1000, 200000):
     for k in range(6):
         print("  %-12s  min %6.2f  median %6.2f  max %6.2f" % (names[k], rel[:, k].min(), np.median(rel[:, k]), rel[:, k].max()))
     print("  last block %d: ticket %.2f  final sum %.2f  flag %.2f" % (last, rel[last, 5], rel[last, 6], rel[last, 7]))
+    if n > 1000:
+        xcc = hw[:, 1] & 0xF
+        cu = (hw[:, 0] >> 8) & 0xF; sh = (hw[:, 0] >> 12) & 0x1; se = (hw[:, 0] >> 13) & 0x7
+        key = xcc.astype(np.int64) * 1000 + se * 100 + sh * 20 + cu
+        uniq, cnt = np.unique(key, return_counts=True)
+        print("  distinct CUs used %d; blocks per CU histogram %s" % (len(uniq), dict(zip(*np.unique(cnt, return_counts=True)))))
+        per = {k: c for k, c in zip(uniq, cnt)}
+        two = np.array([per[k] for k in key]) >= 2
+        print("  pairs-done (us): CUs with 1 block: median %.2f max %.2f | CUs with >=2 blocks: median %.2f max %.2f"
+              % (np.median(rel[~two, 2]), rel[~two, 2].max(), np.median(rel[two, 2]), rel[two, 2].max()))
+        print("  per-XCC block counts", dict(zip(*np.unique(xcc, return_counts=True))))
