@@ -316,8 +316,10 @@ int wait_flag(ndt_handle* h, unsigned long long seq) {
     if ((++spins & 0xFFFF) == 0 &&
         std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
       HIP_TRY(h, hipStreamSynchronize(h->stream));
-      if (__atomic_load_n(f, __ATOMIC_ACQUIRE) != seq)
+      if (__atomic_load_n(f, __ATOMIC_ACQUIRE) != seq) {
+        h->counters_zeroed = 0;  // the ticket words may be stale: re-zero them before the next launch
         return fail(h, NDT_ERR_HIP, "derivative kernel finished without publishing its result");
+      }
       break;
     }
   }
@@ -348,6 +350,7 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, s));
   launch_derivatives(h->sx.p, h->sy.p, h->sz.p, h->n_src, h->geom, h->cell2leaf.p, h->rec.p, pc,
                      nullptr, 1, ec, h->partials.p, h->counters.p, d_out, s, spin ? h->flag.d : nullptr, seq);
+  HIP_TRY(h, hipGetLastError());
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, s));
   if (dev_out) {
     int rc = h->red.allreduce_device(h->dres.p, EV_WORDS, s, &h->err);
@@ -680,6 +683,7 @@ int ndt_eval_derivatives(ndt_handle* h, const double* poses6, const float* trans
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, s));
   launch_derivatives(h->sx.p, h->sy.p, h->sz.p, h->n_src, h->geom, h->cell2leaf.p, h->rec.p,
                      h->hposes.h[0], h->dposes.p, K, ec, h->partials.p, h->counters.p, h->dres.p, s);
+  HIP_TRY(h, hipGetLastError());
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, s));
   if (h->red.wants_device_buffer()) {
     rc = h->red.allreduce_device(h->dres.p, K * EV_WORDS, s, &h->err);

@@ -388,6 +388,36 @@ def test_full_size_linearity_over_shards(pkg, O, c3, c3_ndt):
     c3_ndt.setInputSource(src)
 
 
+def test_large_source_two_level_final_sum(pkg, O, c3, c3_ndt):
+    """> 1M source points: more than 2048 partial rows, so the in-kernel final sum goes through
+    its group level.  Must equal the sum of the single-level evaluations of its chunks."""
+    src = c3["source"]
+    rng = np.random.default_rng(5)
+    chunks = [(src + rng.normal(0, 0.01, src.shape)).astype(np.float32) for _ in range(6)]
+    p = O.matrix_to_pose(c3["gt"])
+    acc = None
+    for ch in chunks:
+        c3_ndt.setInputSource(ch)
+        e = c3_ndt.evalDerivatives(p)[0]
+        acc = e if acc is None else {k: acc[k] + e[k] for k in e}
+    big = np.concatenate(chunks)
+    assert len(big) == 1200000
+    c3_ndt.setInputSource(big)
+    e = c3_ndt.evalDerivatives(p)[0]          # batched kernel
+    assert e["n_pairs"] == acc["n_pairs"] and e["n_with_neighbors"] == acc["n_with_neighbors"]
+    assert e["score"] == pytest.approx(acc["score"], rel=1e-12)
+    assert np.linalg.norm(e["hessian"] - acc["hessian"]) < 1e-11 * np.linalg.norm(acc["hessian"])
+    # single-pose kernel at the same grid size: align's last evaluation re-done by the batched one
+    c3_ndt.setParams(max_iterations=0)
+    c3_ndt.align(c3["gt"])
+    r = c3_ndt.getResult()
+    eg = c3_ndt.evalDerivatives(r["pose"], transforms=[r["T"]])[0]
+    assert r["n_pairs"] == eg["n_pairs"] and r["score"] == eg["score"]
+    assert np.array_equal(r["hessian"], eg["hessian"])
+    c3_ndt.setParams(max_iterations=35)
+    c3_ndt.setInputSource(src)
+
+
 def test_full_size_leaf_invariants(c3_ndt):
     """Checksum-of-checksums style invariants of the voxel table."""
     L = c3_ndt.getLeaves()
