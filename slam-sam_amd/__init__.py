@@ -174,6 +174,7 @@ def lib():
         L.ndt_svn_default_params.argtypes = [C.POINTER(SvnParams)]
         L.ndt_svn_sample_particles.argtypes = [dp, C.c_int, C.c_uint64, dp]
         L.ndt_svn_align.argtypes = [vp, C.POINTER(SvnParams), dp, dp, C.POINTER(SvnResult)]
+        L.ndt_debug_sort_pairs.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, vp]  # test seam, not in the header
         _lib = L
     return _lib
 
@@ -299,6 +300,14 @@ class NormalDistributionsTransform:
         if a.ndim != 2 or a.shape[1] < 3:
             raise ValueError("cloud must be N x >=3 float32")
         return a
+
+    def debugSortPairs(self, keys, end_bit):
+        """Test seam: the voxel build's stable radix sort on caller keys -> (sorted keys, permutation)."""
+        k = np.ascontiguousarray(keys, dtype=np.uint32)
+        ko, vo = np.empty_like(k), np.empty_like(k)
+        self._check(lib().ndt_debug_sort_pairs(self._h, k.ctypes.data, len(k), int(end_bit), ko.ctypes.data,
+                                               vo.ctypes.data))
+        return ko, vo
 
     def setInputTarget(self, cloud):
         a = self._xyz(cloud)

@@ -263,14 +263,17 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
 
   HIP_TRY(h, hipMemsetAsync(h->cell2leaf.p, 0xFF, (size_t)g.ncells * sizeof(int), s));
   HIP_TRY(h, hipMemsetAsync(h->nleaf.p, 0, 2 * sizeof(int), s));
-  launch_cell_keys(x, y, z, n, g, h->keys.p, h->vals.p, h->xyz4.p, s);
   int bits = 1;
   while (bits < 32 && (1ull << bits) <= (unsigned long long)g.ncells) ++bits;  // sentinel = ncells
-  HIP_TRY(h, sort_pairs(h->sort_tmp.p, tmp_bytes, h->keys.p, h->keys2.p, h->vals.p, h->vals2.p, n, bits, s));
-  launch_find_runs(h->keys2.p, n, g.ncells, min_pts, h->nleaf.p, h->run_counts.p, h->run_offsets.p,
+  launch_cell_keys(x, y, z, n, g, h->keys.p, h->xyz4.p, bits, h->sort_tmp.p, s);
+  bool in_b = false;
+  HIP_TRY(h, sort_pairs(h->sort_tmp.p, h->keys.p, h->keys2.p, h->vals.p, h->vals2.p, n, bits, s, &in_b));
+  const uint32_t* keys_sorted = in_b ? h->keys2.p : h->keys.p;
+  const uint32_t* vals_sorted = in_b ? h->vals2.p : h->vals.p;
+  launch_find_runs(keys_sorted, n, g.ncells, min_pts, h->nleaf.p, h->run_counts.p, h->run_offsets.p,
                    h->leaf_start.p, h->leaf_cnt.p, s);
   FinalizeParams fp{h->prm.eig_inflation_ratio, h->prm.cov_mode};
-  launch_finalize_leaves(h->xyz4.p, h->keys2.p, h->vals2.p, h->nleaf.p, h->leaf_start.p, h->leaf_cnt.p,
+  launch_finalize_leaves(h->xyz4.p, keys_sorted, vals_sorted, h->nleaf.p, h->leaf_start.p, h->leaf_cnt.p,
                          max_leaves, fp, h->leaf_sums.p, h->rec.p, h->stats.p, h->cell2leaf.p, s);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemcpyAsync(h->small.h + 8, h->nleaf.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -871,6 +874,32 @@ int ndt_comm_destroy(ndt_handle* h) {
 
 // diagnostic builds only (-DNDT_STAMPS): 8 x 100 MHz stamps per block of the last launch
 int ndt_debug_read_stamps(unsigned long long* out, int nblocks) { return derivs_read_stamps(out, nblocks); }
+
+// test seam (not in the public header): the voxel build's radix sort on caller-supplied keys;
+// vals_out receives the stable sorting permutation.  Host arrays.
+int ndt_debug_sort_pairs(ndt_handle* h, const uint32_t* keys, size_t n, int end_bit, uint32_t* keys_out,
+                         uint32_t* vals_out) {
+  if (!h || (n && (!keys || !keys_out || !vals_out)) || end_bit < 1 || end_bit > 32) return NDT_ERR_INVALID_ARG;
+  if (n > (size_t)std::numeric_limits<int>::max() / 2) return NDT_ERR_INVALID_ARG;
+  if (n == 0) return NDT_OK;
+  int rc = bind_device(h);
+  if (rc) return rc;
+  hipStream_t s = h->stream;
+  HIP_TRY(h, h->keys.ensure(n));
+  HIP_TRY(h, h->vals.ensure(n));
+  HIP_TRY(h, h->keys2.ensure(n));
+  HIP_TRY(h, h->vals2.ensure(n));
+  HIP_TRY(h, h->sort_tmp.ensure(sort_temp_bytes(n)));
+  HIP_TRY(h, hipMemcpyAsync(h->keys.p, keys, n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+  launch_sort_first_count(h->keys.p, n, end_bit, h->sort_tmp.p, s);
+  bool in_b = false;
+  HIP_TRY(h, sort_pairs(h->sort_tmp.p, h->keys.p, h->keys2.p, h->vals.p, h->vals2.p, n, end_bit, s, &in_b));
+  HIP_TRY(h, hipMemcpyAsync(keys_out, in_b ? h->keys2.p : h->keys.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipMemcpyAsync(vals_out, in_b ? h->vals2.p : h->vals.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipStreamSynchronize(s));
+  h->have_grid = false;  // the build's scratch was overwritten
+  return NDT_OK;
+}
 
 int ndt_enable_kernel_timing(ndt_handle* h, int on) {
   if (!h) return NDT_ERR_INVALID_ARG;

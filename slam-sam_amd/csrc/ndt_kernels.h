@@ -13,14 +13,18 @@ void launch_bounds(const float* x, const float* y, const float* z, size_t n, int
 void fold_bounds(const int* rows, int nrows, int out[8]);
 float decode_ordered(int enc);
 
-// xyz4: n x 4 floats (16-byte aligned), packed copy of the cloud for the per-voxel gather
-void launch_cell_keys(const float* x, const float* y, const float* z, size_t n,
-                      const GridGeom& g, uint32_t* keys, uint32_t* vals, float* xyz4, hipStream_t s);
+// Cell key per point + xyz4 (n x 4 floats, 16-byte aligned: packed copy of the cloud for the
+// per-voxel gather) + the first sort digit's tile histograms into sort_temp.
+void launch_cell_keys(const float* x, const float* y, const float* z, size_t n, const GridGeom& g,
+                      uint32_t* keys, float* xyz4, int end_bit, void* sort_temp, hipStream_t s);
 
+// Stable LSD radix sort of (key, point index) on the low end_bit bits; values start as the
+// identity.  Ping-pongs between the a and b buffers; *result_in_b tells where the result is.
 size_t sort_temp_bytes(size_t n);
-hipError_t sort_pairs(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
-                      const uint32_t* vals_in, uint32_t* vals_out, size_t n, int end_bit,
-                      hipStream_t s);
+hipError_t sort_pairs(void* temp, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
+                      size_t n, int end_bit, hipStream_t s, bool* result_in_b);
+// test seam: the first digit's histograms for keys that did not come from launch_cell_keys
+void launch_sort_first_count(const uint32_t* keys, size_t n, int end_bit, void* sort_temp, hipStream_t s);
 
 // runs of equal cell key with >= min_pts points get a leaf slot (ascending cell order);
 // block_counts / block_offsets: runs_blocks(n) ints each; d_nleaf[0] receives the total

@@ -8,8 +8,9 @@
 // hash-map loop:
 //   1. bounds        : one streaming pass, wave-shuffle min/max, 6 int atomics/block
 //   2. cell keys     : one streaming pass (f32 floor, bit-compatible with the ref)
-//   3. stable LSD radix sort of (cell, point index) -- points of one voxel become
-//                      contiguous and stay in input order (deterministic sums)
+//   3. stable LSD radix sort of (cell, point index), hand-written (count / scan /
+//                      scatter per 8-bit digit, wave-ballot ranking) -- points of one
+//                      voxel become contiguous and stay in input order (deterministic sums)
 //   4. run detection : run tails find their head through a wave ballot; leaf slots by
 //                      count / scan / emit (ascending cell order, no atomics)
 //   5. leaf sums     : 8 lanes per voxel gather + reduce sum(x), sum(x x^T) in f64
@@ -19,11 +20,8 @@
 // Compiled with -ffp-contract=off: f32 index arithmetic must round as written.
 #include "ndt_kernels.h"
 
-#include <cstring>
-
-#include <rocprim/rocprim.hpp>
-
 #include <climits>
+#include <cstring>
 
 namespace ndt {
 
@@ -97,22 +95,182 @@ __device__ __forceinline__ int cell_of(float px, float py, float pz, const GridG
   return i0 + i1 * g.mul1 + i2 * g.mul2;
 }
 
-__global__ void __launch_bounds__(256) k_cell_keys(const float* __restrict__ x, const float* __restrict__ y,
-                                                  const float* __restrict__ z, size_t n, GridGeom g,
-                                                  uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                  float4* __restrict__ xyz4) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float a = x[i], b = y[i], c = z[i];
-  // packed copy for the per-voxel gather: one 16-byte line per point instead of three
-  xyz4[i] = make_float4(a, b, c, 0.0f);
-  uint32_t key = (uint32_t)g.ncells;  // sentinel sorts behind every real cell
-  if (finite3(a, b, c)) {
-    int idx = cell_of(a, b, c, g);
-    if (idx >= 0 && idx < g.ncells) key = (uint32_t)idx;
+// ---- stable LSD radix sort of (cell key, point index) ---------------------------------
+// One tile = 2048 consecutive pairs per 256-thread block; wave w owns the contiguous
+// quarter [w*512, (w+1)*512) of the tile and walks it in 8 rounds of 64, so "tile order"
+// is (wave, round, lane).  Per digit pass: count (per-tile histogram, bin-major), scan (one
+// block per bin over the tiles + bin totals), scatter (rank of a pair among the equal
+// digits before it in the tile: equal-digit lanes of a round find each other with 8
+// ballots, rounds chain through a per-wave LDS counter, waves through a 4-entry prefix).
+// No atomics on global memory, no look-back chain between tiles: every launch is a
+// streaming pass, and the result does not depend on scheduling.
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_ROUNDS = 8;
+constexpr int SORT_WAVES = SORT_THREADS / 64;
+constexpr int SORT_TILE = SORT_THREADS * SORT_ROUNDS;
+constexpr int SORT_BINS = 256;
+
+__device__ __forceinline__ int sort_index(int tile, int wave, int round, int lane) {
+  return tile * SORT_TILE + wave * (SORT_TILE / SORT_WAVES) + round * 64 + lane;
+}
+
+// Cell key per point (+ the packed float4 copy the per-voxel gather reads) and, in the same
+// pass, the tile histograms of the first sort digit.
+__global__ void __launch_bounds__(SORT_THREADS) k_cell_keys(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ z, int n, GridGeom g,
+                                                           uint32_t* __restrict__ keys, float4* __restrict__ xyz4,
+                                                           uint32_t digit_mask, int ntiles, int* __restrict__ hist) {
+  __shared__ int h[SORT_BINS];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float a[SORT_ROUNDS], b[SORT_ROUNDS], c[SORT_ROUNDS];
+#pragma unroll
+  for (int r = 0; r < SORT_ROUNDS; ++r) {  // all loads of the tile in flight before any use
+    const int i = sort_index(blockIdx.x, wave, r, lane);
+    const int j = i < n ? i : 0;
+    a[r] = x[j]; b[r] = y[j]; c[r] = z[j];
   }
-  keys[i] = key;
-  vals[i] = (uint32_t)i;
+#pragma unroll
+  for (int r = 0; r < SORT_ROUNDS; ++r) {
+    const int i = sort_index(blockIdx.x, wave, r, lane);
+    if (i >= n) break;
+    // packed copy for the per-voxel gather: one 16-byte line per point instead of three
+    xyz4[i] = make_float4(a[r], b[r], c[r], 0.0f);
+    uint32_t key = (uint32_t)g.ncells;  // sentinel sorts behind every real cell
+    if (finite3(a[r], b[r], c[r])) {
+      int idx = cell_of(a[r], b[r], c[r], g);
+      if (idx >= 0 && idx < g.ncells) key = (uint32_t)idx;
+    }
+    keys[i] = key;
+    atomicAdd(&h[key & digit_mask], 1);
+  }
+  __syncthreads();
+  hist[threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(SORT_THREADS) k_sort_count(const uint32_t* __restrict__ keys, int n, int shift,
+                                                            uint32_t digit_mask, int ntiles, int* __restrict__ hist) {
+  __shared__ int h[SORT_BINS];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t key[SORT_ROUNDS];
+#pragma unroll
+  for (int r = 0; r < SORT_ROUNDS; ++r) {
+    const int i = sort_index(blockIdx.x, wave, r, lane);
+    key[r] = keys[i < n ? i : 0];
+  }
+#pragma unroll
+  for (int r = 0; r < SORT_ROUNDS; ++r)
+    if (sort_index(blockIdx.x, wave, r, lane) < n) atomicAdd(&h[(key[r] >> shift) & digit_mask], 1);
+  __syncthreads();
+  hist[threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+}
+
+__device__ __forceinline__ int wave_inclusive_scan(int v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    int t = __shfl_up(v, off);
+    if (lane >= off) v += t;
+  }
+  return v;
+}
+
+// one block per bin: exclusive scan of that bin's counts over the tiles (in place) + total
+__global__ void __launch_bounds__(SORT_THREADS) k_sort_scan(int* __restrict__ hist, int ntiles, int* __restrict__ totals) {
+  __shared__ int wsum[SORT_WAVES];
+  __shared__ int carry;
+  int* row = hist + (size_t)blockIdx.x * ntiles;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int base = 0; base < ntiles; base += SORT_THREADS) {
+    const int i = base + threadIdx.x;
+    const int v = i < ntiles ? row[i] : 0;
+    const int incl = wave_inclusive_scan(v, lane);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int before = carry;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    if (i < ntiles) row[i] = before + incl - v;
+    __syncthreads();
+    if (threadIdx.x == SORT_THREADS - 1) carry = before + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
+// FIRST: the values are the identity permutation and are synthesised instead of read
+template <bool FIRST>
+__global__ void __launch_bounds__(SORT_THREADS) k_sort_scatter(const uint32_t* __restrict__ keys_in,
+                                                              const uint32_t* __restrict__ vals_in, int n, int shift,
+                                                              uint32_t digit_mask, int ntiles,
+                                                              const int* __restrict__ hist,
+                                                              const int* __restrict__ totals,
+                                                              uint32_t* __restrict__ keys_out,
+                                                              uint32_t* __restrict__ vals_out) {
+  __shared__ int cnt[SORT_WAVES][SORT_BINS];
+  __shared__ int gbase[SORT_BINS];
+  __shared__ int wsum[SORT_WAVES];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  {  // first output slot of every digit for this tile: bins before it + same bin in earlier tiles
+    const int t = totals[threadIdx.x];
+    const int incl = wave_inclusive_scan(t, lane);
+    if (lane == 63) wsum[wave] = incl;
+#pragma unroll
+    for (int w = 0; w < SORT_WAVES; ++w) cnt[w][threadIdx.x] = 0;
+    __syncthreads();
+    int before = 0;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    gbase[threadIdx.x] = before + incl - t + hist[threadIdx.x * ntiles + blockIdx.x];
+  }
+  uint32_t key[SORT_ROUNDS], val[SORT_ROUNDS];
+  int rank[SORT_ROUNDS];
+#pragma unroll
+  for (int r = 0; r < SORT_ROUNDS; ++r) {
+    const int i = sort_index(blockIdx.x, wave, r, lane);
+    key[r] = i < n ? keys_in[i] : 0u;
+    val[r] = FIRST ? (uint32_t)i : (i < n ? vals_in[i] : 0u);
+  }
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int r = 0; r < SORT_ROUNDS; ++r) {
+    const bool valid = sort_index(blockIdx.x, wave, r, lane) < n;
+    const uint32_t d = (key[r] >> shift) & digit_mask;
+    unsigned long long same = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const unsigned long long bal = __ballot(bit);
+      same &= bit ? bal : ~bal;
+    }
+    const int before = cnt[wave][d];
+    const int lower = __popcll(same & lt_mask);
+    rank[r] = before + lower;
+    __builtin_amdgcn_wave_barrier();
+    if (valid && lower == 0) cnt[wave][d] = before + __popcll(same);
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  {
+    int run = 0;
+#pragma unroll
+    for (int w = 0; w < SORT_WAVES; ++w) {
+      const int t = cnt[w][threadIdx.x];
+      cnt[w][threadIdx.x] = run;
+      run += t;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < SORT_ROUNDS; ++r) {
+    if (sort_index(blockIdx.x, wave, r, lane) >= n) break;
+    const uint32_t d = (key[r] >> shift) & digit_mask;
+    const int pos = gbase[d] + cnt[wave][d] + rank[r];
+    keys_out[pos] = key[r];
+    vals_out[pos] = val[r];
+  }
 }
 
 // Runs of equal cell key in the sorted array.  Each run TAIL finds its head: inside
@@ -247,52 +405,102 @@ constexpr int LANES_PER_LEAF = 8;
 constexpr int SUMS_BLOCKS_MAX = 2048;
 
 // ref: voxel_grid_covariance_impl.hpp:236-239 -- per-voxel sum(x) and sum(x x^T) in f64.
-// 8 lanes per leaf gather its points (stable sort => ascending input order) and a fixed
-// 3-step xor tree adds the 8 partial sums: deterministic.
+// A wave owns 8 leaves.  The first LEAF_HEAD points of a leaf are gathered by its own 8 lanes
+// (stable sort => ascending input order) and added by a fixed 3-step xor tree; whatever a
+// crowded leaf holds beyond that is gathered by all 64 lanes of the wave, leaf after leaf, and
+// added by a fixed 6-step tree -- otherwise the most crowded voxel of the map (1000+ points on 8
+// lanes) sets the kernel's duration.  Every association is fixed: the sums are reproducible.
+constexpr int LEAF_HEAD = 64;
+
+struct Moments {
+  double s[3], ss[6];
+};
+
+__device__ __forceinline__ void moments_add(Moments& m, const float4& p, bool live) {
+  const double a = live ? (double)p.x : 0.0, b = live ? (double)p.y : 0.0, c = live ? (double)p.z : 0.0;
+  m.s[0] += a; m.s[1] += b; m.s[2] += c;
+  m.ss[0] += a * a; m.ss[1] += a * b; m.ss[2] += a * c;
+  m.ss[3] += b * b; m.ss[4] += b * c; m.ss[5] += c * c;
+}
+
+template <int WIDTH>
+__device__ __forceinline__ void moments_xor_tree(Moments& m) {
+#pragma unroll
+  for (int off = 1; off < WIDTH; off <<= 1) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) m.s[a] += __shfl_xor(m.s[a], off);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) m.ss[a] += __shfl_xor(m.ss[a], off);
+  }
+}
+
 __global__ void __launch_bounds__(256) k_leaf_sums(const float4* __restrict__ xyz4, const uint32_t* __restrict__ vals,
                                                   const int* __restrict__ nleaf_p,
                                                   const int* __restrict__ leaf_start,
                                                   const int* __restrict__ leaf_cnt, double* __restrict__ sums) {
   const int nleaf = nleaf_p[0];
-  const int sub = threadIdx.x & (LANES_PER_LEAF - 1);
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & (LANES_PER_LEAF - 1);
   const int per_block = 256 / LANES_PER_LEAF;
-  for (int slot = blockIdx.x * per_block + threadIdx.x / LANES_PER_LEAF; slot < nleaf;
-       slot += gridDim.x * per_block) {
-    const int start = leaf_start[slot], cnt = leaf_cnt[slot];
-    double s[3] = {0, 0, 0}, ss[6] = {0, 0, 0, 0, 0, 0};
+  // Wave W takes the leaves W, W + rows, W + 2 rows, ... (rows = ceil(nleaf / 8)): crowded voxels
+  // are neighbours in cell order (a wall, the road), and eight of them in one wave would
+  // serialise.  The loop bound is wave-uniform: all 8 leaves of a wave step together.
+  const int rows = (nleaf + 7) >> 3;
+  for (int row = blockIdx.x * (per_block / 8) + (threadIdx.x >> 6); row < rows; row += gridDim.x * (per_block / 8)) {
+    const int slot = row + (lane >> 3) * rows;
+    const bool have = slot < nleaf;
+    const int start = have ? leaf_start[slot] : 0, cnt = have ? leaf_cnt[slot] : 0;
+    Moments m{};
     // four gathers in flight per lane (index load -> point load is a dependent pair);
     // the adds stay in point order, masked lanes add exact zeros
-    for (int j0 = sub; j0 < cnt; j0 += 4 * LANES_PER_LEAF) {
+    const int head = cnt < LEAF_HEAD ? cnt : LEAF_HEAD;
+    for (int j0 = sub; j0 < head; j0 += 4 * LANES_PER_LEAF) {
       float4 p[4];
       bool live[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int j = j0 + u * LANES_PER_LEAF;
-        live[u] = j < cnt;
+        live[u] = j < head;
         p[u] = xyz4[vals[start + (live[u] ? j : 0)]];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const double a = live[u] ? (double)p[u].x : 0.0, b = live[u] ? (double)p[u].y : 0.0,
-                     c = live[u] ? (double)p[u].z : 0.0;
-        s[0] += a; s[1] += b; s[2] += c;
-        ss[0] += a * a; ss[1] += a * b; ss[2] += a * c;
-        ss[3] += b * b; ss[4] += b * c; ss[5] += c * c;
+      for (int u = 0; u < 4; ++u) moments_add(m, p[u], live[u]);
+    }
+    moments_xor_tree<LANES_PER_LEAF>(m);
+    // crowded leaves: the whole wave gathers the rest
+    unsigned long long crowded = __ballot(cnt > LEAF_HEAD);
+    while (crowded) {
+      const int src = __ffsll((long long)crowded) - 1;  // first lane of that leaf's group
+      crowded &= ~(0xFFull << (src & ~7));
+      const int bstart = __shfl(start, src), bcnt = __shfl(cnt, src);
+      Moments t{};
+      for (int j0 = LEAF_HEAD + lane; j0 < bcnt; j0 += 4 * 64) {
+        float4 p[4];
+        bool live[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = j0 + u * 64;
+          live[u] = j < bcnt;
+          p[u] = xyz4[vals[bstart + (live[u] ? j : LEAF_HEAD)]];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) moments_add(t, p[u], live[u]);
+      }
+      moments_xor_tree<64>(t);
+      if ((lane >> 3) == (src >> 3)) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) m.s[a] += t.s[a];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) m.ss[a] += t.ss[a];
       }
     }
-#pragma unroll
-    for (int off = 1; off < LANES_PER_LEAF; off <<= 1) {
-#pragma unroll
-      for (int a = 0; a < 3; ++a) s[a] += __shfl_xor(s[a], off);
-#pragma unroll
-      for (int a = 0; a < 6; ++a) ss[a] += __shfl_xor(ss[a], off);
-    }
+    if (!have) continue;
     // the 8 lanes hold identical sums; lane k writes word k, lane 0 also word 8
     double* o = sums + (size_t)slot * 9;
-    const double mine = sub == 0 ? s[0] : sub == 1 ? s[1] : sub == 2 ? s[2] : sub == 3 ? ss[0]
-                      : sub == 4 ? ss[1] : sub == 5 ? ss[2] : sub == 6 ? ss[3] : ss[4];
+    const double mine = sub == 0 ? m.s[0] : sub == 1 ? m.s[1] : sub == 2 ? m.s[2] : sub == 3 ? m.ss[0]
+                      : sub == 4 ? m.ss[1] : sub == 5 ? m.ss[2] : sub == 6 ? m.ss[3] : m.ss[4];
     o[sub] = mine;
-    if (sub == 0) o[8] = ss[5];
+    if (sub == 0) o[8] = m.ss[5];
   }
 }
 
@@ -483,34 +691,77 @@ void fold_bounds(const int* rows, int nrows, int out[8]) {
   }
 }
 
+int sort_tiles(size_t n) { return (int)((n + SORT_TILE - 1) / SORT_TILE); }
+
+// scratch of the sort: the bin-major tile histograms + the bin totals
+size_t sort_temp_bytes(size_t n) { return ((size_t)SORT_BINS * sort_tiles(n) + SORT_BINS) * sizeof(int); }
+
+namespace {
+struct SortPlan {
+  int passes;
+  int width[4];
+};
+// ceil(bits / 8) digit passes of near-equal width (23 bits: 8 + 8 + 7)
+SortPlan sort_plan(int end_bit) {
+  SortPlan p{};
+  if (end_bit < 1) end_bit = 1;
+  if (end_bit > 32) end_bit = 32;
+  p.passes = (end_bit + 7) / 8;
+  const int base = end_bit / p.passes, rem = end_bit % p.passes;
+  for (int i = 0; i < p.passes; ++i) p.width[i] = base + (i < rem ? 1 : 0);
+  return p;
+}
+}  // namespace
+
 void launch_cell_keys(const float* x, const float* y, const float* z, size_t n, const GridGeom& g,
-                      uint32_t* keys, uint32_t* vals, float* xyz4, hipStream_t s) {
+                      uint32_t* keys, float* xyz4, int end_bit, void* sort_temp, hipStream_t s) {
   if (n == 0) return;
-  size_t blocks = (n + 255) / 256;
-  hipLaunchKernelGGL(k_cell_keys, dim3((unsigned)blocks), dim3(256), 0, s, x, y, z, n, g, keys, vals,
-                     reinterpret_cast<float4*>(xyz4));
+  const int ntiles = sort_tiles(n);
+  const SortPlan plan = sort_plan(end_bit);
+  hipLaunchKernelGGL(k_cell_keys, dim3((unsigned)ntiles), dim3(SORT_THREADS), 0, s, x, y, z, (int)n, g, keys,
+                     reinterpret_cast<float4*>(xyz4), (1u << plan.width[0]) - 1u, ntiles,
+                     static_cast<int*>(sort_temp));
 }
 
-// rocPRIM's default switches to a merge sort below 1M items (10 merge passes, ~165 us for the
-// 1M-point map); the onesweep LSD radix sort needs ceil(bits/8) passes over the keys only.
-#ifndef NDT_SORT_MERGE_LIMIT
-#define NDT_SORT_MERGE_LIMIT 16384
-#endif
-using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                              rocprim::default_config, NDT_SORT_MERGE_LIMIT>;
-
-size_t sort_temp_bytes(size_t n) {
-  size_t bytes = 0;
-  uint32_t* p = nullptr;
-  (void)rocprim::radix_sort_pairs<SortConfig>(nullptr, bytes, p, p, p, p, n, 0, 32, (hipStream_t)0);
-  return bytes;
+void launch_sort_first_count(const uint32_t* keys, size_t n, int end_bit, void* sort_temp, hipStream_t s) {
+  if (n == 0) return;
+  const int ntiles = sort_tiles(n);
+  const SortPlan plan = sort_plan(end_bit);
+  hipLaunchKernelGGL(k_sort_count, dim3((unsigned)ntiles), dim3(SORT_THREADS), 0, s, keys, (int)n, 0,
+                     (1u << plan.width[0]) - 1u, ntiles, static_cast<int*>(sort_temp));
 }
 
-hipError_t sort_pairs(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
-                      const uint32_t* vals_in, uint32_t* vals_out, size_t n, int end_bit,
-                      hipStream_t s) {
-  return rocprim::radix_sort_pairs<SortConfig>(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out,
-                                               n, 0, (unsigned)end_bit, s);
+// Sorts (keys_a, identity) by the low end_bit bits of the key, stable.  The first digit's tile
+// histograms must already be in `temp` (launch_cell_keys).  The passes ping-pong between the
+// a and b buffers; *result_in_b says where the sorted pairs ended up.
+hipError_t sort_pairs(void* temp, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
+                      size_t n, int end_bit, hipStream_t s, bool* result_in_b) {
+  *result_in_b = false;
+  if (n == 0) return hipSuccess;
+  const int ntiles = sort_tiles(n);
+  int* hist = static_cast<int*>(temp);
+  int* totals = hist + (size_t)SORT_BINS * ntiles;
+  const SortPlan plan = sort_plan(end_bit);
+  uint32_t *kin = keys_a, *kout = keys_b, *vin = vals_a, *vout = vals_b;
+  int shift = 0;
+  for (int p = 0; p < plan.passes; ++p) {
+    const uint32_t mask = (1u << plan.width[p]) - 1u;
+    if (p > 0)
+      hipLaunchKernelGGL(k_sort_count, dim3((unsigned)ntiles), dim3(SORT_THREADS), 0, s, kin, (int)n, shift, mask,
+                         ntiles, hist);
+    hipLaunchKernelGGL(k_sort_scan, dim3(SORT_BINS), dim3(SORT_THREADS), 0, s, hist, ntiles, totals);
+    if (p == 0)
+      hipLaunchKernelGGL(k_sort_scatter<true>, dim3((unsigned)ntiles), dim3(SORT_THREADS), 0, s, kin, vin, (int)n,
+                         shift, mask, ntiles, hist, totals, kout, vout);
+    else
+      hipLaunchKernelGGL(k_sort_scatter<false>, dim3((unsigned)ntiles), dim3(SORT_THREADS), 0, s, kin, vin, (int)n,
+                         shift, mask, ntiles, hist, totals, kout, vout);
+    shift += plan.width[p];
+    uint32_t* t = kin; kin = kout; kout = t;
+    t = vin; vin = vout; vout = t;
+  }
+  *result_in_b = (plan.passes & 1) != 0;
+  return hipGetLastError();
 }
 
 int runs_blocks(size_t n) { return (int)((n + 255) / 256); }

@@ -240,6 +240,37 @@ def test_regularization_and_fixed_step(pkg, O, S):
 
 
 # ---------------------------------------------------------------------------------------
+# the voxel build's hand-written radix sort: bit-exact against a stable argsort
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,bits,kind", [
+    (1, 1, "uniform"), (63, 5, "uniform"), (64, 8, "uniform"), (4096, 8, "uniform"), (4097, 9, "uniform"),
+    (8191, 16, "uniform"), (100000, 17, "uniform"), (1000003, 23, "uniform"), (1000003, 23, "runs"),
+    (300000, 24, "skewed"), (250000, 31, "uniform"), (250000, 32, "uniform"), (70000, 12, "constant"),
+    (500000, 23, "reversed"),
+])
+def test_radix_sort_is_stable_and_exact(pkg, n, bits, kind):
+    rng = np.random.default_rng(n * 131 + bits)
+    hi = (1 << bits) - 1
+    if kind == "uniform":
+        keys = rng.integers(0, hi, n, dtype=np.uint64, endpoint=True)
+    elif kind == "runs":      # scan-order-like: long runs of equal keys, few distinct values (voxel ids)
+        keys = np.repeat(rng.integers(0, hi, n // 40 + 1, dtype=np.uint64), 40)[:n]
+    elif kind == "skewed":    # a handful of heavy cells + a sentinel tail
+        keys = np.where(rng.random(n) < 0.7, rng.integers(0, 16, n), rng.integers(0, hi, n, endpoint=True)).astype(np.uint64)
+        keys[rng.random(n) < 0.05] = hi
+    elif kind == "constant":
+        keys = np.full(n, hi // 3, np.uint64)
+    else:                     # strictly descending
+        keys = (hi - np.arange(n, dtype=np.uint64)) & hi
+    keys = keys.astype(np.uint32)
+    ndt = make_ndt(pkg)
+    ko, vo = ndt.debugSortPairs(keys, bits)
+    perm = np.argsort(keys, kind="stable")
+    assert np.array_equal(vo, perm.astype(np.uint32))
+    assert np.array_equal(ko, keys[perm])
+
+
+# ---------------------------------------------------------------------------------------
 # edge cases (empty, ragged, non-finite, no overlap, input layouts)
 # ---------------------------------------------------------------------------------------
 def test_edge_cases(pkg, O, S):
