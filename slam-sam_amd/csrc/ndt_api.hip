@@ -90,6 +90,10 @@ struct ndt_handle {
   DevBuf<VoxelRecord> rec;
   DevBuf<LeafStats> stats;
   int n_slots = 0, n_valid = 0;
+  // The dense index grid is filled with -1 once per allocation; afterwards only the cells the
+  // previous build published are reset (a 33 MB fill per build otherwise).
+  size_t grid_clean_cap = 0;  // capacity that is -1 everywhere except the dirty leaves' cells
+  int grid_dirty_slots = 0;   // slots of `stats` whose cells may hold an index
   double ms_build = 0;
 
   // source
@@ -203,6 +207,10 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
   h->have_grid = false;
   h->n_tgt = n;
   h->n_slots = h->n_valid = 0;
+  const int dirty_slots = h->grid_dirty_slots;
+  const size_t clean_cap = h->grid_clean_cap;
+  h->grid_clean_cap = 0;  // pessimistic until this build has gone through
+  h->grid_dirty_slots = 0;
   if (n == 0) return fail(h, NDT_ERR_NO_TARGET, "empty target cloud");
   if (n > (size_t)std::numeric_limits<int>::max() / 2) return fail(h, NDT_ERR_INVALID_ARG, "target too large");
   hipStream_t s = h->stream;
@@ -244,7 +252,12 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
 
   const int min_pts = std::max(3, h->prm.min_points_per_voxel);  // ref: voxel_grid_covariance.h:176-184
   const int max_leaves = (int)(n / (size_t)min_pts) + 1;
-  HIP_TRY(h, h->cell2leaf.ensure((size_t)g.ncells));
+  if (clean_cap != 0 && clean_cap == h->cell2leaf.cap && (size_t)g.ncells <= clean_cap) {
+    launch_clear_cells(h->stats.p, dirty_slots, h->cell2leaf.p, h->cell2leaf.cap, s);  // before `stats` can be re-allocated
+  } else {
+    HIP_TRY(h, h->cell2leaf.ensure((size_t)g.ncells));
+    HIP_TRY(h, hipMemsetAsync(h->cell2leaf.p, 0xFF, h->cell2leaf.cap * sizeof(int), s));
+  }
   HIP_TRY(h, h->keys.ensure(n));
   HIP_TRY(h, h->xyz4.ensure(4 * n));
   HIP_TRY(h, h->vals.ensure(n));
@@ -261,7 +274,6 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
   const size_t tmp_bytes = sort_temp_bytes(n);
   HIP_TRY(h, h->sort_tmp.ensure(tmp_bytes));
 
-  HIP_TRY(h, hipMemsetAsync(h->cell2leaf.p, 0xFF, (size_t)g.ncells * sizeof(int), s));
   HIP_TRY(h, hipMemsetAsync(h->nleaf.p, 0, 2 * sizeof(int), s));
   int bits = 1;
   while (bits < 32 && (1ull << bits) <= (unsigned long long)g.ncells) ++bits;  // sentinel = ncells
@@ -284,6 +296,8 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
   h->ms_build = ms;
   h->tm.ms_last_build = ms;
   h->n_slots = h->small.h[8];
+  h->grid_clean_cap = h->cell2leaf.cap;
+  h->grid_dirty_slots = h->n_slots;
   h->n_valid = h->small.h[9];
   h->have_grid = true;
   return NDT_OK;

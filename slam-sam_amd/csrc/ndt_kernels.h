@@ -33,6 +33,9 @@ void launch_find_runs(const uint32_t* keys_sorted, size_t n, int ncells, int min
                       int* block_counts, int* block_offsets, int* leaf_start, int* leaf_cnt,
                       hipStream_t s);
 
+// resets cell2leaf[stats[slot].cell] = -1 for slot < n_slots (the cells the last build published)
+void launch_clear_cells(const LeafStats* stats, int n_slots, int* cell2leaf, size_t cap, hipStream_t s);
+
 struct FinalizeParams {
   double eig_ratio;
   int cov_mode;  // 0 svn, 1 pcl (recalled)

@@ -506,7 +506,7 @@ __global__ void __launch_bounds__(256) k_leaf_sums(const float4* __restrict__ xy
 
 // ref: voxel_grid_covariance_impl.hpp:265-343 -- one thread per leaf: mean, covariance,
 // eigen-decomposition, eigenvalue inflation, inverse, validity checks.
-__global__ void __launch_bounds__(256) k_leaf_finalize(const uint32_t* __restrict__ keys,
+__global__ void __launch_bounds__(64) k_leaf_finalize(const uint32_t* __restrict__ keys,
                                                       int* __restrict__ nleaf_p,
                                                       const int* __restrict__ leaf_start,
                                                       const int* __restrict__ leaf_cnt,
@@ -621,6 +621,14 @@ __global__ void __launch_bounds__(256) k_leaf_finalize(const uint32_t* __restric
     cell2leaf[cell] = slot;
     atomicAdd(nleaf_p + 1, 1);  // leaves that passed every check
   }
+}
+
+__global__ void __launch_bounds__(256) k_clear_cells(const LeafStats* __restrict__ stats, int n_slots,
+                                                    int* __restrict__ cell2leaf, size_t cap) {
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= n_slots) return;
+  const int cell = stats[slot].cell;
+  if (cell >= 0 && (size_t)cell < cap) cell2leaf[cell] = -1;
 }
 
 // Sliding-window target assembly: one archived body-frame scan moved into the
@@ -778,6 +786,12 @@ void launch_find_runs(const uint32_t* keys_sorted, size_t n, int ncells, int min
                      block_counts, block_offsets, leaf_start, leaf_cnt);
 }
 
+void launch_clear_cells(const LeafStats* stats, int n_slots, int* cell2leaf, size_t cap, hipStream_t s) {
+  if (n_slots <= 0) return;
+  hipLaunchKernelGGL(k_clear_cells, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, s, stats, n_slots, cell2leaf,
+                     cap);
+}
+
 void launch_finalize_leaves(const float* xyz4,
                             const uint32_t* keys_sorted, const uint32_t* vals_sorted,
                             int* d_nleaf, const int* leaf_start, const int* leaf_cnt,
@@ -789,7 +803,7 @@ void launch_finalize_leaves(const float* xyz4,
   hipLaunchKernelGGL(k_leaf_sums, dim3((unsigned)blocks), dim3(256), 0, s,
                      reinterpret_cast<const float4*>(xyz4), vals_sorted, d_nleaf,
                      leaf_start, leaf_cnt, sums);
-  hipLaunchKernelGGL(k_leaf_finalize, dim3((unsigned)((max_leaves + 255) / 256)), dim3(256), 0, s,
+  hipLaunchKernelGGL(k_leaf_finalize, dim3((unsigned)((max_leaves + 63) / 64)), dim3(64), 0, s,
                      keys_sorted, d_nleaf, leaf_start, leaf_cnt, sums, fp, rec, stats, cell2leaf);
 }
 
