@@ -240,11 +240,59 @@ def main():
         })
         out["config"]["reduce"] = reduce_mode
 
+    def scaling_probe():
+        """Not part of `value`: the same engine on a source five times larger (the map's own
+        1 M points seen from the scan pose, 2 cm noise), sharded like the headline workload --
+        SURVEY 8e asks where sharding pays, and at 200 k points an evaluation is latency-bound."""
+        if os.environ.get("NDT_BENCH_PROBE", "1") != "1":
+            return None
+        gt = cfg["gt"].astype(np.float64)
+        Rinv, tinv = gt[:3, :3].T, -gt[:3, :3].T @ gt[:3, 3]
+        big = cfg["target"].astype(np.float64) @ Rinv.T + tinv
+        big = (big + np.random.default_rng(5).normal(0.0, 0.02, big.shape)).astype(np.float32)
+        nb = len(big)
+        bb, cb = pkg.shard_range(nb, rank, world)
+        bsrc = [torch.from_numpy(np.ascontiguousarray(big[bb:bb + cb, a])).to(dev) for a in range(3)]
+        torch.cuda.synchronize()
+        if world > 1:
+            ndt.setGlobalSourceSize(nb)
+
+        def pstep():
+            ndt.setInputTargetDevice(tgt[0].data_ptr(), tgt[1].data_ptr(), tgt[2].data_ptr(), len(cfg["target"]))
+            ndt.setInputSourceDevice(bsrc[0].data_ptr(), bsrc[1].data_ptr(), bsrc[2].data_ptr(), cb)
+            ndt.align(cfg["guess"])
+            return ndt.getResult()
+
+        pstep()
+        fence()
+        t0 = time.perf_counter()
+        k, iters, evals = 5, 0, 0
+        for _ in range(k):
+            r = pstep()
+            iters += r["iterations"]
+            evals += r["n_evaluations"]
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device="cpu" if rehearsal else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+            ndt.setGlobalSourceSize(n_src_total)
+        err_t, err_r = S.pose_error(r["T"], cfg["gt"])
+        ndt.setInputSourceDevice(src[0].data_ptr(), src[1].data_ptr(), src[2].data_ptr(), c)
+        return {"workload": "same map, %d-point source (the map seen from the scan pose, 2 cm noise), sharded /%d" % (nb, world),
+                "n_source": nb, "value": iters / el, "unit": "iterations/s", "ms_per_step": 1e3 * el / k,
+                "iterations_per_align": iters / k, "evaluations_per_align": evals / k,
+                "final_error_vs_ground_truth": {"m": err_t, "rad": err_r}}
+
     variants = {}
     if world == 1:
         res = timed_region()
         out = instrumented(res, "none", variants)
         headline(out, res, "none")
+        probe = scaling_probe()
+        if out is not None and probe is not None:
+            out["scaling_probe"] = probe
         if out is not None and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, params, args.cpu_seconds)
     else:
@@ -281,6 +329,10 @@ def main():
                     out = instrumented(res, mode, variants)
                     if rank != 0:
                         out = {"config": {"reduce_variants": variants}}  # placeholder: only rank 0 prints
+                    probe = scaling_probe()
+                    if probe is not None:
+                        probe["reduce"] = mode
+                        out["scaling_probe"] = probe
                 if best is None or res["elapsed"] < best["elapsed"]:
                     best = res
                     headline(out, res, mode)
