@@ -49,15 +49,25 @@ __global__ void __launch_bounds__(256) k_bounds(const float* __restrict__ x, con
   int mn[3] = {INT_MAX, INT_MAX, INT_MAX};
   int mx[3] = {INT_MIN, INT_MIN, INT_MIN};
   int cnt = 0;
-  size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    float a = x[i], b = y[i], c = z[i];
-    if (!finite3(a, b, c)) continue;
-    int ea = encode_ordered(a), eb = encode_ordered(b), ec = encode_ordered(c);
-    mn[0] = min(mn[0], ea); mx[0] = max(mx[0], ea);
-    mn[1] = min(mn[1], eb); mx[1] = max(mx[1], eb);
-    mn[2] = min(mn[2], ec); mx[2] = max(mx[2], ec);
-    ++cnt;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  // four strided points per trip: 12 loads in flight instead of 3 (the pass is latency-bound)
+  for (size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 4 * stride) {
+    float a[4], b[4], c[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const size_t i = i0 + u * stride;
+      const size_t j = i < n ? i : i0;
+      a[u] = x[j]; b[u] = y[j]; c[u] = z[j];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (i0 + u * stride >= n || !finite3(a[u], b[u], c[u])) continue;
+      int ea = encode_ordered(a[u]), eb = encode_ordered(b[u]), ec = encode_ordered(c[u]);
+      mn[0] = min(mn[0], ea); mx[0] = max(mx[0], ea);
+      mn[1] = min(mn[1], eb); mx[1] = max(mx[1], eb);
+      mn[2] = min(mn[2], ec); mx[2] = max(mx[2], ec);
+      ++cnt;
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -273,67 +283,126 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_scatter(const uint32_t* _
   }
 }
 
-// Runs of equal cell key in the sorted array.  Each run TAIL finds its head: inside
-// the wave through a ballot of head flags (no memory traffic), and only for runs
-// that began in an earlier wave by a backward gallop + bisection.  Runs with at
-// least min_pts points become leaves (ref: voxel_grid_covariance_impl.hpp:270-273).
-// Leaf slots are handed out by a count / scan / emit triple instead of a global
-// atomic counter (one contended address served ~90 adds/us and cost 0.1 ms): slots
-// come out in ascending cell order, identically on every run.
+// Runs of equal cell key in the sorted array.  A thread owns RUN_KEYS consecutive keys (two
+// 16-byte loads), a block one 2048-key tile.  Every run TAIL needs its head: the thread's
+// own last head, else the last head of a lower lane (wave max-scan), else of a lower wave
+// (LDS), and only for a run that began before the tile a backward gallop + bisection in
+// global memory.  Runs with at least min_pts points become leaves
+// (ref: voxel_grid_covariance_impl.hpp:270-273).  Leaf slots are handed out by a
+// count / scan / emit triple instead of a global atomic counter (one contended address
+// served ~90 adds/us and cost 0.1 ms): slots come out in ascending cell order, identically
+// on every run.
+constexpr int RUN_KEYS = 8;
+constexpr int RUN_TILE = 256 * RUN_KEYS;
+
 template <bool EMIT>
 __global__ void __launch_bounds__(256) k_runs(const uint32_t* __restrict__ keys, int n, int ncells, int min_pts,
                                              int* __restrict__ block_counts,
                                              const int* __restrict__ block_offsets,
                                              int* __restrict__ leaf_start, int* __restrict__ leaf_cnt) {
+  __shared__ int wave_head[4];
   __shared__ int wave_total[4];
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s0 = blockIdx.x * RUN_TILE + threadIdx.x * RUN_KEYS;
   const uint32_t sentinel = 0xFFFFFFFFu;
-  const uint32_t key = s < n ? keys[s] : sentinel;
-  uint32_t prev = __shfl_up(key, 1), next = __shfl_down(key, 1);
-  if (lane == 0) prev = s > 0 && s - 1 < n ? keys[s - 1] : sentinel;
-  if (lane == 63) next = s + 1 < n ? keys[s + 1] : sentinel;
-  const bool valid = s < n && key < (uint32_t)ncells;
-  const bool head = valid && (s == 0 || prev != key);
-  const bool tail = valid && (s == n - 1 || next != key);
-  const unsigned long long heads = __ballot(head);
-  int start = s;
-  if (tail) {
-    const unsigned long long below = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
-    if (below) {
-      start = s - (lane - (63 - __clzll((long long)below)));
-    } else {
-      // the run began before this wave: keys[wave_base] == key; walk back
-      int hi = s - lane;  // known to hold key
-      int step = 1, lo;
-      for (;;) {
-        int nx = hi - step;
-        if (nx < 0) { lo = -1; break; }
-        if (keys[nx] != key) { lo = nx; break; }
-        hi = nx;
-        step <<= 1;
+  uint32_t k[RUN_KEYS];
+  if (s0 + RUN_KEYS <= n) {  // keys is 16-byte aligned and s0 a multiple of 8
+    const uint4 a = *reinterpret_cast<const uint4*>(keys + s0);
+    const uint4 b = *reinterpret_cast<const uint4*>(keys + s0 + 4);
+    k[0] = a.x; k[1] = a.y; k[2] = a.z; k[3] = a.w; k[4] = b.x; k[5] = b.y; k[6] = b.z; k[7] = b.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < RUN_KEYS; ++j) k[j] = s0 + j < n ? keys[s0 + j] : sentinel;
+  }
+  uint32_t prev = __shfl_up(k[RUN_KEYS - 1], 1), next = __shfl_down(k[0], 1);
+  if (lane == 0) prev = s0 > 0 && s0 - 1 < n ? keys[s0 - 1] : sentinel;
+  if (lane == 63) next = s0 + RUN_KEYS < n ? keys[s0 + RUN_KEYS] : sentinel;
+
+  // last head position inside this thread (-1: none), and the same for everything before it
+  int own_head = -1;
+#pragma unroll
+  for (int j = 0; j < RUN_KEYS; ++j) {
+    const uint32_t before = j == 0 ? prev : k[j - 1];
+    const bool valid = s0 + j < n && k[j] < (uint32_t)ncells;
+    if (valid && (s0 + j == 0 || before != k[j])) own_head = s0 + j;
+  }
+  int incl = own_head;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off);
+    if (lane >= off) incl = max(incl, t);
+  }
+  int head_before = __shfl_up(incl, 1);
+  if (lane == 0) head_before = -1;
+  if (lane == 63) wave_head[wave] = incl;
+  __syncthreads();
+  for (int w = 0; w < wave; ++w) head_before = max(head_before, wave_head[w]);
+
+  // walk the keys again: count (and emit) the leaf tails
+  int cur_head = head_before;
+  int nleaf = 0;
+  int starts[RUN_KEYS], counts[RUN_KEYS];
+#pragma unroll
+  for (int j = 0; j < RUN_KEYS; ++j) {
+    const int s = s0 + j;
+    const uint32_t before = j == 0 ? prev : k[j - 1];
+    const uint32_t after = j == RUN_KEYS - 1 ? next : k[j + 1];
+    const bool valid = s < n && k[j] < (uint32_t)ncells;
+    if (valid && (s == 0 || before != k[j])) cur_head = s;
+    const bool tail = valid && (s == n - 1 || after != k[j]);
+    counts[j] = 0;
+    starts[j] = 0;
+    if (tail) {
+      int start = cur_head;
+      if (start < 0) {
+        // the run began before this tile: keys[tile_base] == key; walk back
+        int hi = blockIdx.x * RUN_TILE;  // known to hold key
+        int step = 1, lo;
+        for (;;) {
+          int nx = hi - step;
+          if (nx < 0) { lo = -1; break; }
+          if (keys[nx] != k[j]) { lo = nx; break; }
+          hi = nx;
+          step <<= 1;
+        }
+        while (hi - lo > 1) {  // keys[lo] != key (or lo == -1), keys[hi] == key
+          int mid = (lo + hi) >> 1;
+          if (keys[mid] == k[j]) hi = mid; else lo = mid;
+        }
+        start = hi;
       }
-      while (hi - lo > 1) {  // keys[lo] != key (or lo == -1), keys[hi] == key
-        int mid = (lo + hi) >> 1;
-        if (keys[mid] == key) hi = mid; else lo = mid;
+      const int cnt = s - start + 1;
+      if (cnt >= min_pts) {
+        starts[j] = start;
+        counts[j] = cnt;
+        ++nleaf;
       }
-      start = hi;
     }
   }
-  const int cnt = s - start + 1;
-  const bool leaf = tail && cnt >= min_pts;
-  const unsigned long long leaves = __ballot(leaf);
-  if (lane == 0) wave_total[wave] = __popcll(leaves);
+  // slots in position order: lower lanes, lower waves, lower blocks first
+  int lincl = nleaf;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(lincl, off);
+    if (lane >= off) lincl += t;
+  }
+  if (lane == 63) wave_total[wave] = lincl;
   __syncthreads();
   if (!EMIT) {
     if (threadIdx.x == 0) block_counts[blockIdx.x] = wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3];
     return;
   }
-  if (!leaf) return;
-  int slot = block_offsets[blockIdx.x] + __popcll(leaves & ((1ull << lane) - 1ull));
+  if (nleaf == 0) return;
+  int slot = block_offsets[blockIdx.x] + lincl - nleaf;
   for (int w = 0; w < wave; ++w) slot += wave_total[w];
-  leaf_start[slot] = start;
-  leaf_cnt[slot] = cnt;
+#pragma unroll
+  for (int j = 0; j < RUN_KEYS; ++j) {
+    if (counts[j] > 0) {
+      leaf_start[slot] = starts[j];
+      leaf_cnt[slot] = counts[j];
+      ++slot;
+    }
+  }
 }
 
 // exclusive scan of the per-block leaf counts (one block; a few thousand values)
@@ -772,7 +841,7 @@ hipError_t sort_pairs(void* temp, uint32_t* keys_a, uint32_t* keys_b, uint32_t* 
   return hipGetLastError();
 }
 
-int runs_blocks(size_t n) { return (int)((n + 255) / 256); }
+int runs_blocks(size_t n) { return (int)((n + RUN_TILE - 1) / RUN_TILE); }
 
 void launch_find_runs(const uint32_t* keys_sorted, size_t n, int ncells, int min_pts, int* d_nleaf,
                       int* block_counts, int* block_offsets, int* leaf_start, int* leaf_cnt,
