@@ -201,6 +201,14 @@ int ndt_eval_derivatives(ndt_handle* h, const double* poses6, const float* trans
 /* unpack one evaluation into score, g[6], H[36] (row-major) */
 void ndt_unpack_eval(const double* eval_words, double* score, double* g6, double* H36);
 
+/* Covariance of a registration result for the pose graph: cov = -(H + eps I)^-1 of
+ * ndt_result.hessian (ref: run/pipeline.cpp:594-596, eps = 1e-6 there), and with
+ * gtsam_order != 0 the block permutation of RegisterCallback::reorderCovarianceForGTSAM
+ * (ref: src/registercallback.cpp:170-186: rotation block first, cross blocks left where
+ * they are).  Host-only, no handle.  NDT_ERR_INVALID_ARG when H + eps I is singular or
+ * not finite. */
+int ndt_result_covariance(const double hessian36[36], double eps, int gtsam_order, double cov36[36]);
+
 /* output cloud of align(): source transformed by T (device-side), packed xyz */
 int ndt_transform_source(ndt_handle* h, const float T_colmajor[16], float* out_xyz, size_t cap_points);
 

@@ -63,6 +63,11 @@ struct NdtResult {
   float nearest_voxel_transformation_likelihood = 0.0f;
   int iteration_num = 0;
   std::array<double, 36> hessian{};  // row-major 6x6 of the maximised score
+  // -(hessian + eps I)^-1 in the block order the drivers hand to GTSAM
+  // (ref: run/pipeline.cpp:594-603, src/registercallback.cpp:170-186); false if singular
+  bool covarianceForGtsam(std::array<double, 36>& cov, double eps = 1e-6, bool gtsam_order = true) const {
+    return ndt_result_covariance(hessian.data(), eps, gtsam_order ? 1 : 0, cov.data()) == NDT_OK;
+  }
 #if NDT_HIP_WITH_PCL
   Eigen::Matrix4f poseEigen() const { return Eigen::Map<const Eigen::Matrix4f>(pose.data()); }
   Eigen::Matrix<double, 6, 6> hessianEigen() const {

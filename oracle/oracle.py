@@ -238,6 +238,23 @@ def matrix_to_pose(T):
     return p
 
 
+def covariance_for_gtsam(hessian, eps=1e-6, gtsam_order=True):
+    """NumPy restatement of what the drivers do with NdtResult::hessian: lidarCov =
+    -(hessian + 1e-6 I)^-1 (ref: run/pipeline.cpp:594-596), then
+    RegisterCallback::reorderCovarianceForGTSAM (ref: src/registercallback.cpp:170-186):
+    C_tt -> bottom-right, C_rr -> top-left, the two cross blocks copied in place."""
+    H = np.asarray(hessian, dtype=np.float64).reshape(6, 6)
+    cov = -np.linalg.inv(H + eps * np.eye(6))
+    if not gtsam_order:
+        return cov
+    out = np.empty((6, 6))
+    out[3:, 3:] = cov[:3, :3]
+    out[:3, :3] = cov[3:, 3:]
+    out[:3, 3:] = cov[:3, 3:]
+    out[3:, :3] = cov[3:, :3]
+    return out
+
+
 def two_plane_fixture():
     """(source Nx3 f32, target Nx3 f32, gt 4x4 f64, guess 4x4 f64) of the reference test."""
     n = 35912

@@ -113,6 +113,7 @@ ABI_SYMBOLS = [
     "ndt_set_global_source_size", "ndt_enable_kernel_timing", "ndt_get_timing",
     "ndt_svn_default_params", "ndt_svn_sample_particles", "ndt_svn_align",
     "ndt_keyframe_put", "ndt_keyframe_erase", "ndt_keyframe_count", "ndt_set_target_from_keyframes",
+    "ndt_result_covariance",
 ]
 
 _lib = None
@@ -174,6 +175,7 @@ def lib():
         L.ndt_svn_default_params.argtypes = [C.POINTER(SvnParams)]
         L.ndt_svn_sample_particles.argtypes = [dp, C.c_int, C.c_uint64, dp]
         L.ndt_svn_align.argtypes = [vp, C.POINTER(SvnParams), dp, dp, C.POINTER(SvnResult)]
+        L.ndt_result_covariance.argtypes = [dp, C.c_double, C.c_int, dp]
         L.ndt_debug_sort_pairs.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, vp]  # test seam, not in the header
         _lib = L
     return _lib
@@ -459,6 +461,17 @@ def comm_unique_id():
     if rc != 0:
         raise NdtError(rc, "ndt_comm_unique_id")
     return buf.raw
+
+
+def result_covariance(hessian, eps=1e-6, gtsam_order=True):
+    """-(H + eps I)^-1 of an align() Hessian, optionally in the block order the drivers hand to
+    GTSAM (ref: run/pipeline.cpp:594-603, src/registercallback.cpp:170-186)."""
+    H = np.ascontiguousarray(hessian, dtype=np.float64).reshape(36)
+    out = np.zeros(36)
+    rc = lib().ndt_result_covariance(_dp(H), float(eps), 1 if gtsam_order else 0, _dp(out))
+    if rc != 0:
+        raise NdtError(rc, "Hessian + eps I is singular or not finite")
+    return out.reshape(6, 6)
 
 
 def newton_align(params, n_source_total, guess, eval_fn, regularization_pose=None):

@@ -886,6 +886,11 @@ int ndt_comm_destroy(ndt_handle* h) {
   return NDT_OK;
 }
 
+int ndt_result_covariance(const double hessian36[36], double eps, int gtsam_order, double cov36[36]) {
+  if (!hessian36 || !cov36 || !std::isfinite(eps)) return NDT_ERR_INVALID_ARG;
+  return result_covariance(hessian36, eps, gtsam_order != 0, cov36) ? NDT_OK : NDT_ERR_INVALID_ARG;
+}
+
 // diagnostic builds only (-DNDT_STAMPS): 8 x 100 MHz stamps per block of the last launch
 int ndt_debug_read_stamps(unsigned long long* out, int nblocks) { return derivs_read_stamps(out, nblocks); }
 

@@ -13,6 +13,7 @@
 
 #include <chrono>
 #include <cmath>
+#include <utility>
 #include <cstring>
 #include <limits>
 
@@ -413,6 +414,47 @@ int newton_align(const ndt_params& prm, int64_t n_source_total, const float gues
   out->n_points_with_neighbors = (int64_t)sv.cur_.n_with;
   out->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return 0;
+}
+
+bool result_covariance(const double H[36], double eps, bool gtsam_order, double cov[36]) {
+  // Gauss-Jordan with partial pivoting on [H + eps I | -I]
+  double a[6][12];
+  for (int i = 0; i < 6; ++i) {
+    for (int j = 0; j < 6; ++j) {
+      a[i][j] = H[6 * i + j] + (i == j ? eps : 0.0);
+      a[i][6 + j] = i == j ? -1.0 : 0.0;
+      if (!std::isfinite(a[i][j])) return false;
+    }
+  }
+  for (int c = 0; c < 6; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < 6; ++r)
+      if (std::fabs(a[r][c]) > std::fabs(a[piv][c])) piv = r;
+    if (a[piv][c] == 0.0) return false;
+    if (piv != c)
+      for (int j = 0; j < 12; ++j) std::swap(a[piv][j], a[c][j]);
+    const double inv = 1.0 / a[c][c];
+    for (int j = 0; j < 12; ++j) a[c][j] *= inv;
+    for (int r = 0; r < 6; ++r) {
+      if (r == c) continue;
+      const double f = a[r][c];
+      if (f == 0.0) continue;
+      for (int j = 0; j < 12; ++j) a[r][j] -= f * a[c][j];
+    }
+  }
+  for (int i = 0; i < 6; ++i) {
+    for (int j = 0; j < 6; ++j) {
+      const double v = a[i][6 + j];
+      if (!std::isfinite(v)) return false;
+      // GTSAM order: C_rr top-left, C_tt bottom-right, the cross blocks stay where they are
+      // (exactly what reorderCovarianceForGTSAM does -- it does not transpose them)
+      const int bi = i / 3, bj = j / 3;
+      const int oi = gtsam_order && bi == bj ? (i + 3) % 6 : i;
+      const int oj = gtsam_order && bi == bj ? (j + 3) % 6 : j;
+      cov[6 * oi + oj] = v;
+    }
+  }
+  return true;
 }
 
 }  // namespace ndt

@@ -41,4 +41,9 @@ using EvalFn = std::function<int(const double*, const float*, bool, Eval*)>;
 int newton_align(const ndt_params& prm, int64_t n_source_total, const float guess[16],
                  const EvalFn& fn, ndt_result* out, bool hessian_in_trials = false);
 
+// cov = -(H + eps I)^-1, optionally with the [rotation, translation] block order of a GTSAM
+// Pose3 noise model (ref: run/pipeline.cpp:594-596, src/registercallback.cpp:170-186).
+// Returns false when H + eps I is singular or not finite.
+bool result_covariance(const double H[36], double eps, bool gtsam_order, double cov[36]);
+
 }  // namespace ndt

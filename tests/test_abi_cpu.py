@@ -149,3 +149,24 @@ def test_pack_unpack_roundtrip(pkg):
     assert u["score"] == 1.5 and u["n_with_neighbors"] == 7 and u["n_pairs"] == 11
     np.testing.assert_array_equal(u["gradient"], g)
     np.testing.assert_array_equal(u["hessian"], H)
+
+
+def test_result_covariance_matches_driver_recipe(pkg, O):
+    """-(H + 1e-6 I)^-1 and the GTSAM block order (ref: run/pipeline.cpp:594-603,
+    src/registercallback.cpp:170-186) -- host-only entry point, runs without a GPU."""
+    rng = np.random.default_rng(3)
+    for scale in (1.0, 1e4, 1e-3):
+        A = rng.normal(size=(6, 6))
+        H = -(A @ A.T + 0.1 * np.eye(6)) * scale        # Hessian of a maximised score: negative definite
+        H[:3, 3:] *= 3.0                                 # make the cross blocks visibly asymmetric in size
+        H[3:, :3] = H[:3, 3:].T
+        for order in (True, False):
+            got = pkg.result_covariance(H, 1e-6, order)
+            want = O.covariance_for_gtsam(H, 1e-6, order)
+            np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-12 * np.abs(want).max())
+    # the cross blocks are copied, not transposed (reference behaviour)
+    H = -np.diag([1.0, 2, 3, 4, 5, 6]); H[0, 4] = H[4, 0] = 0.5
+    c = pkg.result_covariance(H, 0.0, False); g = pkg.result_covariance(H, 0.0, True)
+    assert np.array_equal(g[:3, 3:], c[:3, 3:]) and np.array_equal(g[:3, :3], c[3:, 3:]) and np.array_equal(g[3:, 3:], c[:3, :3])
+    with pytest.raises(pkg.NdtError):
+        pkg.result_covariance(np.zeros((6, 6)), 0.0)
