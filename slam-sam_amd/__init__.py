@@ -19,7 +19,8 @@ import numpy as np
 from . import synth  # noqa: F401  (seeded synthetic cloud generators)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libndt_hip.so")
+# NDT_HIP_LIB: tuning aid (A/B of two builds in one GPU session); the default is the in-tree build
+LIB_PATH = os.environ.get("NDT_HIP_LIB") or os.path.join(_HERE, "libndt_hip.so")
 
 EVAL_WORDS = 32
 # pclomp::NeighborSearchMethod order

@@ -4,6 +4,7 @@
 // owns every device allocation.  There is no CPU path: without a device every
 // compute call fails with NDT_ERR_NO_DEVICE.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -105,8 +106,7 @@ struct ndt_handle {
   PinBuf<float> stage;               // host->device upload staging
   PinBuf<double> result;             // evaluation results (K * EV_WORDS)
   PinBuf<int> small;                 // bounds / counters read-back
-  PinBuf<unsigned long long> flag;   // completion word the derivative kernel writes
-  unsigned long long eval_seq = 0;
+  PinBuf<unsigned long long> flag;   // 32 result slots {seq, value} the single-pose kernel writes for the host
   DevBuf<double> partials, dres;
   DevBuf<unsigned int> counters;     // per-pose tickets of the in-kernel final reduction
   size_t counters_zeroed = 0;
@@ -336,18 +336,38 @@ int ready_for_eval(ndt_handle* h) {
   return NDT_OK;
 }
 
-// Wait for the derivative kernel's completion word in pinned host memory.  Polling it
-// sees the result ~4 us sooner than hipStreamSynchronize (measured: 7.7 vs 11.5 us launch +
-// completion round trip on MI355X); falls back to the stream if the word never arrives.
-int wait_flag(ndt_handle* h, unsigned long long seq) {
-  volatile unsigned long long* f = h->flag.h;
+// Launch sequence numbers tag every partial / result slot the derivative kernel writes; they
+// must never repeat within the process (a freed partials buffer of one handle can become
+// another's), hence one counter for all handles, starting at 1 (zeroed memory never matches).
+std::atomic<unsigned long long> g_launch_seq{1};
+
+// (re)allocates the partial rows; fresh memory is zeroed so that no slot carries a stale tag
+int ensure_partials(ndt_handle* h, size_t words) {
+  if (words <= h->partials.cap) return NDT_OK;
+  HIP_TRY(h, h->partials.ensure(words));
+  HIP_TRY(h, hipMemsetAsync(h->partials.p, 0, h->partials.cap * sizeof(double), h->stream));
+  return NDT_OK;
+}
+
+// Wait for the derivative kernel's 32 result slots {seq, value} in pinned host memory (each
+// slot is one 16-byte device store).  Polling them sees the result ~4 us sooner than
+// hipStreamSynchronize (measured: 7.7 vs 11.5 us launch + completion round trip on MI355X);
+// falls back to the stream if they never arrive.
+bool slots_complete(const volatile unsigned long long* slots, unsigned long long seq) {
+  for (int v = EV_WORDS - 1; v >= 0; --v)
+    if (__atomic_load_n(slots + 2 * v, __ATOMIC_ACQUIRE) != seq) return false;
+  return true;
+}
+
+int wait_slots(ndt_handle* h, unsigned long long seq) {
+  const volatile unsigned long long* f = h->flag.h;
   const auto t0 = std::chrono::steady_clock::now();
   unsigned int spins = 0;
-  while (__atomic_load_n(f, __ATOMIC_ACQUIRE) != seq) {
+  while (!slots_complete(f, seq)) {
     if ((++spins & 0xFFFF) == 0 &&
         std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
       HIP_TRY(h, hipStreamSynchronize(h->stream));
-      if (__atomic_load_n(f, __ATOMIC_ACQUIRE) != seq) {
+      if (!slots_complete(f, seq)) {
         h->counters_zeroed = 0;  // the ticket words may be stale: re-zero them before the next launch
         return fail(h, NDT_ERR_HIP, "derivative kernel finished without publishing its result");
       }
@@ -363,11 +383,14 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
   PoseConsts pc;
   fill_pose_consts(p, T, &pc);
   const EvalConsts ec = make_eval_consts(h, need_h);
-  HIP_TRY(h, h->partials.ensure(derivs_partials_words(h->n_src, 1)));
+  {
+    int rc = ensure_partials(h, derivs_partials_words(h->n_src, 1));
+    if (rc) return rc;
+  }
   HIP_TRY(h, h->result.ensure(EV_WORDS));
   if (!h->flag.h) {
-    HIP_TRY(h, h->flag.ensure(8));
-    h->flag.h[0] = 0;
+    HIP_TRY(h, h->flag.ensure(2 * EV_WORDS));
+    std::memset(h->flag.h, 0, 2 * EV_WORDS * sizeof(unsigned long long));
   }
   const bool dev_out = h->red.wants_device_buffer();
   if (dev_out) HIP_TRY(h, h->dres.ensure(EV_WORDS));
@@ -377,7 +400,7 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
   }
   double* d_out = dev_out ? h->dres.p : h->result.d;
   const bool spin = !dev_out && !h->timing;
-  const unsigned long long seq = ++h->eval_seq;
+  const unsigned long long seq = g_launch_seq.fetch_add(1, std::memory_order_relaxed);
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, s));
   launch_derivatives(h->sx.p, h->sy.p, h->sz.p, h->n_src, h->geom, h->cell2leaf.p, h->rec.p, pc,
                      nullptr, 1, ec, h->partials.p, h->counters.p, d_out, s, spin ? h->flag.d : nullptr, seq);
@@ -389,7 +412,7 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
     HIP_TRY(h, hipMemcpyAsync(h->result.h, h->dres.p, EV_WORDS * sizeof(double), hipMemcpyDeviceToHost, s));
   }
   if (spin) {
-    int rc = wait_flag(h, seq);
+    int rc = wait_slots(h, seq);
     if (rc) return rc;
   } else {
     HIP_TRY(h, hipStreamSynchronize(s));
@@ -403,7 +426,11 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
     h->tm.n_timed_evals++;
   }
   double words[EV_WORDS];
-  std::memcpy(words, h->result.h, sizeof(words));
+  if (spin) {
+    for (int v = 0; v < EV_WORDS; ++v) std::memcpy(&words[v], &h->flag.h[2 * v + 1], sizeof(double));
+  } else {
+    std::memcpy(words, h->result.h, sizeof(words));
+  }
   if (!dev_out) {
     int rc = h->red.allreduce_host(words, EV_WORDS, &h->err);
     if (rc) return rc;
@@ -705,7 +732,8 @@ int ndt_eval_derivatives(ndt_handle* h, const double* poses6, const float* trans
     fill_pose_consts(poses6 + 6 * (size_t)k, Tk, &h->hposes.h[k]);
   }
   const EvalConsts ec = make_eval_consts(h, compute_hessian != 0);
-  HIP_TRY(h, h->partials.ensure(derivs_partials_words(h->n_src, K)));
+  rc = ensure_partials(h, derivs_partials_words(h->n_src, K));
+  if (rc) return rc;
   HIP_TRY(h, h->result.ensure((size_t)K * EV_WORDS));
   HIP_TRY(h, h->dres.ensure((size_t)K * EV_WORDS));
   rc = ensure_counters(h, (size_t)K * derivs_counters_per_pose());
@@ -713,7 +741,8 @@ int ndt_eval_derivatives(ndt_handle* h, const double* poses6, const float* trans
   HIP_TRY(h, hipMemcpyAsync(h->dposes.p, h->hposes.h, (size_t)K * sizeof(PoseConsts), hipMemcpyHostToDevice, s));
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, s));
   launch_derivatives(h->sx.p, h->sy.p, h->sz.p, h->n_src, h->geom, h->cell2leaf.p, h->rec.p,
-                     h->hposes.h[0], h->dposes.p, K, ec, h->partials.p, h->counters.p, h->dres.p, s);
+                     h->hposes.h[0], h->dposes.p, K, ec, h->partials.p, h->counters.p, h->dres.p, s, nullptr,
+                     g_launch_seq.fetch_add(1, std::memory_order_relaxed));
   HIP_TRY(h, hipGetLastError());
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, s));
   if (h->red.wants_device_buffer()) {

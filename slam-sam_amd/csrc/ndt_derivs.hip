@@ -15,7 +15,7 @@
 //   * 31 f64 accumulators per thread; recursive-halving reduce-scatter across the
 //     wave (32 cross-lane moves, not 32*6), LDS across the 4 waves, one partial row
 //     per block; the last-arriving block adds the rows in fixed order inside the
-//     same launch (agent-scope release/acquire), so results are bit-reproducible.
+//     same launch (tagged 16-byte slots, no fences), so results are bit-reproducible.
 // No MFMA: 3x3 / 6x6 work is not a dense contraction.
 // Compiled with -ffp-contract=off; the transform and the index arithmetic must
 // round exactly as written to classify points into the same voxels as the ref.
@@ -365,65 +365,106 @@ constexpr int COUNTERS_PER_POSE = 1 + NGROUPS;
 constexpr int MAX_WAVES = MAX_BLOCK / 64;
 constexpr int MAX_COLS = MAX_BLOCK / 32;  // row-parallel lanes of the final sum
 
-// Cross-block hand-off without cache-wide fences (cdna_hip_programming.md Guideline 16,
-// "every store sc1 ... every load sc1" form): rows are written with agent-scope
-// write-through stores, the storing wave drains them (vmcnt(0)) and only then takes
-// its ticket; the block that draws the last ticket reads the rows with agent-scope
-// loads (which bypass the per-CU L1).  A release/acquire fence pair here costs a full
-// L2 write-back + L1 invalidate per block and dominated the kernel.
-__device__ __forceinline__ void store_agent(double* p, double v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// Cross-block hand-off without fences and without waiting for a store to be acknowledged
+// (cdna_hip_programming.md Guideline 16, "every store sc1 ... every load sc1" form, taken one
+// step further).  A partial row is 32 slots of 16 bytes {tag, value}: the tag is the launch's
+// process-wide unique sequence number, and a slot is written by ONE 16-byte store of one lane
+// and read by ONE 16-byte load of one lane, so a reader sees a slot either entirely old (a tag
+// of an earlier launch) or entirely new.  The storing wave takes its ticket right after issuing
+// the stores; the block that draws the last ticket therefore knows every row has been
+// *issued*, reads the rows with agent-scope loads and simply re-reads a slot whose tag is not
+// this launch's yet.  The finished evaluation goes to pinned host memory in the same slot
+// format and the host polls the 32 tags.  Against the previous protocol (drain the row stores,
+// then ticket; drain the result stores, then a flag word) this removes two store-acknowledge
+// round trips (~1 us each) from every evaluation's critical path; a release/acquire fence pair
+// per block had cost 2.5x the kernel.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int ROW_WORDS = 2 * EV_WORDS;   // 32 x {tag, value}
+constexpr int AUX_AGENT = 16;             // sc1
+constexpr int AUX_SYSTEM = 17;            // sc0 sc1
+constexpr int SUM_BATCH = 20;             // rows per thread and memory round trip (80 VGPRs in flight; 25 would spill)
+constexpr unsigned int SPIN_LIMIT = 1u << 22;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t slots_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xFFFFFFFFu, 0x00020000);
 }
-__device__ __forceinline__ double load_agent(const double* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ void store_slot(__amdgpu_buffer_rsrc_t r, unsigned int byte_off, unsigned long long tag,
+                                           double v, bool system_scope) {
+  const unsigned long long vb = (unsigned long long)__double_as_longlong(v);
+  u32x4 d;
+  d.x = (unsigned int)tag; d.y = (unsigned int)(tag >> 32); d.z = (unsigned int)vb; d.w = (unsigned int)(vb >> 32);
+  if (system_scope) __builtin_amdgcn_raw_buffer_store_b128(d, r, byte_off, 0, AUX_SYSTEM);
+  else __builtin_amdgcn_raw_buffer_store_b128(d, r, byte_off, 0, AUX_AGENT);
 }
 
-// wave 0, lane 0, after wave 0 stored the block's row: drain, take a ticket.
+// wave 0, lane 0, right after wave 0 issued the block's row stores
 __device__ __forceinline__ int ticket_is_last(unsigned int* counter, unsigned int expected) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const unsigned int t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return (t == expected - 1u) ? 1 : 0;
 }
 
-// Fixed-order sum of rows [first, end): thread (c = tid>>5, v = tid&31) takes word v of
-// rows first+c, first+c+ncols, ... (ncols = blockDim/32); 32 loads are issued before the
-// first add so one memory round trip covers 32*ncols rows.  The column sums are then added in order.
-__device__ __forceinline__ void sum_rows(const double* __restrict__ rows, int first, int end,
-                                         double (*lds_c)[EV_WORDS], double* __restrict__ dst, bool dst_agent) {
+// Fixed-order sum of the tagged rows [first, end) of `rows` (byte offsets from its base):
+// thread (c = tid>>5, v = tid&31) takes slot v of rows first+c, first+c+ncols, ... (ncols =
+// blockDim/32); SUM_BATCH loads are issued before the first add so one memory round trip covers
+// SUM_BATCH*ncols rows.  The column sums are then added in order and the result is written to
+// dst as tagged slots (group rows, or the host's result buffer) or as 32 plain doubles.
+__device__ __forceinline__ void sum_rows(__amdgpu_buffer_rsrc_t rows, unsigned int rows_off, int first, int end,
+                                         unsigned long long seq, double (*lds_c)[EV_WORDS],
+                                         __amdgpu_buffer_rsrc_t dst, unsigned int dst_off, bool dst_system,
+                                         double* plain_dst) {
   const int v = threadIdx.x & 31, c = threadIdx.x >> 5;
   const int ncols = (int)blockDim.x >> 5;
+  const unsigned int tag_lo = (unsigned int)seq, tag_hi = (unsigned int)(seq >> 32);
   double s = 0.0;
-  for (int b0 = first + c; b0 < end; b0 += 32 * ncols) {
-    double t[32];
+  for (int b0 = first + c; b0 < end; b0 += SUM_BATCH * ncols) {
+    u32x4 t[SUM_BATCH];
+    unsigned int tries = 0;
+    for (;;) {
+      asm volatile("" ::: "memory");  // the loads below must be re-issued on every trip
+      bool ok = true;
 #pragma unroll
-    for (int k = 0; k < 32; ++k) {
-      const int b = b0 + k * ncols;
-      t[k] = b < end ? load_agent(rows + (size_t)b * EV_WORDS + v) : 0.0;
+      for (int k = 0; k < SUM_BATCH; ++k) {
+        const int b = b0 + k * ncols;
+        if (b < end) {
+          t[k] = __builtin_amdgcn_raw_buffer_load_b128(rows, rows_off + ((unsigned int)b * EV_WORDS + v) * 16u, 0, AUX_AGENT);
+        } else {
+          t[k].x = tag_lo; t[k].y = tag_hi; t[k].z = 0u; t[k].w = 0u;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < SUM_BATCH; ++k) ok = ok && t[k].x == tag_lo && t[k].y == tag_hi;
+      if (ok) break;
+      if (++tries > SPIN_LIMIT) {  // cannot happen (every row was issued before its ticket); exit anyway
+        s = __longlong_as_double(0x7ff8000000000000ll);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
     }
 #pragma unroll
-    for (int k = 0; k < 32; ++k) s += t[k];
+    for (int k = 0; k < SUM_BATCH; ++k)
+      s += __longlong_as_double((long long)(((unsigned long long)t[k].w << 32) | t[k].z));
   }
   lds_c[c][v] = s;
   __syncthreads();
   if (threadIdx.x < EV_WORDS) {
     double t = 0.0;
     for (int k = 0; k < ncols; ++k) t += lds_c[k][threadIdx.x];
-    if (dst_agent) store_agent(dst + threadIdx.x, t); else dst[threadIdx.x] = t;
+    if (plain_dst) plain_dst[threadIdx.x] = t;
+    else store_slot(dst, dst_off + threadIdx.x * 16u, seq, t, dst_system);
   }
 }
 
-// Block sum of the 32 accumulator words -> one row per block; the rows are added INSIDE
+// Block sum of the 32 accumulator words -> one tagged row per block; the rows are added INSIDE
 // the same launch: the block that draws the last ticket adds all rows in fixed order and
 // writes the evaluation (grids above 2048 rows go through 32 group rows first).  No second
 // kernel, no float atomics, and the summation tree does not depend on arrival order:
-// results are bit-reproducible.  If `flag` is set the finished evaluation is followed by
-// a system-scope store of `seq` so the host can spin on pinned memory instead of waiting
-// for the stream.
+// results are bit-reproducible.  host_slots != nullptr: the evaluation is written as 32 tagged
+// slots into pinned host memory for the host to poll; otherwise 32 plain doubles go to `out`.
 __device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], double* __restrict__ rows,
                                                     double* __restrict__ group_rows,
                                                     unsigned int* __restrict__ counters,
                                                     double* __restrict__ out,
-                                                    unsigned long long* flag, unsigned long long seq,
+                                                    unsigned long long* host_slots, unsigned long long seq,
                                                     int single_level_max) {
   __shared__ double lds_w[MAX_WAVES][EV_WORDS];
   __shared__ double lds_c[MAX_COLS][EV_WORDS];
@@ -432,22 +473,17 @@ __device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], double
   wave_reduce_scatter32(acc, lane);
   if ((lane & 1) == 0) lds_w[wave][lane >> 1] = acc[0];
   __syncthreads();
+  const __amdgpu_buffer_rsrc_t rrows = slots_rsrc(rows);
   if (threadIdx.x < EV_WORDS) {
     double sum = 0.0;
     const int nwaves = (int)blockDim.x >> 6;
     for (int wv = 0; wv < nwaves; ++wv) sum += lds_w[wv][threadIdx.x];
-    store_agent(rows + (size_t)blockIdx.x * EV_WORDS + threadIdx.x, sum);
+    store_slot(rrows, ((unsigned int)blockIdx.x * EV_WORDS + threadIdx.x) * 16u, seq, sum, false);
   }
   NDT_STAMP(4);
-#if defined(NDT_ABL) && NDT_ABL == 4  // ablation: no tickets, block 0 publishes
-  if (blockIdx.x == 0 && flag != nullptr && threadIdx.x == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  return;
-#endif
   const int nb = (int)gridDim.x;
   int ngroups = 1;
+  const __amdgpu_buffer_rsrc_t rgroups = slots_rsrc(group_rows);
   if (nb > single_level_max) {
     const int gsize = (nb + NGROUPS - 1) / NGROUPS;  // blocks per group
     ngroups = (nb + gsize - 1) / gsize;              // <= NGROUPS
@@ -457,24 +493,20 @@ __device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], double
     if (threadIdx.x == 0) s_last = ticket_is_last(counters + 1 + grp, (unsigned int)(end - first));
     __syncthreads();
     if (!s_last) return;
-    sum_rows(rows, first, end, lds_c, group_rows + (size_t)grp * EV_WORDS, true);
+    sum_rows(rrows, 0u, first, end, seq, lds_c, rgroups, (unsigned int)grp * EV_WORDS * 16u, false, nullptr);
     __syncthreads();
-    rows = group_rows;
   }
-  const int nrows = nb > single_level_max ? ngroups : nb;
+  const bool two_level = nb > single_level_max;
+  const int nrows = two_level ? ngroups : nb;
   if (threadIdx.x == 0) s_last = ticket_is_last(counters, (unsigned int)nrows);
   NDT_STAMP(5);
   __syncthreads();
   if (!s_last) return;
-  sum_rows(rows, 0, nrows, lds_c, out, false);
+  sum_rows(two_level ? rgroups : rrows, 0u, 0, nrows, seq, lds_c, slots_rsrc(host_slots), 0u, true,
+           host_slots ? nullptr : out);
   NDT_STAMP(6);
   if (threadIdx.x <= ngroups)  // leave the tickets at zero for the next launch
     __hip_atomic_store(counters + threadIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (flag != nullptr && threadIdx.x == 0) {
-    // `out` was stored by wave 0 (threads < 32): drain, then publish to the host
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
   NDT_STAMP(7);
 }
 
@@ -547,8 +579,8 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
   expand_point<MODE>(acc, a, x, y, z, tab);
 #endif
   NDT_STAMP(3);
-  double* base = partials + (size_t)blockIdx.y * (gridDim.x + NGROUPS) * EV_WORDS;
-  block_reduce_finish(acc, base + (size_t)NGROUPS * EV_WORDS, base, counters + blockIdx.y * COUNTERS_PER_POSE,
+  double* base = partials + (size_t)blockIdx.y * (gridDim.x + NGROUPS) * ROW_WORDS;
+  block_reduce_finish(acc, base + (size_t)NGROUPS * ROW_WORDS, base, counters + blockIdx.y * COUNTERS_PER_POSE,
                       out + (size_t)blockIdx.y * EV_WORDS, BATCH ? nullptr : flag, seq, ec.single_level_max);
 }
 
@@ -566,7 +598,7 @@ __global__ void __launch_bounds__(256) k_transform(const float* __restrict__ sx,
 }  // namespace
 
 size_t derivs_partials_words(size_t n_src, int K) {
-  return (size_t)K * ((size_t)derivs_grid_blocks(n_src) + NGROUPS) * EV_WORDS;
+  return (size_t)K * ((size_t)derivs_grid_blocks(n_src, K) + NGROUPS) * ROW_WORDS;
 }
 int derivs_counters_per_pose() { return COUNTERS_PER_POSE; }
 
@@ -585,19 +617,24 @@ int derivs_read_stamps(unsigned long long* out, int nblocks) {
 // Threads per block.  512 (8 waves) measured best on MI355X from 50k to 4M points: with
 // 126 VGPRs two such blocks fill a CU (4 waves/SIMD); smaller blocks multiply the partial
 // rows of the in-kernel final sum, larger ones make every wave wait on wider barriers
-// (sweep 128..832 in profiles/r01_block_sweep.txt).  NDT_DERIV_BLOCK overrides it for tuning.
-int derivs_block_threads(size_t n_src) {
-  (void)n_src;
+// (sweep 128..832 in profiles/r01_block_sweep.txt).  One exception, single-pose launches of
+// 164k..262k points (the 200k-point scan of the headline workload): 1024-thread blocks still
+// put at most one block on every CU (same 4 waves/SIMD on the busiest) and leave <= 256 rows,
+// which the final sum reads in ONE round trip (a 512-thread final block covers 16 x SUM_BATCH =
+// 320 rows per trip): 23.4 vs 24.4 us per evaluation.  NDT_DERIV_BLOCK overrides it for tuning.
+int derivs_block_threads(size_t n_src, int K) {
   static const int forced = [] {
     const char* e = getenv("NDT_DERIV_BLOCK");  // multiple of 64, 64..1024
     int v = e ? atoi(e) : 0;
     return (v >= 64 && v <= MAX_BLOCK && v % 64 == 0) ? v : 0;
   }();
-  return forced ? forced : 512;
+  if (forced) return forced;
+  if (K == 1 && n_src > (size_t)512 * 16 * SUM_BATCH && n_src <= (size_t)1024 * 256) return 1024;
+  return 512;
 }
 
-int derivs_grid_blocks(size_t n_src) {
-  const size_t bt = (size_t)derivs_block_threads(n_src);
+int derivs_grid_blocks(size_t n_src, int K) {
+  const size_t bt = (size_t)derivs_block_threads(n_src, K);
   size_t blocks = (n_src + bt - 1) / bt;  // one point per thread
   if (blocks < 1) blocks = 1;
   return (int)blocks;
@@ -609,8 +646,8 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
                         const EvalConsts& ec, double* d_partials, unsigned int* d_counters,
                         double* d_out, hipStream_t s, unsigned long long* d_flag,
                         unsigned long long seq) {
-  const int blocks = derivs_grid_blocks(n_src);
-  const int threads = derivs_block_threads(n_src);
+  const int blocks = derivs_grid_blocks(n_src, d_poses ? K : 1);
+  const int threads = derivs_block_threads(n_src, d_poses ? K : 1);
   const int mode = !ec.need_hessian ? 0 : (ec.gauss_newton ? 2 : 1);
   EvalConsts ecl = ec;
   static const int slm = [] {
@@ -631,8 +668,8 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
   } while (0)
   unsigned long long* const no_flag = nullptr;
   if (d_poses) {
-    if (ec.kdtree) NDT_LAUNCH_MODE(true, true, K, no_flag, 0ull);
-    else NDT_LAUNCH_MODE(true, false, K, no_flag, 0ull);
+    if (ec.kdtree) NDT_LAUNCH_MODE(true, true, K, no_flag, seq);
+    else NDT_LAUNCH_MODE(true, false, K, no_flag, seq);
   } else {
     if (ec.kdtree) NDT_LAUNCH_MODE(false, true, 1, d_flag, seq);
     else NDT_LAUNCH_MODE(false, false, 1, d_flag, seq);

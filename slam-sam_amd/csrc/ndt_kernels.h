@@ -53,23 +53,25 @@ void launch_transform_append(const float* x, const float* y, const float* z, siz
                              hipStream_t s);
 
 // ---- derivative evaluation (ndt_derivs.hip) ---------------------------------
-int derivs_grid_blocks(size_t n_src);
-int derivs_block_threads(size_t n_src);
+int derivs_grid_blocks(size_t n_src, int K);
+int derivs_block_threads(size_t n_src, int K);
 size_t derivs_partials_words(size_t n_src, int K);  // doubles needed in d_partials
 int derivs_counters_per_pose();
 int derivs_read_stamps(unsigned long long* out, int nblocks);  // diagnostic builds (-DNDT_STAMPS) only                     // ticket words per pose in d_counters
-// d_partials: derivs_partials_words() doubles; d_counters: K * derivs_counters_per_pose()
-// zero-initialised ticket words (left at zero again by every launch); d_out: K * EV_WORDS doubles (device
-// memory or device-mapped pinned host memory).  If d_poses is null the single pose
-// `pose` is passed as a kernel argument.  One launch: the last block to finish adds
-// the per-block rows in fixed order.  d_flag (single-pose path only, device-mapped pinned
-// host memory) receives `seq` after d_out has been written, for host-side spinning.
+// d_partials: derivs_partials_words() doubles, ZEROED when allocated (rows of tagged slots);
+// d_counters: K * derivs_counters_per_pose() zero-initialised ticket words (left at zero again
+// by every launch).  `seq`: a sequence number no earlier launch IN THIS PROCESS has used (it
+// tags every partial slot).  If d_poses is null the single pose `pose` is passed as a kernel
+// argument.  One launch: the last block to finish adds the per-block rows in fixed order.
+// Result: d_host_slots == nullptr -> K * EV_WORDS plain doubles in d_out (device memory);
+// d_host_slots != nullptr (single-pose path only, device-mapped pinned host memory, 2 * EV_WORDS
+// words) -> 32 slots {seq, value} for the host to poll, d_out unused.
 void launch_derivatives(const float* sx, const float* sy, const float* sz, size_t n_src,
                         const GridGeom& g, const int* cell2leaf, const VoxelRecord* rec,
                         const PoseConsts& pose, const PoseConsts* d_poses, int K,
                         const EvalConsts& ec, double* d_partials, unsigned int* d_counters,
-                        double* d_out, hipStream_t s, unsigned long long* d_flag = nullptr,
-                        unsigned long long seq = 0);
+                        double* d_out, hipStream_t s, unsigned long long* d_host_slots,
+                        unsigned long long seq);
 
 void launch_transform(const float* sx, const float* sy, const float* sz, size_t n,
                       const PoseConsts& pose, float* out_xyz, hipStream_t s);
