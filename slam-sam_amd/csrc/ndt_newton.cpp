@@ -13,6 +13,8 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <utility>
 #include <cstring>
 #include <limits>
@@ -179,6 +181,47 @@ namespace {
 // eigen-decomposition H = Q L Q^T (two-sided Jacobi); for a symmetric matrix
 // this is the SVD pseudo-inverse the reference obtains from
 // Eigen::JacobiSVD(H).solve(b), with the same rank threshold 6*eps*|l|max.
+// Fast path, taken in the regular case of a comfortably negative-definite H (the Hessian of a
+// maximised score near its optimum): Cholesky of -H, 0.1 us instead of the 2-3 us of the
+// eigen-decomposition -- which sits on the critical path of every Newton iteration, between
+// one evaluation's result and the next launch.  With pivots within 1e-10 of each other no
+// singular value is anywhere near the pseudo-inverse's rank threshold, so both routes return
+// H^-1 b up to rounding; anything else (indefinite, ill-conditioned, non-finite) takes the
+// eigen-decomposition below.
+bool solve_negdef6(const double A[6][6], const double b[6], double x[6]) {
+  double L[6][6];
+  double dmin = std::numeric_limits<double>::infinity(), dmax = 0.0;
+  for (int j = 0; j < 6; ++j) {
+    double d = -A[j][j];
+    for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+    if (!(d > 0.0) || !std::isfinite(d)) return false;
+    dmin = std::fmin(dmin, d);
+    dmax = std::fmax(dmax, d);
+    const double l = std::sqrt(d), inv = 1.0 / l;
+    L[j][j] = l;
+    for (int i = j + 1; i < 6; ++i) {
+      double v = -A[i][j];
+      for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
+      L[i][j] = v * inv;
+    }
+  }
+  if (!(dmin > 1e-10 * dmax)) return false;
+  double y[6];
+  for (int i = 0; i < 6; ++i) {  // L y = -b
+    double v = -b[i];
+    for (int k = 0; k < i; ++k) v -= L[i][k] * y[k];
+    y[i] = v / L[i][i];
+  }
+  for (int i = 5; i >= 0; --i) {  // L^T x = y
+    double v = y[i];
+    for (int k = i + 1; k < 6; ++k) v -= L[k][i] * x[k];
+    x[i] = v / L[i][i];
+  }
+  for (int i = 0; i < 6; ++i)
+    if (!std::isfinite(x[i])) return false;
+  return true;
+}
+
 void solve_sym6(const double Hin[36], const double b[6], double x[6]) {
   double A[6][6], Q[6][6];
   for (int i = 0; i < 6; ++i)
@@ -186,6 +229,7 @@ void solve_sym6(const double Hin[36], const double b[6], double x[6]) {
       A[i][j] = 0.5 * (Hin[6 * i + j] + Hin[6 * j + i]);
       Q[i][j] = (i == j) ? 1.0 : 0.0;
     }
+  if (solve_negdef6(A, b, x)) return;
   for (int sweep = 0; sweep < 100; ++sweep) {
     double off = 0, dg = 0;
     for (int i = 0; i < 6; ++i)
