@@ -21,6 +21,7 @@
 // round exactly as written to classify points into the same voxels as the ref.
 #include "ndt_kernels.h"
 
+#include <cstddef>
 #include <cstdlib>
 
 namespace ndt {
@@ -81,7 +82,9 @@ __device__ __forceinline__ void pair_update(PairAcc& a, const VoxelRecord& r, fl
   double f = ec.d1 * ec.d2 * e;
   const bool dok = ok && fabs(f) >= 1e-15;
   f = dok ? f : 0.0;
-  if (!ok) { v0 = 0.0; v1 = 0.0; v2 = 0.0; }  // keeps a NaN/Inf v out of the sums
+  // v is finite whenever it gets here: the caller replaces a non-finite transformed point by
+  // the origin (it has no neighbours, so every f is 0) and stored records are finite, so
+  // f * v is an exact zero for a masked pair without zeroing v itself
   a.w[0] += f * v0; a.w[1] += f * v1; a.w[2] += f * v2;
   if (MODE != 0) {
     a.S[0] += f * r.icov[0]; a.S[1] += f * r.icov[1]; a.S[2] += f * r.icov[2];
@@ -192,19 +195,42 @@ __device__ __forceinline__ void point_pairs(PairAcc& a, float x, float y, float 
   float yt = P.R[3] * x + (P.R[4] * y + (P.R[5] * z + P.t[1]));
   float zt = P.R[6] * x + (P.R[7] * y + (P.R[8] * z + P.t[2]));
   const bool finite = isfinite(xt) && isfinite(yt) && isfinite(zt);  // ref :573: such points are skipped
+  if (!finite) { xt = 0.0f; yt = 0.0f; zt = 0.0f; }  // keeps NaN / Inf out of the (masked) pair arithmetic
 
-  // ref: voxel_grid_covariance_impl.hpp:560-600 -- neighbours are found by
-  // offsetting the POINT by +-leaf in f32 and re-classifying it.
+  // ref: voxel_grid_covariance_impl.hpp:560-600 -- neighbours are found by offsetting the
+  // POINT by +-leaf in f32 and re-classifying it (probe_cell).  The seven classifications share
+  // their per-axis pieces: a probe differs from the centre in one coordinate only, so only that
+  // axis' bounds test, floor and index are recomputed -- same f32 operations on the same
+  // operands as seven independent probe_cell() calls, a third of the instructions.
   const float w = g.leaf;
+  const float cx[3] = {xt, xt + w, xt - w}, cy[3] = {yt, yt + w, yt - w}, cz[3] = {zt, zt + w, zt - w};
+  bool inx[3], iny[3], inz[3];
+  unsigned int ix[3], iy[3], iz[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    inx[k] = cx[k] >= g.lo[0] && cx[k] < g.hi[0];
+    iny[k] = cy[k] >= g.lo[1] && cy[k] < g.hi[1];
+    inz[k] = cz[k] >= g.lo[2] && cz[k] < g.hi[2];
+    // (out-of-range coordinates convert to saturated garbage that the bounds flags mask;
+    // unsigned arithmetic so that garbage may wrap)
+    ix[k] = (unsigned int)(int)(floorf(cx[k] * g.inv_leaf) - (float)g.min_b[0]);
+    iy[k] = (unsigned int)(int)(floorf(cy[k] * g.inv_leaf) - (float)g.min_b[1]) * (unsigned int)g.mul1;
+    iz[k] = (unsigned int)(int)(floorf(cz[k] * g.inv_leaf) - (float)g.min_b[2]) * (unsigned int)g.mul2;
+  }
   int cell[7];
-  cell[0] = probe_cell(xt, yt, zt, g);
+  {
+    const int idx0 = (int)(ix[0] + iy[0] + iz[0]);
+    cell[0] = (inx[0] && iny[0] && inz[0] && idx0 >= 0 && idx0 < g.ncells) ? idx0 : -1;
+  }
   if (ec.direct7) {
-    cell[1] = probe_cell(xt + w, yt, zt, g);
-    cell[2] = probe_cell(xt - w, yt, zt, g);
-    cell[3] = probe_cell(xt, yt + w, zt, g);
-    cell[4] = probe_cell(xt, yt - w, zt, g);
-    cell[5] = probe_cell(xt, yt, zt + w, g);
-    cell[6] = probe_cell(xt, yt, zt - w, g);
+#pragma unroll
+    for (int k = 1; k < 3; ++k) {
+      const int ax = (int)(ix[k] + iy[0] + iz[0]), ay = (int)(ix[0] + iy[k] + iz[0]), az = (int)(ix[0] + iy[0] + iz[k]);
+      // an idx outside [0, ncells) can never be a stored key of the reference's hash map: a miss
+      cell[k] = (inx[k] && iny[0] && inz[0] && ax >= 0 && ax < g.ncells) ? ax : -1;
+      cell[2 + k] = (inx[0] && iny[k] && inz[0] && ay >= 0 && ay < g.ncells) ? ay : -1;
+      cell[4 + k] = (inx[0] && iny[0] && inz[k] && az >= 0 && az < g.ncells) ? az : -1;
+    }
   } else {
 #pragma unroll
     for (int k = 1; k < 7; ++k) cell[k] = -1;
@@ -510,6 +536,30 @@ __device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], double
   NDT_STAMP(7);
 }
 
+// The explicit arguments of k_derivatives as the kernel-argument segment lays them out
+// (natural alignment in declaration order, first argument at offset 0): the single-pose kernel
+// reads its angle tables from the segment as memory.
+struct DerivKernArgs {
+  const float* sx;
+  const float* sy;
+  const float* sz;
+  int n;
+  GridGeom g;
+  const int* cell2leaf;
+  const VoxelRecord* rec;
+  PoseConsts pose;
+  const PoseConsts* poses;
+  EvalConsts ec;
+  double* partials;
+  unsigned int* counters;
+  double* out;
+  unsigned long long* flag;
+  unsigned long long seq;
+};
+constexpr unsigned int KERNARG_TABLES_OFFSET = offsetof(DerivKernArgs, pose) + offsetof(PoseConsts, jang);
+static_assert(offsetof(PoseConsts, hang) == offsetof(PoseConsts, jang) + 24 * sizeof(float) &&
+              offsetof(AngleTables, hang) == 24 * sizeof(float), "jang / hang must be contiguous");
+
 template <bool BATCH, int MODE, bool KD>
 __global__ void __launch_bounds__(MAX_BLOCK)
 k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, int n,
@@ -529,25 +579,26 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
 #endif
   __shared__ AngleTables tab;
   RigidRT rt;
+  // The 69 table words are fetched by 69 lanes as one vector load each -- from the pose array,
+  // or straight out of the kernel-argument segment -- at the very start, and written to LDS
+  // only behind the pair phase: a wave-0 prologue of 69 scalar-to-vector moves and four
+  // serialised s_load waits used to sit in front of every block's first point load.
+  float tab_word = 0.0f;
   if (BATCH) {
     const PoseConsts& pg = poses[blockIdx.y];
 #pragma unroll
     for (int k = 0; k < 9; ++k) rt.R[k] = pg.R[k];
 #pragma unroll
     for (int k = 0; k < 3; ++k) rt.t[k] = pg.t[k];
-    const float* src = pg.jang;  // jang[24] and hang[45] are contiguous
-    float* dst = tab.jang;
-    for (int k = threadIdx.x; k < 69; k += (int)blockDim.x) dst[k] = src[k];
+    if (threadIdx.x < 69) tab_word = pg.jang[threadIdx.x];  // jang[24] and hang[45] are contiguous
   } else {
 #pragma unroll
     for (int k = 0; k < 9; ++k) rt.R[k] = pose_arg.R[k];
 #pragma unroll
     for (int k = 0; k < 3; ++k) rt.t[k] = pose_arg.t[k];
-    if (threadIdx.x == 0) {
-#pragma unroll
-      for (int k = 0; k < 24; ++k) tab.jang[k] = pose_arg.jang[k];
-#pragma unroll
-      for (int k = 0; k < 45; ++k) tab.hang[k] = pose_arg.hang[k];
+    if (threadIdx.x < 69) {
+      const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();  // constant -> generic address space
+      tab_word = reinterpret_cast<const float*>(ka + KERNARG_TABLES_OFFSET)[threadIdx.x];
     }
   }
   // exactly one source point per thread: the 32 accumulator words are only live from the
@@ -568,6 +619,7 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
 #endif
   }
   NDT_STAMP(2);
+  if (threadIdx.x < 69) tab.jang[threadIdx.x] = tab_word;  // runs on into hang[]: the two arrays are contiguous
   __syncthreads();  // angle tables visible
   double acc[EV_WORDS];
 #if defined(NDT_ABL) && NDT_ABL >= 3  // ablation: launch + reduction only
