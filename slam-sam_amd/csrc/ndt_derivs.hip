@@ -30,21 +30,14 @@ namespace {
 
 constexpr int MAX_BLOCK = 1024;  // block size is chosen per launch (derivs_block_threads), <= 16 waves
 
-// ref: voxel_grid_covariance_impl.hpp:46-71 (f32 bounds) +
-// voxel_grid_covariance.h:297-300 (index).  -1 = outside the grid.
-__device__ __forceinline__ int probe_cell(float px, float py, float pz, const GridGeom& g) {
-  bool in = px >= g.lo[0] && px < g.hi[0] && py >= g.lo[1] && py < g.hi[1] && pz >= g.lo[2] &&
-            pz < g.hi[2];
-  if (!in) return -1;
-  int i0 = (int)(floorf(px * g.inv_leaf) - (float)g.min_b[0]);
-  int i1 = (int)(floorf(py * g.inv_leaf) - (float)g.min_b[1]);
-  int i2 = (int)(floorf(pz * g.inv_leaf) - (float)g.min_b[2]);
-  int idx = i0 + i1 * g.mul1 + i2 * g.mul2;
-  // The reference looks idx up in its hash map whatever its value (f32 rounding at
-  // an upper face can alias into the next row); an idx outside [0, ncells) can
-  // never be a stored key there, so it is a miss here too -- same outcome.
-  return (idx >= 0 && idx < g.ncells) ? idx : -1;
-}
+// Classifying a point into a voxel (ref: voxel_grid_covariance_impl.hpp:46-71 for the f32 bounds
+// test, voxel_grid_covariance.h:297-300 for the index):
+//   in   = lo <= p < hi on every axis (f32);   i_a = (int)(floorf(p_a * inv_leaf) - (float)min_b_a);
+//   idx  = i0 + i1 * mul1 + i2 * mul2.
+// The reference looks idx up in its hash map whatever its value (f32 rounding at an upper face
+// can alias into the next row); an idx outside [0, ncells) can never be a stored key there, so
+// it is a miss here too -- same outcome.  point_pairs() evaluates this for the point and its
+// six face-offset copies with the per-axis pieces shared.
 
 struct PairAcc {
   double w[3];
@@ -181,7 +174,8 @@ struct RigidRT {
 };
 
 // Phase 1 of a point: transform, neighbour lookup, pair sums.  Needs only R|t.
-template <int MODE>
+// D7: DIRECT7 (centre + 6 face neighbours); otherwise DIRECT1 (the point's own voxel only).
+template <int MODE, bool D7>
 __device__ __forceinline__ void point_pairs(PairAcc& a, float x, float y, float z, const GridGeom& g,
                                             const int* __restrict__ cell2leaf,
                                             const VoxelRecord* __restrict__ rec, const RigidRT& P,
@@ -198,10 +192,10 @@ __device__ __forceinline__ void point_pairs(PairAcc& a, float x, float y, float 
   if (!finite) { xt = 0.0f; yt = 0.0f; zt = 0.0f; }  // keeps NaN / Inf out of the (masked) pair arithmetic
 
   // ref: voxel_grid_covariance_impl.hpp:560-600 -- neighbours are found by offsetting the
-  // POINT by +-leaf in f32 and re-classifying it (probe_cell).  The seven classifications share
+  // POINT by +-leaf in f32 and re-classifying it (see above).  The seven classifications share
   // their per-axis pieces: a probe differs from the centre in one coordinate only, so only that
   // axis' bounds test, floor and index are recomputed -- same f32 operations on the same
-  // operands as seven independent probe_cell() calls, a third of the instructions.
+  // operands as seven independent classifications, a third of the instructions.
   const float w = g.leaf;
   const float cx[3] = {xt, xt + w, xt - w}, cy[3] = {yt, yt + w, yt - w}, cz[3] = {zt, zt + w, zt - w};
   bool inx[3], iny[3], inz[3];
@@ -222,7 +216,7 @@ __device__ __forceinline__ void point_pairs(PairAcc& a, float x, float y, float 
     const int idx0 = (int)(ix[0] + iy[0] + iz[0]);
     cell[0] = (inx[0] && iny[0] && inz[0] && idx0 >= 0 && idx0 < g.ncells) ? idx0 : -1;
   }
-  if (ec.direct7) {
+  if (D7) {
 #pragma unroll
     for (int k = 1; k < 3; ++k) {
       const int ax = (int)(ix[k] + iy[0] + iz[0]), ay = (int)(ix[0] + iy[k] + iz[0]), az = (int)(ix[0] + iy[0] + iz[k]);
@@ -234,6 +228,12 @@ __device__ __forceinline__ void point_pairs(PairAcc& a, float x, float y, float 
   } else {
 #pragma unroll
     for (int k = 1; k < 7; ++k) cell[k] = -1;
+  }
+  if (!D7) {  // DIRECT1 (ref: getNeighborhoodAtPoint1, voxel_grid_covariance_impl.hpp:604-615)
+    const int slot0 = (finite && cell[0] >= 0) ? cell2leaf[cell[0]] : -1;
+    const VoxelRecord r0 = rec[slot0 >= 0 ? slot0 : 0];
+    pair_update<MODE>(a, r0, xt, yt, zt, ec, slot0 >= 0);
+    return;
   }
   int slot[7];
 #pragma unroll
@@ -285,40 +285,57 @@ __device__ __forceinline__ bool kd_within(const VoxelRecord& r, float xt, float 
 
 // KDTREE neighbourhood: every valid voxel whose centroid lies within one leaf size of the
 // point.  Such a centroid can only be in the 3x3x3 cells around the point's cell, so the
-// kd-tree becomes 27 index probes + a distance test; one z-layer (9 cells) at a time.
+// kd-tree becomes 27 index probes + a distance test.  A point has 3-4 such neighbours out of
+// 27 cells, so the candidates are compacted first: every lane writes the leaves of its
+// occupied cells to its own LDS column (cell order, so the summation order is fixed), and the
+// wave then runs max-over-lanes(count) predicated pair updates instead of 27.
+constexpr int KD_CELLS = 27;
+
 template <int MODE>
 __device__ __forceinline__ void point_pairs_kd(PairAcc& a, float x, float y, float z, const GridGeom& g,
                                                const int* __restrict__ cell2leaf,
                                                const VoxelRecord* __restrict__ rec, const RigidRT& P,
-                                               const EvalConsts& ec) {
+                                               const EvalConsts& ec, int* __restrict__ lds_list, bool active) {
   a.w[0] = a.w[1] = a.w[2] = 0.0;
 #pragma unroll
   for (int k = 0; k < 6; ++k) a.S[k] = 0.0;
   a.score = 0.0; a.best = 0.0; a.npairs = 0;
-  const float xt = P.R[0] * x + (P.R[1] * y + (P.R[2] * z + P.t[0]));
-  const float yt = P.R[3] * x + (P.R[4] * y + (P.R[5] * z + P.t[1]));
-  const float zt = P.R[6] * x + (P.R[7] * y + (P.R[8] * z + P.t[2]));
-  const bool finite = isfinite(xt) && isfinite(yt) && isfinite(zt);
+  float xt = P.R[0] * x + (P.R[1] * y + (P.R[2] * z + P.t[0]));
+  float yt = P.R[3] * x + (P.R[4] * y + (P.R[5] * z + P.t[1]));
+  float zt = P.R[6] * x + (P.R[7] * y + (P.R[8] * z + P.t[2]));
+  const bool finite = active && isfinite(xt) && isfinite(yt) && isfinite(zt);
+  if (!finite) { xt = 0.0f; yt = 0.0f; zt = 0.0f; }
   // the point's own (possibly out-of-box) cell, same f32 arithmetic as the grid build
   const int i0 = finite ? (int)(floorf(xt * g.inv_leaf) - (float)g.min_b[0]) : -4;
   const int i1 = finite ? (int)(floorf(yt * g.inv_leaf) - (float)g.min_b[1]) : -4;
   const int i2 = finite ? (int)(floorf(zt * g.inv_leaf) - (float)g.min_b[2]) : -4;
-  for (int dz = -1; dz <= 1; ++dz) {
-    const int c2 = i2 + dz;
-    const bool zok = c2 >= 0 && c2 < g.div_b[2];
-    int slot[9];
+  int slot[KD_CELLS];
 #pragma unroll
-    for (int n = 0; n < 9; ++n) {
-      const int c0 = i0 + (n % 3) - 1, c1 = i1 + (n / 3) - 1;
-      const bool ok = zok && c0 >= 0 && c0 < g.div_b[0] && c1 >= 0 && c1 < g.div_b[1];
-      slot[n] = ok ? cell2leaf[c0 + c1 * g.mul1 + c2 * g.mul2] : -1;
-    }
+  for (int n = 0; n < KD_CELLS; ++n) {  // all 27 index loads in flight
+    const int c0 = i0 + (n % 3) - 1, c1 = i1 + ((n / 3) % 3) - 1, c2 = i2 + (n / 9) - 1;
+    const bool ok = c0 >= 0 && c0 < g.div_b[0] && c1 >= 0 && c1 < g.div_b[1] && c2 >= 0 && c2 < g.div_b[2];
+    slot[n] = ok ? cell2leaf[c0 + c1 * g.mul1 + c2 * g.mul2] : -1;
+  }
+  // column `threadIdx.x` of lds_list[KD_CELLS][blockDim.x]: conflict-free for a wave
+  const int stride = (int)blockDim.x;
+  int count = 0;
 #pragma unroll
-    for (int n = 0; n < 9; ++n) {
-      const VoxelRecord r = rec[slot[n] >= 0 ? slot[n] : 0];
-      const bool present = slot[n] >= 0 && kd_within(r, xt, yt, zt, ec.kd_radius2);
-      pair_update<MODE>(a, r, xt, yt, zt, ec, present);
+  for (int n = 0; n < KD_CELLS; ++n) {
+    if (slot[n] >= 0) {
+      lds_list[count * stride + (int)threadIdx.x] = slot[n];
+      ++count;
     }
+  }
+  // wave-uniform trip count (the lanes of a wave only read their own column: no barrier needed)
+  int trips = count;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) trips = max(trips, __shfl_xor(trips, off));
+  for (int j = 0; j < trips; ++j) {
+    const bool have = j < count;
+    const int sl = have ? lds_list[j * stride + (int)threadIdx.x] : 0;
+    const VoxelRecord r = rec[sl];
+    const bool present = have && kd_within(r, xt, yt, zt, ec.kd_radius2);
+    pair_update<MODE>(a, r, xt, yt, zt, ec, present);
   }
 }
 
@@ -560,7 +577,8 @@ constexpr unsigned int KERNARG_TABLES_OFFSET = offsetof(DerivKernArgs, pose) + o
 static_assert(offsetof(PoseConsts, hang) == offsetof(PoseConsts, jang) + 24 * sizeof(float) &&
               offsetof(AngleTables, hang) == 24 * sizeof(float), "jang / hang must be contiguous");
 
-template <bool BATCH, int MODE, bool KD>
+// NB: neighbourhood -- 0 DIRECT1, 1 DIRECT7, 2 KDTREE
+template <bool BATCH, int MODE, int NB>
 __global__ void __launch_bounds__(MAX_BLOCK)
 k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, int n,
               GridGeom g, const int* __restrict__ cell2leaf, const VoxelRecord* __restrict__ rec,
@@ -610,12 +628,17 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
 #pragma unroll
   for (int k = 0; k < 6; ++k) a.S[k] = 0.0;
   a.score = 0.0; a.best = 0.0; a.npairs = 0;
-  if (i < n) {
+  if (NB == 2) {
+    // every lane takes part (wave-wide trip count): lanes beyond n run with nothing to add
+    extern __shared__ int lds_kd_list[];  // KD_CELLS x blockDim.x leaf indices
+    if (i < n) { x = sx[i]; y = sy[i]; z = sz[i]; }
+    NDT_STAMP(1);
+    point_pairs_kd<MODE>(a, x, y, z, g, cell2leaf, rec, rt, ec, lds_kd_list, i < n);
+  } else if (i < n) {
     x = sx[i]; y = sy[i]; z = sz[i];
     NDT_STAMP(1);
 #if !(defined(NDT_ABL) && NDT_ABL >= 3)
-    if (KD) point_pairs_kd<MODE>(a, x, y, z, g, cell2leaf, rec, rt, ec);
-    else point_pairs<MODE>(a, x, y, z, g, cell2leaf, rec, rt, ec);
+    point_pairs<MODE, NB == 1>(a, x, y, z, g, cell2leaf, rec, rt, ec);
 #endif
   }
   NDT_STAMP(2);
@@ -708,24 +731,28 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
     return v > 0 ? v : SINGLE_LEVEL_MAX_DEFAULT;
   }();
   ecl.single_level_max = slm;
-#define NDT_LAUNCH(B, M, KD, GY, FLAG, SEQ)                                                         \
-  hipLaunchKernelGGL((k_derivatives<B, M, KD>), dim3(blocks, GY), dim3(threads), 0, s, sx, sy, sz,     \
-                     (int)n_src, g, cell2leaf, rec, pose, d_poses, ecl, d_partials, d_counters, d_out, \
+  const int nb = ec.kdtree ? 2 : (ec.direct7 ? 1 : 0);
+  const size_t dyn_lds = nb == 2 ? (size_t)KD_CELLS * threads * sizeof(int) : 0;
+#define NDT_LAUNCH(B, M, NBH, GY, FLAG, SEQ)                                                              \
+  hipLaunchKernelGGL((k_derivatives<B, M, NBH>), dim3(blocks, GY), dim3(threads), dyn_lds, s, sx, sy, sz,  \
+                     (int)n_src, g, cell2leaf, rec, pose, d_poses, ecl, d_partials, d_counters, d_out,     \
                      FLAG, SEQ)
-#define NDT_LAUNCH_MODE(B, KD, GY, FLAG, SEQ)                \
-  do {                                                        \
-    if (mode == 0) NDT_LAUNCH(B, 0, KD, GY, FLAG, SEQ);       \
-    else if (mode == 1) NDT_LAUNCH(B, 1, KD, GY, FLAG, SEQ);  \
-    else NDT_LAUNCH(B, 2, KD, GY, FLAG, SEQ);                 \
+#define NDT_LAUNCH_MODE(B, NBH, GY, FLAG, SEQ)                 \
+  do {                                                          \
+    if (mode == 0) NDT_LAUNCH(B, 0, NBH, GY, FLAG, SEQ);        \
+    else if (mode == 1) NDT_LAUNCH(B, 1, NBH, GY, FLAG, SEQ);   \
+    else NDT_LAUNCH(B, 2, NBH, GY, FLAG, SEQ);                  \
+  } while (0)
+#define NDT_LAUNCH_NB(B, GY, FLAG, SEQ)                        \
+  do {                                                          \
+    if (nb == 0) NDT_LAUNCH_MODE(B, 0, GY, FLAG, SEQ);          \
+    else if (nb == 1) NDT_LAUNCH_MODE(B, 1, GY, FLAG, SEQ);     \
+    else NDT_LAUNCH_MODE(B, 2, GY, FLAG, SEQ);                  \
   } while (0)
   unsigned long long* const no_flag = nullptr;
-  if (d_poses) {
-    if (ec.kdtree) NDT_LAUNCH_MODE(true, true, K, no_flag, seq);
-    else NDT_LAUNCH_MODE(true, false, K, no_flag, seq);
-  } else {
-    if (ec.kdtree) NDT_LAUNCH_MODE(false, true, 1, d_flag, seq);
-    else NDT_LAUNCH_MODE(false, false, 1, d_flag, seq);
-  }
+  if (d_poses) NDT_LAUNCH_NB(true, K, no_flag, seq);
+  else NDT_LAUNCH_NB(false, 1, d_flag, seq);
+#undef NDT_LAUNCH_NB
 #undef NDT_LAUNCH_MODE
 #undef NDT_LAUNCH
 }

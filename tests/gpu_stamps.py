@@ -11,7 +11,8 @@ L = pkg.lib()
 L.ndt_debug_read_stamps.argtypes = [C.c_void_p, C.c_int]
 for n in (1000, 200000):
     ndt.setInputSource(cfg["source"][:n])
-    nb = (n + 511) // 512
+    bt = int(os.environ.get("NDT_DERIV_BLOCK", "0")) or (1024 if 163840 < n <= 262144 else 512)
+    nb = (n + bt - 1) // bt
     for _ in range(5): ndt.align(cfg["gt"])
     raw = np.zeros(nb * 9, np.uint64)
     got = L.ndt_debug_read_stamps(raw.ctypes.data, nb)
@@ -35,6 +36,7 @@ for n in (1000, 200000):
         print("  distinct CUs used %d; blocks per CU histogram %s" % (len(uniq), dict(zip(*np.unique(cnt, return_counts=True)))))
         per = {k: c for k, c in zip(uniq, cnt)}
         two = np.array([per[k] for k in key]) >= 2
-        print("  pairs-done (us): CUs with 1 block: median %.2f max %.2f | CUs with >=2 blocks: median %.2f max %.2f"
-              % (np.median(rel[~two, 2]), rel[~two, 2].max(), np.median(rel[two, 2]), rel[two, 2].max()))
+        if two.any() and (~two).any():
+            print("  pairs-done (us): CUs with 1 block: median %.2f max %.2f | CUs with >=2 blocks: median %.2f max %.2f"
+                  % (np.median(rel[~two, 2]), rel[~two, 2].max(), np.median(rel[two, 2]), rel[two, 2].max()))
         print("  per-XCC block counts", dict(zip(*np.unique(xcc, return_counts=True))))
