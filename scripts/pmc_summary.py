@@ -4,7 +4,7 @@ root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
 for f in sorted(glob.glob(root + "/*/*/*counter_collection.csv")):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
-        m = re.search(r"(k_[a-z_]+(<\w+>)?|rocprim[^<]*<[^,]*|__amd_rocclr_\w+)", r["Kernel_Name"])
+        m = re.search(r"(k_[a-z_]+(<[^>]*>)?|rocprim[^<]*<[^,]*|__amd_rocclr_\w+)", r["Kernel_Name"])
         name = m.group(1)[-52:] if m else r["Kernel_Name"][:52]
         acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
     print("==", f)

@@ -8,8 +8,10 @@ tag = sys.argv[1] if len(sys.argv) > 1 else ""
 cfg = S.config_c3()
 ndt = pkg.NormalDistributionsTransform(device_id=0, resolution=0.5, step_size=0.1, trans_epsilon=1e-4, max_iterations=35)
 ndt.setInputTarget(cfg["target"])
-for n in (1000, 20000, 200000):
-    ndt.setInputSource(np.ascontiguousarray(cfg["source"][:: max(1, 200000 // n)][:n]))
+big = cfg["target"] @ np.linalg.inv(cfg["gt"])[:3, :3].T.astype(np.float32) + np.linalg.inv(cfg["gt"])[:3, 3].astype(np.float32)
+for n in (1000, 20000, 200000, 500000, 1000000):
+    src = cfg["source"][:: max(1, 200000 // n)][:n] if n <= 200000 else big[:n]
+    ndt.setInputSource(np.ascontiguousarray(src, dtype=np.float32))
     for _ in range(5): ndt.align(cfg["guess"])
     ts, ev = [], 0
     for _ in range(30):
