@@ -182,6 +182,10 @@ int64_t ndt_keyframe_count(const ndt_handle* h);
  * as pcl::transformPointCloud with a double matrix), then the voxel-grid build */
 int ndt_set_target_from_keyframes(ndt_handle* h, const int64_t* ids, const double* poses16,
                                   int n_keyframes);
+/* setInputSource(archive[id]): the scan that was just archived is also the one to register
+ * (ref: run/pipeline.cpp:558 registers pointsBody, :784 archives the same cloud) -- one upload
+ * serves both */
+int ndt_set_source_from_keyframe(ndt_handle* h, int64_t id);
 
 /* setRegularizationPose (ref: run/pipeline_ligo_tc.cpp:531) */
 int ndt_set_regularization_pose(ndt_handle* h, const float pose_colmajor[16]);

@@ -114,7 +114,7 @@ ABI_SYMBOLS = [
     "ndt_set_global_source_size", "ndt_enable_kernel_timing", "ndt_get_timing",
     "ndt_svn_default_params", "ndt_svn_sample_particles", "ndt_svn_align",
     "ndt_keyframe_put", "ndt_keyframe_erase", "ndt_keyframe_count", "ndt_set_target_from_keyframes",
-    "ndt_result_covariance",
+    "ndt_result_covariance", "ndt_set_source_from_keyframe",
 ]
 
 _lib = None
@@ -172,6 +172,7 @@ def lib():
         L.ndt_keyframe_count.restype = C.c_int64
         L.ndt_keyframe_count.argtypes = [vp]
         L.ndt_set_target_from_keyframes.argtypes = [vp, C.POINTER(C.c_int64), dp, C.c_int]
+        L.ndt_set_source_from_keyframe.argtypes = [vp, C.c_int64]
         L.ndt_svn_default_params.restype = None
         L.ndt_svn_default_params.argtypes = [C.POINTER(SvnParams)]
         L.ndt_svn_sample_particles.argtypes = [dp, C.c_int, C.c_uint64, dp]
@@ -342,6 +343,9 @@ class NormalDistributionsTransform:
     def putKeyframe(self, kf_id, cloud):
         a = self._xyz(cloud)
         self._check(lib().ndt_keyframe_put(self._h, int(kf_id), a.ctypes.data, len(a), a.strides[0]))
+
+    def setInputSourceFromKeyframe(self, kf_id):
+        self._check(lib().ndt_set_source_from_keyframe(self._h, int(kf_id)))
 
     def eraseKeyframe(self, kf_id):
         self._check(lib().ndt_keyframe_erase(self._h, int(kf_id)))

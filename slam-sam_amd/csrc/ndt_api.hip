@@ -641,6 +641,14 @@ int ndt_keyframe_put(ndt_handle* h, int64_t id, const float* xyz, size_t n, size
   return NDT_OK;
 }
 
+int ndt_set_source_from_keyframe(ndt_handle* h, int64_t id) {
+  if (!h) return NDT_ERR_INVALID_ARG;
+  auto it = h->keyframes.find(id);
+  if (it == h->keyframes.end()) return fail(h, NDT_ERR_INVALID_ARG, "unknown keyframe id");
+  const ndt_handle::Keyframe& kf = it->second;
+  return ndt_set_source_device(h, kf.x.p, kf.y.p, kf.z.p, kf.n);
+}
+
 int ndt_keyframe_erase(ndt_handle* h, int64_t id) {
   if (!h) return NDT_ERR_INVALID_ARG;
   auto it = h->keyframes.find(id);

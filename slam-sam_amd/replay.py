@@ -39,13 +39,29 @@ def run_lidar_odometry(engine, stream, mode="ndt", svn_seed=0, priors=None):
         scan, _ = stream[k]
         prev_scan = stream[k - 1][0]
         t0 = time.perf_counter()
-        target = synth.transform(poses[k - 1], prev_scan)           # ref: run/pipeline.cpp:554-556
+        if mode != "ndt_keyframes":
+            target = synth.transform(poses[k - 1], prev_scan)       # ref: run/pipeline.cpp:554-556
         if priors is not None:
             guess = np.asarray(priors[k], dtype=np.float64)
         elif k >= 2:                                                 # constant-velocity prediction
             guess = poses[k - 1] @ np.linalg.inv(poses[k - 2]) @ poses[k - 1]
         else:
             guess = poses[k - 1].copy()
+        if mode == "ndt_keyframes":
+            # device-resident variant: every scan crosses PCIe once, as a keyframe;
+            # the target is keyframe k-1 moved by its pose ON the device, the source is keyframe k
+            if k == 1:
+                engine.putKeyframe(0, prev_scan)
+            engine.putKeyframe(k, scan)
+            engine.setInputTargetFromKeyframes([k - 1], [poses[k - 1]])
+            engine.setInputSourceFromKeyframe(k)
+            T = engine.align(guess)
+            iters.append(engine.getFinalNumIteration())
+            if k >= 2:
+                engine.eraseKeyframe(k - 2)
+            poses.append(np.asarray(T, dtype=np.float64))
+            ms.append(1e3 * (time.perf_counter() - t0))
+            continue
         engine.setInputTarget(target)                                # :557
         if mode == "ndt":
             engine.setInputSource(scan)                              # :558

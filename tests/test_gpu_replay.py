@@ -40,6 +40,27 @@ def test_replay_ndt_odometry(pkg, O, S):
         assert dt < 1e-3 and dr < 1e-4
 
 
+def test_replay_ndt_odometry_device_resident(pkg, S):
+    """Same odometry with the scans archived on the device (keyframe API): one upload per scan,
+    the target assembled and the source taken from the archive.  Must track the host-path result."""
+    from slam_sam_amd import replay
+    stream = replay.make_stream(n_frames=8)
+    kw = dict(resolution=1.0, step_size=0.1, trans_epsilon=1e-4, max_iterations=35)
+    host = pkg.NormalDistributionsTransform(device_id=0, **kw)
+    ref = replay.run_lidar_odometry(host, stream)
+    dev = pkg.NormalDistributionsTransform(device_id=0, **kw)
+    replay.run_lidar_odometry(dev, stream[:3], mode="ndt_keyframes")  # warm-up (allocations)
+    out = replay.run_lidar_odometry(dev, stream, mode="ndt_keyframes")
+    print("C5 NDT replay, device-resident keyframes: %.1f Hz end to end, %.2f ms/frame, iterations %s"
+          % (out["hz"], out["ms"].mean(), out["iterations"]))
+    assert dev.keyframeCount() == 2
+    for a, b in zip(out["poses"], ref["poses"]):
+        dt, dr = S.pose_error(a, b)       # the device moves the target with a double matrix (pcl semantics),
+        assert dt < 1e-3 and dr < 1e-4    # the harness with NumPy: identical up to an f32 ulp per point
+    err = replay.trajectory_errors(out["poses"], stream)
+    assert max(e[0] for e in err) < 0.05
+
+
 def test_replay_svn_odometry(pkg, S):
     from slam_sam_amd import replay
     stream = replay.make_stream(n_frames=5)
