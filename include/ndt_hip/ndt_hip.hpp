@@ -233,6 +233,26 @@ class NormalDistributionsTransform
     return grid_;
   }
 
+  // ---- device-resident keyframe archive (ref: run/pipeline_ligo_tc.cpp:519-529, run/pipeline.cpp:554-557,784) ----
+  // not part of pclomp: the body-frame scans stay in HBM, the sliding-window target is assembled
+  // there from ids + poses (column-major 4x4 doubles, e.g. gtsam::Pose3::matrix().data())
+  template <class Cloud>
+  void putKeyframe(int64_t id, const Cloud& cloud) {
+    if (!h_) { status_ = NDT_ERR_NO_DEVICE; return; }
+    status_ = cloud.points.empty() ? ndt_keyframe_put(h_, id, nullptr, 0, 12)
+                                   : ndt_keyframe_put(h_, id, &cloud.points[0].x, cloud.points.size(), sizeof(cloud.points[0]));
+  }
+  void eraseKeyframe(int64_t id) { status_ = h_ ? ndt_keyframe_erase(h_, id) : NDT_ERR_NO_DEVICE; }
+  int64_t keyframeCount() const { return h_ ? ndt_keyframe_count(h_) : 0; }
+  // poses_colmajor: ids.size() x 16 doubles
+  void setInputTargetFromKeyframes(const std::vector<int64_t>& ids, const double* poses_colmajor) {
+    status_ = h_ ? ndt_set_target_from_keyframes(h_, ids.data(), poses_colmajor, (int)ids.size()) : NDT_ERR_NO_DEVICE;
+  }
+  void setInputSourceFromKeyframe(int64_t id) {
+    status_ = h_ ? ndt_set_source_from_keyframe(h_, id) : NDT_ERR_NO_DEVICE;
+    if (status_ == NDT_OK) { source_.reset(); n_src_ = 0; }  // align()'s output cloud is not filled on this path
+  }
+
   int lastStatus() const { return status_; }
   std::string lastError() const { return h_ ? ndt_last_error(h_) : "no engine (ndt_create failed: GPU required)"; }
   const ndt_result& rawResult() const { return res_; }

@@ -1,6 +1,7 @@
 // The reference's ConvergenceComparison.PclOmp test
 // (ref: extern/svn_ndt/test/test_svn_ndt.cpp:138-199) written against the C++ adapter's
 // PCL-free face.  Exit code 0 = pass.  Needs an MI355X; run by tests/test_gpu_cpp_adapter.py.
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <random>
@@ -79,6 +80,30 @@ int main() {
   empty.computeTransformation(o2, guess);
   ok = ok && !empty.hasConverged() && empty.lastStatus() == NDT_ERR_NO_TARGET &&
        empty.getFinalTransformation() == guess;
+  // keyframe archive: target = keyframe 1 (the target cloud, identity pose), source = keyframe 2
+  // -> the same registration, with both clouds resident on the device; plus the covariance helper
+  {
+    ndt_hip::NormalDistributionsTransform<PointT, PointT> kf;
+    kf.setResolution(1.0f);
+    kf.setMaximumIterations(50);
+    kf.setTransformationEpsilon(1e-4);
+    kf.setStepSize(0.1);
+    kf.putKeyframe(1, *tgt);
+    kf.putKeyframe(2, *src);
+    const double eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    kf.setInputTargetFromKeyframes({1}, eye);
+    kf.setInputSourceFromKeyframe(2);
+    Cloud o3;
+    kf.computeTransformation(o3, guess);
+    ndt_hip::Matrix4f T2 = kf.getFinalTransformation();
+    double d2 = 0;
+    for (int i = 0; i < 16; ++i) d2 = std::fmax(d2, std::fabs((double)T2[i] - (double)T[i]));
+    std::array<double, 36> cov{};
+    const bool cov_ok = kf.getResult().covarianceForGtsam(cov);
+    std::printf("keyframes: status=%d converged=%d max|T - T_host|=%.2e cov_ok=%d cov[rot x]=%.3g\n", kf.lastStatus(),
+                (int)kf.hasConverged(), d2, (int)cov_ok, cov[0]);
+    ok = ok && kf.lastStatus() == NDT_OK && kf.hasConverged() && d2 < 1e-5 && kf.keyframeCount() == 2 && cov_ok && cov[0] > 0.0;
+  }
   // svn_ndt-shaped adapter: K = 8 particles, Gauss-Newton Hessian, one launch per iteration
   ndt_hip::SvnNormalDistributionsTransform<PointT, PointT> svn;
   svn.setResolution(1.0f);
