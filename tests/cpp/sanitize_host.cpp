@@ -1,0 +1,161 @@
+// Host-side code of the engine under AddressSanitizer + UndefinedBehaviorSanitizer (CPU only: GPU
+// sanitizers are not available on the pool).  Compiles ndt_newton.cpp / ndt_comm.cpp directly
+// (no HIP kernels involved) and drives them through their internal interfaces:
+//   * Newton + More-Thuente on a synthetic concave score with an analytic evaluator, including
+//     evaluations that fail and evaluations that return non-finite values;
+//   * the 6x6 solve (Cholesky fast path and eigen route), result_covariance, pose <-> matrix;
+//   * the shared-memory reducer with 4 threads x 2000 rounds (bit-identical sums on every rank);
+//   * SE(3) exp / log round trips.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <unistd.h>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../slam-sam_amd/csrc/ndt_comm.h"
+#include "../../slam-sam_amd/csrc/ndt_newton.h"
+#include "../../slam-sam_amd/csrc/ndt_se3.h"
+
+static int fails = 0;
+#define CHECK(c)                                                        \
+  do {                                                                  \
+    if (!(c)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #c); ++fails; } \
+  } while (0)
+
+int main() {
+  std::mt19937 rng(7);
+  std::normal_distribution<double> N(0.0, 1.0);
+  // ---- Newton driver on score(p) = -(p - p*)^T A (p - p*) / 2 + c --------------------------------
+  double A[36], M[36];
+  for (auto& v : M) v = N(rng);
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) {
+      double s = i == j ? 2.0 : 0.0;
+      for (int k = 0; k < 6; ++k) s += M[6 * i + k] * M[6 * j + k];
+      A[6 * i + j] = s * 50.0;
+    }
+  const double popt[6] = {0.4, -0.1, 0.25, 0.02, -0.03, 0.1};
+  int calls = 0;
+  ndt::EvalFn fn = [&](const double* p, const float*, bool need_h, ndt::Eval* e) -> int {
+    ++calls;
+    double d[6];
+    for (int i = 0; i < 6; ++i) d[i] = p[i] - popt[i];
+    e->score = 1000.0;
+    for (int i = 0; i < 6; ++i) {
+      double g = 0;
+      for (int j = 0; j < 6; ++j) g += A[6 * i + j] * d[j];
+      e->g[i] = -g;
+      e->score -= 0.5 * d[i] * g;
+    }
+    for (int i = 0; i < 36; ++i) e->H[i] = need_h ? -A[i] : 0.0;
+    e->nvtl_sum = 10; e->n_with = 10; e->n_pairs = 40;
+    return 0;
+  };
+  ndt_params prm;   // ndt_default_params() lives in the HIP translation unit: same values by hand
+  std::memset(&prm, 0, sizeof(prm));
+  prm.resolution = 1.0f; prm.outlier_ratio = 0.55; prm.search_method = NDT_DIRECT7; prm.min_points_per_voxel = 6;
+  prm.eig_inflation_ratio = 0.01; prm.hessian_mode = NDT_HESSIAN_FULL; prm.use_line_search = 1;
+  prm.trans_epsilon = 1e-6; prm.step_size = 0.1; prm.max_iterations = 60;
+  float guess[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  ndt_result r;
+  for (int in_trials = 0; in_trials < 2; ++in_trials) {
+    std::memset(&r, 0, sizeof(r));
+    CHECK(ndt::newton_align(prm, 100, guess, fn, &r, in_trials != 0) == 0);
+    CHECK(r.converged == 1);
+    double err = 0;
+    for (int i = 0; i < 6; ++i) err = std::fmax(err, std::fabs(r.final_pose[i] - popt[i]));
+    CHECK(err < 1e-3);
+  }
+  prm.use_line_search = 0;
+  std::memset(&r, 0, sizeof(r));
+  CHECK(ndt::newton_align(prm, 100, guess, fn, &r) == 0);
+  prm.use_line_search = 1;
+  // evaluator failure is propagated, non-finite evaluations do not crash the driver
+  int n = 0;
+  ndt::EvalFn failing = [&](const double* p, const float* T, bool h, ndt::Eval* e) -> int {
+    return ++n == 3 ? -3 : fn(p, T, h, e);
+  };
+  CHECK(ndt::newton_align(prm, 100, guess, failing, &r) != 0);
+  ndt::EvalFn nan_eval = [&](const double* p, const float* T, bool h, ndt::Eval* e) -> int {
+    fn(p, T, h, e);
+    e->score = std::nan(""); e->g[2] = INFINITY; e->H[7] = std::nan("");
+    return 0;
+  };
+  std::memset(&r, 0, sizeof(r));
+  (void)ndt::newton_align(prm, 100, guess, nan_eval, &r);
+  CHECK(std::isfinite(r.final_transformation[12]));
+
+  // ---- pose <-> matrix, covariance ---------------------------------------------------------------
+  for (int t = 0; t < 200; ++t) {
+    double p[6] = {N(rng) * 10, N(rng) * 10, N(rng), N(rng) * 0.5, N(rng) * 0.5, N(rng)}, q[6];
+    float T[16];
+    ndt::pose_to_matrix(p, T);
+    ndt::matrix_to_pose(T, q);
+    float T2[16];
+    ndt::pose_to_matrix(q, T2);
+    for (int i = 0; i < 16; ++i) CHECK(std::fabs(T[i] - T2[i]) < 2e-5f);
+    float jang[24], hang[45];
+    ndt::angle_tables(p, jang, hang);
+  }
+  double H[36], cov[36];
+  for (int i = 0; i < 36; ++i) H[i] = -A[i];
+  CHECK(ndt::result_covariance(H, 1e-6, true, cov));
+  CHECK(cov[0] > 0);
+  std::memset(H, 0, sizeof(H));
+  CHECK(!ndt::result_covariance(H, 0.0, false, cov));
+  H[0] = std::nan("");
+  CHECK(!ndt::result_covariance(H, 1e-6, false, cov));
+  double d1, d2;
+  ndt::gauss_constants(1.0, 0.55, &d1, &d2);
+  CHECK(std::isfinite(d1) && std::isfinite(d2));
+
+  // ---- shared-memory reducer: 4 ranks as threads ---------------------------------------------------
+  {
+    const int R = 4, rounds = 2000;
+    const std::string name = "/ndt_sanitize_" + std::to_string((long)getpid());
+    std::vector<std::vector<double>> last(R, std::vector<double>(NDT_EVAL_WORDS));
+    std::vector<int> rc(R, 0);
+    std::vector<std::thread> th;
+    for (int k = 0; k < R; ++k)
+      th.emplace_back([&, k] {
+        ndt::Reducer red;
+        std::string err;
+        if (red.init_shm(name.c_str(), k, R, &err) != NDT_OK) { rc[k] = 1; return; }
+        double w[NDT_EVAL_WORDS];
+        for (int it = 0; it < rounds; ++it) {
+          for (int i = 0; i < NDT_EVAL_WORDS; ++i) w[i] = (k + 1) * 0.1 * (i + 1) + it * 1e-3;
+          if (red.allreduce_host(w, NDT_EVAL_WORDS, &err) != NDT_OK) { rc[k] = 2; return; }
+        }
+        std::memcpy(last[k].data(), w, sizeof(w));
+      });
+    for (auto& t : th) t.join();
+    for (int k = 0; k < R; ++k) CHECK(rc[k] == 0);
+    for (int k = 1; k < R; ++k) CHECK(std::memcmp(last[0].data(), last[k].data(), sizeof(double) * NDT_EVAL_WORDS) == 0);
+    double want = 0;
+    for (int k = 0; k < R; ++k) want += (k + 1) * 0.1 * 1 + (rounds - 1) * 1e-3;
+    CHECK(std::fabs(last[0][0] - want) < 1e-9);
+  }
+
+  // ---- SE(3) ---------------------------------------------------------------------------------------
+  for (int t = 0; t < 500; ++t) {
+    double xi[6], back[6];
+    const double scale = t % 5 == 0 ? 1e-9 : 1.0;  // small-angle branches too
+    for (int i = 0; i < 3; ++i) xi[i] = N(rng) * 0.9 * scale;
+    const double wn = std::sqrt(xi[0] * xi[0] + xi[1] * xi[1] + xi[2] * xi[2]);
+    if (wn > 3.0)  // Log is the inverse of Exp only inside the ball |w| < pi
+      for (int i = 0; i < 3; ++i) xi[i] *= 3.0 / wn;
+    for (int i = 3; i < 6; ++i) xi[i] = N(rng) * 5.0;
+    ndt::se3::Pose P = ndt::se3::expmap(xi);
+    ndt::se3::logmap(P, back);
+    for (int i = 0; i < 6; ++i) CHECK(std::fabs(xi[i] - back[i]) < 1e-7 * (1.0 + std::fabs(xi[i])));
+    double T[16];
+    ndt::se3::to_colmajor(ndt::se3::between(P, ndt::se3::retract(P, xi)), T);
+    double rpy[3];
+    ndt::se3::rpy(P, rpy);
+  }
+  std::printf(fails ? "FAIL (%d)\n" : "PASS\n", fails);
+  return fails ? 1 : 0;
+}
