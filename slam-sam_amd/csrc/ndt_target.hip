@@ -680,13 +680,16 @@ __global__ void __launch_bounds__(64) k_leaf_finalize(const uint32_t* __restrict
   for (int a = 0; a < 3; ++a) L.evals[a] = d[a];
   if (!ok) L.count = -cnt;
   stats[slot] = L;
+  // Every slot gets a finite record: the derivative kernel reads record 0 for an absent
+  // neighbour (masked by f = 0, but 0 * NaN would still poison the sums), and slot 0 may well be
+  // a rejected leaf.  Only accepted leaves are reachable through the cell -> leaf grid.
+  VoxelRecord r;
+  r.mean[0] = ok ? mean[0] : 0.0; r.mean[1] = ok ? mean[1] : 0.0; r.mean[2] = ok ? mean[2] : 0.0;
+  r.icov[0] = ok ? I[0] : 0.0; r.icov[1] = ok ? I[1] : 0.0; r.icov[2] = ok ? I[2] : 0.0;
+  r.icov[3] = ok ? I[4] : 0.0; r.icov[4] = ok ? I[5] : 0.0; r.icov[5] = ok ? I[8] : 0.0;
+  r.pad = (double)cnt;
+  rec[slot] = r;
   if (ok) {
-    VoxelRecord r;
-    r.mean[0] = mean[0]; r.mean[1] = mean[1]; r.mean[2] = mean[2];
-    r.icov[0] = I[0]; r.icov[1] = I[1]; r.icov[2] = I[2];
-    r.icov[3] = I[4]; r.icov[4] = I[5]; r.icov[5] = I[8];
-    r.pad = (double)cnt;
-    rec[slot] = r;
     cell2leaf[cell] = slot;
     atomicAdd(nleaf_p + 1, 1);  // leaves that passed every check
   }

@@ -319,6 +319,29 @@ def test_edge_cases(pkg, O, S):
     assert ei.value.code == -6
 
 
+def test_rejected_first_leaf_does_not_poison_sums(pkg, O, S):
+    """An absent neighbour is evaluated against record 0 and masked with f = 0; record 0 must then
+    be finite even when leaf 0 was rejected (here: eight identical points in the lowest cell, zero
+    covariance), or 0 * NaN reaches the sums.  Found by the randomised sweep."""
+    cfg = S.config_c1()
+    lo = cfg["target"].min(axis=0) - 3.0
+    tgt = np.concatenate([np.repeat(lo[None, :], 8, axis=0), cfg["target"]]).astype(np.float32)
+    kw = dict(resolution=1.0, step_size=0.1, trans_epsilon=1e-4, max_iterations=30)
+    grid = O.Grid(tgt, O.default_params(**kw))
+    OL = grid.export()
+    assert 0 not in OL["cell"]           # the lowest cell (slot 0 of the build) is rejected and erased (ref :307, :341)
+    ndt = make_ndt(pkg, **kw)
+    ndt.setInputTarget(tgt)
+    assert_leaves_match(ndt.getLeaves(), OL)
+    ndt.setInputSource(cfg["source"])
+    p = O.matrix_to_pose(cfg["guess"])
+    for method, omethod in ((pkg.DIRECT7, O.DIRECT7), (pkg.DIRECT1, O.DIRECT1), (pkg.KDTREE, O.KDTREE)):
+        ndt.setParams(search_method=method)
+        e = ndt.evalDerivatives(p)[0]
+        assert np.isfinite(e["gradient"]).all() and np.isfinite(e["hessian"]).all()
+        assert_derivs_match(e, grid.derivatives(cfg["source"], p, params=O.default_params(search_method=omethod, **kw)))
+
+
 def test_input_layouts_agree(pkg, S):
     """packed xyz, PCL-style 32-byte AoS (PointXYZI) and SoA inputs give identical results."""
     cfg = S.config_c1()
