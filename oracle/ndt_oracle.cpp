@@ -585,8 +585,11 @@ void point_derivatives(const float x[3], const float jang[24], const float hang[
   d.Hp[5][5][0] = xh[12]; d.Hp[5][5][1] = xh[13]; d.Hp[5][5][2] = xh[14];
 }
 
-// ref: svn_ndt_impl.hpp:401-513 (vendored per-pair update)
-double update_pair_svn(double g[6], double H[36], const PointDeriv& d, const double xr[3],
+// ref: svn_ndt_impl.hpp:401-513 (vendored per-pair update).  F = float is the reference's
+// arithmetic (x_trans4 / c_inv4 / point_gradient4 are float there); F = double carries the same
+// formulas in f64 (ORACLE_PAIR_SVN_F64, a test seam).
+template <typename F>
+double update_pair_svn_t(double g[6], double H[36], const PointDeriv& d, const double xr[3],
                        const double ci[9], double d1, double d2, bool need_h, bool gauss_newton) {
   double cx[3];
   for (int a = 0; a < 3; ++a) cx[a] = ci[3 * a] * xr[0] + ci[3 * a + 1] * xr[1] + ci[3 * a + 2] * xr[2];
@@ -600,17 +603,17 @@ double update_pair_svn(double g[6], double H[36], const PointDeriv& d, const dou
   double factor = d1 * d2 * e;
   if (!std::isfinite(factor) || std::fabs(factor) < 1e-15) return score_inc;
 
-  float x4[3] = {static_cast<float>(xr[0]), static_cast<float>(xr[1]), static_cast<float>(xr[2])};
-  float c4[9];
-  for (int a = 0; a < 9; ++a) c4[a] = static_cast<float>(ci[a]);
-  float tv[3][6];  // C^-1 * J
+  F x4[3] = {static_cast<F>(xr[0]), static_cast<F>(xr[1]), static_cast<F>(xr[2])};
+  F c4[9];
+  for (int a = 0; a < 9; ++a) c4[a] = static_cast<F>(ci[a]);
+  F tv[3][6];  // C^-1 * J
   for (int a = 0; a < 3; ++a)
     for (int j = 0; j < 6; ++j) {
-      float s = 0;
-      for (int k = 0; k < 3; ++k) s += c4[3 * a + k] * d.J[k][j];
+      F s = 0;
+      for (int k = 0; k < 3; ++k) s += c4[3 * a + k] * static_cast<F>(d.J[k][j]);
       tv[a][j] = s;
     }
-  float gc[6];  // (x-mu)^T C^-1 J
+  F gc[6];  // (x-mu)^T C^-1 J
   for (int j = 0; j < 6; ++j) gc[j] = x4[0] * tv[0][j] + x4[1] * tv[1][j] + x4[2] * tv[2][j];
   double ginc[6];
   bool gfin = true;
@@ -625,16 +628,17 @@ double update_pair_svn(double g[6], double H[36], const PointDeriv& d, const dou
     double hc[36];
     for (int i = 0; i < 6; ++i)
       for (int j = 0; j < 6; ++j) {
-        float s = 0;
-        for (int k = 0; k < 3; ++k) s += d.J[k][i] * tv[k][j];
+        F s = 0;
+        for (int k = 0; k < 3; ++k) s += static_cast<F>(d.J[k][i]) * tv[k][j];
         hc[6 * i + j] = static_cast<double>(s);  // term2 = J^T C^-1 J
       }
     if (!gauss_newton) {
-      float xc[3];
+      F xc[3];
       for (int k = 0; k < 3; ++k) xc[k] = x4[0] * c4[k] + x4[1] * c4[3 + k] + x4[2] * c4[6 + k];
       for (int i = 0; i < 6; ++i)
         for (int j = i; j < 6; ++j) {
-          float t3 = xc[0] * d.Hp[i][j][0] + xc[1] * d.Hp[i][j][1] + xc[2] * d.Hp[i][j][2];
+          F t3 = xc[0] * static_cast<F>(d.Hp[i][j][0]) + xc[1] * static_cast<F>(d.Hp[i][j][1]) +
+                 xc[2] * static_cast<F>(d.Hp[i][j][2]);
           double t1 = -d2 * (static_cast<double>(gc[i]) * static_cast<double>(gc[j]));
           double add_ij = t1 + static_cast<double>(t3);
           hc[6 * i + j] += add_ij;
@@ -650,6 +654,11 @@ double update_pair_svn(double g[6], double H[36], const PointDeriv& d, const dou
       for (int a = 0; a < 36; ++a) H[a] += hc[a];
   }
   return score_inc;
+}
+
+double update_pair_svn(double g[6], double H[36], const PointDeriv& d, const double xr[3],
+                       const double ci[9], double d1, double d2, bool need_h, bool gauss_newton) {
+  return update_pair_svn_t<float>(g, H, d, xr, ci, d1, d2, need_h, gauss_newton);
 }
 
 // [RECALLED] upstream pclomp updateDerivatives: everything in f32, guard on
@@ -715,7 +724,7 @@ extern "C" void oracle_derivatives(const oracle_grid* g, const float* src, size_
   oracle_angle_tables(pose6, jang, hang);
   const bool need_h = compute_hessian != 0;
   const bool gn = prm->hessian_mode == ORACLE_HESSIAN_GAUSS_NEWTON;
-  const bool need_hp = need_h && !(gn && prm->pair_mode == ORACLE_PAIR_SVN);
+  const bool need_hp = need_h && !(gn && prm->pair_mode != ORACLE_PAIR_PCLOMP_RECALLED);
 
   int nthreads = std::max(1, prm->num_threads);
   std::vector<Accum> accs(nthreads);
@@ -748,9 +757,11 @@ extern "C" void oracle_derivatives(const oracle_grid* g, const float* src, size_
         double xr[3] = {static_cast<double>(xt[0]) - L.mean[0],
                         static_cast<double>(xt[1]) - L.mean[1],
                         static_cast<double>(xt[2]) - L.mean[2]};
-        double s = (prm->pair_mode == ORACLE_PAIR_SVN)
+        double s = prm->pair_mode == ORACLE_PAIR_SVN
                        ? update_pair_svn(pg, pH, pd, xr, L.icov, d1, d2, need_h, gn)
-                       : update_pair_pclomp(pg, pH, pd, xr, L.icov, d1, d2, need_h);
+                       : prm->pair_mode == ORACLE_PAIR_SVN_F64
+                             ? update_pair_svn_t<double>(pg, pH, pd, xr, L.icov, d1, d2, need_h, gn)
+                             : update_pair_pclomp(pg, pH, pd, xr, L.icov, d1, d2, need_h);
         ps += s;
         best = std::max(best, s);
       }

@@ -40,9 +40,13 @@ enum { ORACLE_HESSIAN_FULL = 0, ORACLE_HESSIAN_GAUSS_NEWTON = 1 };
  * to use the "(n-1)/n" form -- unverifiable here, kept as a switch. */
 enum { ORACLE_COV_SVN = 0, ORACLE_COV_PCL_RECALLED = 1 };
 /* per-pair arithmetic: vendored (f64 Mahalanobis + exp, guards 50 / 1e-15,
- * svn_ndt_impl.hpp:418-447) or upstream pclomp as recalled (all-f32, [0,1]
- * guard). */
-enum { ORACLE_PAIR_SVN = 0, ORACLE_PAIR_PCLOMP_RECALLED = 1 };
+ * svn_ndt_impl.hpp:418-447; products of the gradient / Hessian terms in f32, :412-415,
+ * :449-494) or upstream pclomp as recalled (all-f32, [0,1] guard).
+ * ORACLE_PAIR_SVN_F64: the vendored FORMULAS with every product carried in f64 -- not what
+ * the reference computes, but what its f32 products approximate; lets the tests separate
+ * "the kernel implements other formulas" (never) from "the reference rounds to f32"
+ * (1e-7 per product, up to ~4e-5 of the sums on ill-conditioned voxels). */
+enum { ORACLE_PAIR_SVN = 0, ORACLE_PAIR_PCLOMP_RECALLED = 1, ORACLE_PAIR_SVN_F64 = 2 };
 
 typedef struct oracle_params {
   float resolution;            /* voxel leaf size (m) */

@@ -2,13 +2,14 @@
 duplicated points, coplanar / collinear voxels, non-finite entries, negative and large offsets,
 odd leaf sizes and min-point thresholds) through the C-ABI, in all three neighbourhood modes and
 all three Hessian modes.  Same tolerances as tests/test_gpu_parity.py: voxel membership, point
-counts and pair counts bit-exact; means 1e-12; covariances 1e-9 of their largest entry (looser
-where the reference's own single-pass formula cancels); score 1e-8 (1e-9 on ordinary clouds; the
-near-degenerate voxels of the `dupes` clouds carry the covariance tolerance into the inverse);
-gradient / Hessian 5e-6 of
-their norms (the oracle rounds the per-pair Jacobian products to f32 as the reference does, the
-kernel keeps f64: 1e-8..1e-7 on ordinary clouds, up to 1.2e-6 on collinear voxels whose inflated
-inverse covariances are ill-conditioned)."""
+counts and pair counts bit-exact; means 1e-12; covariances 1e-9 of their largest entry, looser by
+the cancellation loss of the reference's own single-pass formula (`amp` below, which also widens
+the derivative tolerances of a cloud whose thinnest voxel is ill-conditioned); score 1e-8.
+Gradient / Hessian: the reference forms the per-pair products in f32 (float x_trans4, c_inv4,
+point_gradient4: svn_ndt_impl.hpp:412-415), the kernel in f64.  So the kernel is compared (1) with
+the oracle's f64 evaluation of the same formulas (`pair_mode=2`, a test seam): 1e-9 of the norms;
+(2) with the oracle's reference arithmetic: no farther from it than that arithmetic is from f64
+(measured 1e-8..1e-7 on ordinary clouds, up to 4e-5 on collinear / few-point voxels)."""
 import numpy as np
 import pytest
 
@@ -38,7 +39,7 @@ def make_cloud(rng, kind, n, offset):
 
 CASES = []
 _rng = np.random.default_rng(20241004)
-for i, kind in enumerate(["blobs", "planes", "lines", "dupes", "box"] * 10):
+for i, kind in enumerate(["blobs", "planes", "lines", "dupes", "box"] * 20):
     CASES.append(dict(
         seed=1000 + i, kind=kind,
         n=int(_rng.choice([7, 60, 700, 5000, 20000])),
@@ -76,13 +77,18 @@ def test_random_cloud_parity(pkg, O, S, case):
     assert np.array_equal(gi["min_b"], grid.min_b) and np.array_equal(gi["div_b"], grid.div_b)
     L, OL = ndt.getLeaves(), grid.export()
     assert np.array_equal(L["cell"], OL["cell"]) and np.array_equal(L["count"], OL["count"])
+    amp = 0.0
     if len(OL["cell"]):
         np.testing.assert_allclose(L["mean"], OL["mean"], rtol=1e-12, atol=0)
-        # the single-pass covariance loses (|mean| / spread)^2 * eps in both implementations
+        # The reference's single-pass covariance (sum xx^T / n - mean mean^T) loses
+        # (|mean| / spread)^2 * eps to cancellation in BOTH implementations, which sum in different
+        # orders: a millimetre-thin voxel 1.5 km from the origin keeps ~4 digits.  The inflated
+        # inverse, and with it score / gradient / Hessian, inherit that: tolerances scale with it.
         spread = np.sqrt(np.maximum(np.abs(OL["cov"]).max(axis=(1, 2)), 1e-30))
         loss = 1e-9 + 64 * np.finfo(np.float64).eps * (np.abs(OL["mean"]).max(axis=1) / spread) ** 2
         scale = np.abs(OL["cov"]).max(axis=(1, 2))
         assert ((np.abs(L["cov"] - OL["cov"]).max(axis=(1, 2)) / scale) < loss).all()
+        amp = float(loss.max())
     ndt.setInputSource(src)
     if not (OL["count"] > 0).any():   # no voxel passed the eigenvalue checks: loud refusal, as for an empty target
         with pytest.raises(pkg.NdtError) as ei:
@@ -94,16 +100,27 @@ def test_random_cloud_parity(pkg, O, S, case):
     for method, omethod in ((pkg.DIRECT7, O.DIRECT7), (pkg.DIRECT1, O.DIRECT1), (pkg.KDTREE, O.KDTREE)):
         for hmode in (pkg.HESSIAN_FULL, pkg.HESSIAN_GAUSS_NEWTON):
             ndt.setParams(search_method=method, hessian_mode=hmode)
-            oprm = O.default_params(num_threads=4, search_method=omethod,
-                                    hessian_mode=1 if hmode == pkg.HESSIAN_GAUSS_NEWTON else 0, **kw)
+            okw = dict(num_threads=4, search_method=omethod,
+                       hessian_mode=1 if hmode == pkg.HESSIAN_GAUSS_NEWTON else 0, **kw)
+            oprm = O.default_params(**okw)                 # the reference's arithmetic (f32 products)
+            oprm64 = O.default_params(pair_mode=2, **okw)  # the same formulas carried in f64 (test seam)
             got = ndt.evalDerivatives(poses)
             for p, e in zip(poses, got):
                 d = grid.derivatives(src, p, params=oprm)
+                x = grid.derivatives(src, p, params=oprm64)
                 assert e["n_pairs"] == d["n_pairs"] and e["n_with_neighbors"] == d["n_with_neighbors"]
-                assert e["score"] == pytest.approx(d["score"], rel=1e-8, abs=1e-9)
-                gn, hn = np.linalg.norm(d["gradient"]), np.linalg.norm(d["hessian"])
-                assert np.linalg.norm(e["gradient"] - d["gradient"]) <= 5e-6 * gn + 1e-9
-                assert np.linalg.norm(e["hessian"] - d["hessian"]) <= 5e-6 * hn + 1e-9
+                assert e["score"] == pytest.approx(d["score"], rel=1e-8 + amp, abs=1e-9)
+                gn, hn = np.linalg.norm(x["gradient"]), np.linalg.norm(x["hessian"])
+                # (1) the kernel evaluates the reference's formulas: against their f64 evaluation
+                #     it agrees to 1e-9 (+ what the two covariance tables differ by)
+                assert np.linalg.norm(e["gradient"] - x["gradient"]) <= (1e-9 + 30 * amp) * gn + 1e-9
+                assert np.linalg.norm(e["hessian"] - x["hessian"]) <= (1e-9 + 30 * amp) * hn + 1e-9
+                # (2) against the reference's own f32 products it is as far off as they are from f64
+                rg = np.linalg.norm(d["gradient"] - x["gradient"])
+                rh = np.linalg.norm(d["hessian"] - x["hessian"])
+                assert np.linalg.norm(e["gradient"] - d["gradient"]) <= 1.01 * rg + (1e-9 + 30 * amp) * gn + 1e-9
+                assert np.linalg.norm(e["hessian"] - d["hessian"]) <= 1.01 * rh + (1e-9 + 30 * amp) * hn + 1e-9
+                assert rg <= 2e-4 * gn + 1e-9 and rh <= 2e-4 * hn + 1e-9   # and that spread is f32-sized
             # score + gradient only (the line search's cheap evaluation) agrees with the full one
             e0 = ndt.evalDerivatives(poses[0], compute_hessian=False)[0]
             assert e0["score"] == got[0]["score"] and np.array_equal(e0["gradient"], got[0]["gradient"])
