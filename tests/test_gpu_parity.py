@@ -124,8 +124,11 @@ def test_config_parity(pkg, O, S, c2, name):
     ndt.setInputSource(cfg["source"])
     p0 = O.matrix_to_pose(cfg["guess"])
     poses = np.stack([p0, p0 + [0.05, -0.03, 0.02, 0.01, -0.005, 0.008], O.matrix_to_pose(cfg["gt"])])
+    prm64 = O.default_params(resolution=res, step_size=0.1, trans_epsilon=1e-4, max_iterations=35, num_threads=8,
+                             pair_mode=2)   # test seam: the reference's formulas with f64 products
     for p, e in zip(poses, ndt.evalDerivatives(poses)):
-        assert_derivs_match(e, grid.derivatives(cfg["source"], p))
+        assert_derivs_match(e, grid.derivatives(cfg["source"], p))                       # reference arithmetic: 1e-6
+        assert_derivs_match(e, grid.derivatives(cfg["source"], p, params=prm64), 1e-9)   # same formulas in f64: 1e-9
     # single-pose launch path (kernel-argument pose) must agree with the batched one bit for bit
     e1 = ndt.evalDerivatives(poses[1])[0]
     eb = ndt.evalDerivatives(poses)[1]
