@@ -345,6 +345,38 @@ def test_rejected_first_leaf_does_not_poison_sums(pkg, O, S):
         assert_derivs_match(e, grid.derivatives(cfg["source"], p, params=O.default_params(search_method=omethod, **kw)))
 
 
+def test_two_engines_in_two_threads(pkg, S):
+    """One engine per thread, as the reference's drivers run them (an NDT odometry thread beside
+    an SVN / map thread): two handles driven concurrently give exactly the single-threaded results
+    (process-wide launch tags, per-handle streams and buffers)."""
+    import threading
+    cfgs = [S.config_c1(), S.config_c2()]
+    kw = [dict(resolution=float(c["resolution"]), step_size=0.1, trans_epsilon=1e-4, max_iterations=35) for c in cfgs]
+
+    def run(i, out, reps):
+        ndt = pkg.NormalDistributionsTransform(device_id=0, **kw[i])
+        res = []
+        for _ in range(reps):
+            ndt.setInputTarget(cfgs[i]["target"])
+            ndt.setInputSource(cfgs[i]["source"])
+            ndt.align(cfgs[i]["guess"])
+            r = ndt.getResult()
+            res.append((r["T"].copy(), r["score"], r["iterations"]))
+        out[i] = res
+
+    ref = [None, None]
+    for i in range(2):
+        run(i, ref, 1)
+    got = [None, None]
+    th = [threading.Thread(target=run, args=(i, got, 12)) for i in range(2)]
+    for t in th: t.start()
+    for t in th: t.join()
+    for i in range(2):
+        assert got[i] is not None and len(got[i]) == 12
+        for T, score, it in got[i]:
+            assert np.array_equal(T, ref[i][0][0]) and score == ref[i][0][1] and it == ref[i][0][2]
+
+
 def test_input_layouts_agree(pkg, S):
     """packed xyz, PCL-style 32-byte AoS (PointXYZI) and SoA inputs give identical results."""
     cfg = S.config_c1()
