@@ -21,6 +21,12 @@ reported baseline, not the target.
 import argparse
 import json
 import os
+
+# NumPy's BLAS keeps a pool of spinning worker threads alive for a while after every matmul; on the
+# GPU box's 16-CPU share they compete with the engine's polling thread (measured: a 1M x 3 matmul
+# right before a timed region cost it 2.4x).  The synthetic workloads need no threaded BLAS.
+for _v in ("OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "BLIS_NUM_THREADS"):
+    os.environ.setdefault(_v, "1")
 import sys
 import threading
 import time
@@ -254,7 +260,11 @@ def main():
             return None
         gt = cfg["gt"].astype(np.float64)
         Rinv, tinv = gt[:3, :3].T, -gt[:3, :3].T @ gt[:3, 3]
-        big = cfg["target"].astype(np.float64) @ Rinv.T + tinv
+        t64 = cfg["target"].astype(np.float64)
+        # element-wise on purpose: a BLAS matmul here leaves a pool of spinning worker threads
+        # behind that competes with the engine's polling thread for the box's CPU share
+        big = np.stack([t64[:, 0] * Rinv[r, 0] + t64[:, 1] * Rinv[r, 1] + t64[:, 2] * Rinv[r, 2] + tinv[r]
+                        for r in range(3)], axis=1)
         big = (big + np.random.default_rng(5).normal(0.0, 0.02, big.shape)).astype(np.float32)
         nb = len(big)
         bb, cb = pkg.shard_range(nb, rank, world)
