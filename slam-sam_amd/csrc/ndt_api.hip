@@ -621,10 +621,9 @@ int ndt_set_source_device(ndt_handle* h, const float* dx, const float* dy, const
   HIP_TRY(h, h->sy.ensure(n));
   HIP_TRY(h, h->sz.ensure(n));
   if (n) {
-    HIP_TRY(h, hipMemcpyAsync(h->sx.p, dx, n * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->sy.p, dy, n * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->sz.p, dz, n * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    launch_copy_soa(dx, dy, dz, n, h->sx.p, h->sy.p, h->sz.p, h->stream);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));  // the caller's arrays are consumed during the call
   }
   h->n_src = n;
   return NDT_OK;

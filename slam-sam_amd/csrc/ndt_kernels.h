@@ -48,6 +48,9 @@ void launch_finalize_leaves(const float* xyz4,
                             VoxelRecord* rec, LeafStats* stats, int* cell2leaf, hipStream_t s);
 
 // out[i] = (float)(R x + t) in f64 (sliding-window target assembly); out arrays hold n floats
+// device-to-device copy of three SoA arrays in one launch
+void launch_copy_soa(const float* x, const float* y, const float* z, size_t n, float* ox, float* oy, float* oz,
+                     hipStream_t s);
 void launch_transform_append(const float* x, const float* y, const float* z, size_t n,
                              const double pose_colmajor[16], float* ox, float* oy, float* oz,
                              hipStream_t s);

@@ -727,6 +727,27 @@ __global__ void __launch_bounds__(256) k_transform_append(const float* __restric
 
 }  // namespace
 
+// three SoA arrays in one launch (three hipMemcpyAsync cost three dispatches)
+__global__ void __launch_bounds__(256) k_copy_soa(const float* __restrict__ x, const float* __restrict__ y,
+                                                 const float* __restrict__ z, size_t n, float* __restrict__ ox,
+                                                 float* __restrict__ oy, float* __restrict__ oz) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 4 <= n && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)z | (uintptr_t)ox | (uintptr_t)oy | (uintptr_t)oz) & 15) == 0)) {
+    *reinterpret_cast<float4*>(ox + i) = *reinterpret_cast<const float4*>(x + i);
+    *reinterpret_cast<float4*>(oy + i) = *reinterpret_cast<const float4*>(y + i);
+    *reinterpret_cast<float4*>(oz + i) = *reinterpret_cast<const float4*>(z + i);
+  } else {
+    for (size_t j = i; j < n && j < i + 4; ++j) { ox[j] = x[j]; oy[j] = y[j]; oz[j] = z[j]; }
+  }
+}
+
+void launch_copy_soa(const float* x, const float* y, const float* z, size_t n, float* ox, float* oy, float* oz,
+                     hipStream_t s) {
+  if (n == 0) return;
+  const size_t threads = (n + 3) / 4;
+  hipLaunchKernelGGL(k_copy_soa, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, x, y, z, n, ox, oy, oz);
+}
+
 void launch_transform_append(const float* x, const float* y, const float* z, size_t n,
                              const double pose_colmajor[16], float* ox, float* oy, float* oz,
                              hipStream_t s) {
