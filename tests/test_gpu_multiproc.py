@@ -60,5 +60,7 @@ def test_two_processes_one_gpu_shm_reduction(pkg, S, tmp_path):
     # ... which is the single-process result up to f64 association of the two partial sums
     dt, dr = S.pose_error(z[0]["T"], T)
     assert dt < 1e-5 and dr < 1e-6
-    assert int(z[0]["n_pairs"]) == ndt.evalDerivatives(r["pose"])[0]["n_pairs"] or True
+    # pair count of the last evaluation: the two runs stop within 1e-5 m of each other, so only
+    # points sitting on a voxel face can be counted differently
+    assert abs(int(z[0]["n_pairs"]) - int(r["n_pairs"])) <= max(2, 1e-4 * r["n_pairs"])
     assert float(z[0]["tp"]) == pytest.approx(r["transform_probability"], rel=1e-6)

@@ -169,12 +169,24 @@ def test_km_scale_coordinates(pkg, O, S):
     p = O.matrix_to_pose(guess)
     assert_derivs_match(ndt.evalDerivatives(p)[0], grid.derivatives(cfg["source"], p), tol=1e-5)
     T = ndt.align(guess)
+    # At 3 km one f32 ulp is 0.24 mm: every transformed point is quantised at that level (the
+    # reference transforms in f32 too, ref: svn_ndt_impl.hpp:761), so the score is a staircase in
+    # the pose and the fixture's weak direction (both planes contain the x axis) turns any last-bit
+    # difference into a different More-Thuente decision.  The oracle shows this on itself, without
+    # a GPU: its own two arithmetics -- the reference's f32 per-pair products (pair_mode 0) and the
+    # same formulas in f64 (pair_mode 2) -- end 12.1 mm apart here and 0.07 mm apart at the origin
+    # (tests/test_oracle.py::test_km_scale_gap_is_the_references_f32_products).  The kernel
+    # carries f64, so it is held to the f64 trajectory at the 1 mm / 0.1 mrad of SURVEY 8c, and
+    # to the reference-arithmetic one at that measured 12 mm (+ margin).
+    prm64 = O.default_params(resolution=1.0, step_size=0.1, trans_epsilon=1e-4, max_iterations=50, pair_mode=2)
+    ref64 = grid.align(cfg["source"], guess, params=prm64)
+    dt, dr = S.pose_error(T, ref64["T"])
+    assert dt < ALIGN_TOL_M and dr < ALIGN_TOL_RAD, (dt, dr)
+    assert ndt.getResult()["iterations"] == ref64["iterations"]
     ref = grid.align(cfg["source"], guess)
-    # At 3 km one f32 ulp is 0.24 mm: every transformed point is quantised at that level, the
-    # score surface is rough near the optimum and the line search may settle a few ulps apart.
-    # Parity here = same optimum within the basin's flatness, not the 1 mm of metre-scale clouds.
+    gap_t, gap_r = S.pose_error(ref64["T"], ref["T"])   # the oracle against itself
     dt, dr = S.pose_error(T, ref["T"])
-    assert dt < 0.03 and dr < 2e-3, (dt, dr)
+    assert dt < gap_t + ALIGN_TOL_M and dr < gap_r + ALIGN_TOL_RAD, (dt, dr, gap_t, gap_r)
     assert ndt.getResult()["score"] == pytest.approx(ref["score"], rel=2e-3)
     assert S.pose_error(T, gt)[0] < 0.05 and S.pose_error(ref["T"], gt)[0] < 0.05
 
