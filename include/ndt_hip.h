@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define NDT_HIP_ABI_VERSION 1
+#define NDT_HIP_ABI_VERSION 2
 
 typedef enum ndt_status {
   NDT_OK = 0,
@@ -56,7 +56,9 @@ typedef enum ndt_status {
 typedef enum ndt_search_method {
   NDT_KDTREE = 0,   /* radius search (radius = resolution) over voxel centroids
                        (ref: voxel_grid_covariance_impl.hpp:505-554), done as a 27-cell scan */
-  NDT_DIRECT26 = 1, /* not implemented: upstream-only mode with no statement in the reference tree */
+  NDT_DIRECT26 = 1, /* [RECALLED] pclomp getNeighborhoodAtPoint: every valid voxel of the 3x3x3 block around the
+                       point's cell, enumerated in integer index space.  The reference tree holds only the
+                       enum value (run/pipeline.cpp:471-480) and a commented stub (svn_ndt_impl.hpp:581-583) */
   NDT_DIRECT7 = 2,
   NDT_DIRECT1 = 3
 } ndt_search_method;
@@ -78,6 +80,22 @@ typedef enum ndt_reduce_mode {
   NDT_REDUCE_HOOK = 3  /* caller-supplied all-reduce callback */
 } ndt_reduce_mode;
 
+typedef enum ndt_wait_mode {
+  NDT_WAIT_SPIN = 0,   /* the calling thread polls the result slots in pinned memory (lowest latency;
+                          occupies one host core for the duration of ndt_align) */
+  NDT_WAIT_BLOCK = 1   /* the calling thread sleeps in hipStreamSynchronize (+3..4 us per evaluation;
+                          for hosts that cannot spare a core: the drivers run 6-7 threads + OpenMP) */
+} ndt_wait_mode;
+
+/* Named parameter sets.  ndt_default_params() is the vendored-code hybrid the parity tests pin
+ * (svn covariance, full Hessian, no ridge, More-Thuente); the presets restate the two engines. */
+typedef enum ndt_preset {
+  NDT_PRESET_DEFAULT = 0,
+  NDT_PRESET_PCLOMP_RECALLED = 1, /* upstream pclomp as recalled: PCL covariance normalisation
+                                     (n-1)/n, full Hessian, no ridge, More-Thuente line search, min 6 points */
+  NDT_PRESET_SVN = 2              /* vendored svn_ndt: n/(n-1) covariance, Gauss-Newton Hessian, +1e-6 I */
+} ndt_preset;
+
 /* Parameter block; mirrors the pclomp / svn_ndt setters the drivers call and
  * RegisterCallback's JSON fields (ref: include/registercallback.hpp:37-54,
  * src/registercallback.cpp:24-91). */
@@ -97,6 +115,7 @@ typedef struct ndt_params {
   float regularization_scale_factor; /* setRegularizationScaleFactor (run/pipeline_ligo_tc.cpp:293) */
   int num_threads;               /* setNumThreads; recorded only -- there is no CPU path */
   int device_id;                 /* HIP device ordinal; -1 = current device */
+  int wait_mode;                 /* ndt_wait_mode */
 } ndt_params;
 
 typedef struct ndt_handle ndt_handle;
@@ -117,6 +136,9 @@ typedef struct ndt_result {
   int64_t n_points_with_neighbors;
   double ms_total;                /* wall time of ndt_align */
   double ms_device;               /* sum of device-side evaluation time (HIP events) */
+  int n_evaluations_reused;       /* line-search requests at the pose of the evaluation before them
+                                     (a step clamped to its lower bound is re-tried up to 10 times):
+                                     answered without a launch, bit-identical by construction */
 } ndt_result;
 
 /* Per-voxel statistics, the accessors extractNdtData() uses
@@ -148,6 +170,9 @@ typedef struct ndt_grid_info {
 /* ---- lifecycle ---------------------------------------------------------- */
 int ndt_abi_version(void);
 void ndt_default_params(ndt_params* p);
+/* overwrites the algorithm switches of *p (cov_mode, hessian_mode, add_ridge, use_line_search,
+ * min_points_per_voxel) with a named set; everything else is left as it is */
+int ndt_params_preset(ndt_params* p, int preset /* ndt_preset */);
 int ndt_create(const ndt_params* p, ndt_handle** out);   /* new pclomp::NormalDistributionsTransform */
 int ndt_destroy(ndt_handle* h);
 int ndt_set_params(ndt_handle* h, const ndt_params* p);  /* a changed resolution rebuilds the grid */
@@ -205,6 +230,20 @@ int ndt_eval_derivatives(ndt_handle* h, const double* poses6, const float* trans
 /* unpack one evaluation into score, g[6], H[36] (row-major) */
 void ndt_unpack_eval(const double* eval_words, double* score, double* g6, double* H36);
 
+/* Scoring-only evaluation (pclomp's calculateTransformationProbability /
+ * calculateNearestVoxelTransformationLikelihood [RECALLED]; the reference names them only through
+ * SURVEY 8f-4): score, transform probability (score / #source points) and NVTL (mean over the points
+ * that have a neighbour of their best per-voxel score) of the current source under T against the
+ * current target.  One launch of the score-only kernel: no gradient, no Hessian. */
+typedef struct ndt_score {
+  double score;
+  double transform_probability;
+  double nearest_voxel_transformation_likelihood;
+  int64_t n_pairs;
+  int64_t n_points_with_neighbors;
+} ndt_score;
+int ndt_score_transform(ndt_handle* h, const float T_colmajor[16], ndt_score* out);
+
 /* Covariance of a registration result for the pose graph: cov = -(H + eps I)^-1 of
  * ndt_result.hessian (ref: run/pipeline.cpp:594-596, eps = 1e-6 there), and with
  * gtsam_order != 0 the block permutation of RegisterCallback::reorderCovarianceForGTSAM
@@ -244,6 +283,10 @@ int ndt_comm_init_shm(ndt_handle* h, const char* name, int rank, int nranks);
 typedef int (*ndt_allreduce_fn)(void* ctx, double* words, int n);
 int ndt_comm_init_hook(ndt_handle* h, ndt_allreduce_fn fn, void* ctx, int rank, int nranks);
 int ndt_comm_destroy(ndt_handle* h);
+/* which collective library serves the RCCL reducer: ncclGetVersion() code (e.g. 22105) and the
+ * path of the shared object the symbol was resolved from (the process may hold two librccl.so:
+ * ROCm's and the one bundled with PyTorch); returns the version or < 0 */
+int ndt_comm_info(char* path_buf, size_t cap);
 /* total source points over all ranks (for transform_probability); set by the
  * caller after sharding, defaults to the local count */
 int ndt_set_global_source_size(ndt_handle* h, int64_t n_total);

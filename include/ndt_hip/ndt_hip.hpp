@@ -1,33 +1,59 @@
 // ndt_hip.hpp -- header-only C++ adapter over the C-ABI (include/ndt_hip.h) with the method
-// names of `pclomp::NormalDistributionsTransform` that the reference's drivers call
-// (ref: run/pipeline.cpp:464-481,557-568; run/pipeline_ligo_tc.cpp:287-305,529-538;
-//  include/pipeline.hpp:175-206; extern/svn_ndt/test/test_svn_ndt.cpp:144-179).
+// names AND the value types of `pclomp::NormalDistributionsTransform` /
+// `svn_ndt::SvnNormalDistributionsTransform` that the reference's drivers use
+// (ref: run/pipeline.cpp:464-481,557-604; run/pipeline_ligo_tc.cpp:287-305,529-541;
+//  run/pipeline_ins_map_distribution.cpp:346-371; run/pipeline_lo_svn.cpp:299-320,387-388;
+//  include/pipeline.hpp:163-222; extern/svn_ndt/test/test_svn_ndt.cpp:144-179).
 //
-// Two faces, same names:
-//   * with PCL (`__has_include(<pcl/registration/registration.h>)`, or -DNDT_HIP_WITH_PCL=1):
-//     `ndt_hip::NormalDistributionsTransform<PointSource, PointTarget>` derives from
-//     `pcl::Registration`, so it can be assigned to `RegisterCallback::registration`
+// Three optional faces, detected with __has_include (or forced with -DNDT_HIP_WITH_*=0/1):
+//   * Eigen  (<Eigen/Core>): Matrix4f / Matrix6d / Vector3d / Matrix3d ARE the Eigen types, so
+//     `ndt_result.hessian + Matrix6d::Identity() * 1e-6` (run/pipeline.cpp:594-596) and
+//     `.mean = leaf.getMean()` (include/pipeline.hpp:196-201) compile as written.
+//     Without Eigen they are small column-major POD matrices with the same accessors.
+//   * PCL    (<pcl/registration/registration.h>, needs Eigen): the engine derives from
+//     `pcl::Registration`, so it can be stored in `RegisterCallback::registration`
 //     (ref: include/registercallback.hpp:35) and driven through setInputTarget /
-//     setInputSource / align / getFinalTransformation / hasConverged unchanged.
-//     NOTE: this branch cannot be compiled in the build image (no PCL/Eigen there).
-//   * without PCL: a dependency-free twin on `ndt_hip::PointCloud<PointT>` and
-//     `ndt_hip::Matrix4f` (16 floats, column-major) used by tests/cpp/test_adapter.cpp.
+//     setInputSource / align / getFinalTransformation / hasConverged.
+//   * GTSAM  (<gtsam/geometry/Pose3.h>): `SvnNormalDistributionsTransform::align(cloud,
+//     gtsam::Pose3)` returning `SvnNdtResult{gtsam::Pose3 final_pose; Matrix6d
+//     final_covariance; ...}` (ref: extern/svn_ndt/include/svn_ndt.h:40-51,100-182).
+// include/compat/ holds `pclomp/ndt_omp.h`, `svn_ndt.h`, ... that alias the reference's
+// namespaces onto this header: with that directory in front of extern/ndt_omp/include and
+// extern/svn_ndt/include the drivers compile unchanged.
+//
+// The build image has neither Eigen, PCL nor GTSAM: the three faces are compile- and run-tested
+// against minimal API mocks (tests/cpp/mock/, test doubles -- not the libraries), the plain face
+// by tests/cpp/test_adapter.cpp.
+//
 // Failures never throw: like the reference (ref: svn_ndt_impl.hpp:682-702) a failed align
 // leaves the guess as the final transformation and hasConverged() == false; the status and
 // message are available through lastStatus() / lastError().
 #pragma once
 
+#include <algorithm>
 #include <array>
 #include <cstddef>
 #include <cstring>
 #include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../ndt_hip.h"
 
-#if !defined(NDT_HIP_WITH_PCL)
+#if !defined(NDT_HIP_WITH_EIGEN)
 #if defined(__has_include)
+#if __has_include(<Eigen/Core>)
+#define NDT_HIP_WITH_EIGEN 1
+#endif
+#endif
+#endif
+#ifndef NDT_HIP_WITH_EIGEN
+#define NDT_HIP_WITH_EIGEN 0
+#endif
+
+#if !defined(NDT_HIP_WITH_PCL)
+#if NDT_HIP_WITH_EIGEN && defined(__has_include)
 #if __has_include(<pcl/registration/registration.h>)
 #define NDT_HIP_WITH_PCL 1
 #endif
@@ -37,67 +63,142 @@
 #define NDT_HIP_WITH_PCL 0
 #endif
 
+#if !defined(NDT_HIP_WITH_GTSAM)
+#if NDT_HIP_WITH_EIGEN && defined(__has_include)
+#if __has_include(<gtsam/geometry/Pose3.h>)
+#define NDT_HIP_WITH_GTSAM 1
+#endif
+#endif
+#endif
+#ifndef NDT_HIP_WITH_GTSAM
+#define NDT_HIP_WITH_GTSAM 0
+#endif
+
+#if NDT_HIP_WITH_EIGEN
+#include <Eigen/Core>
+#endif
 #if NDT_HIP_WITH_PCL
 #include <pcl/point_cloud.h>
 #include <pcl/registration/registration.h>
-#include <Eigen/Core>
+#endif
+#if NDT_HIP_WITH_GTSAM
+#include <gtsam/geometry/Pose3.h>
 #endif
 
 namespace ndt_hip {
 
-// same order as pclomp::NeighborSearchMethod
+// same order as pclomp::NeighborSearchMethod (ref: run/pipeline.cpp:471-480)
 enum NeighborSearchMethod { KDTREE = NDT_KDTREE, DIRECT26 = NDT_DIRECT26, DIRECT7 = NDT_DIRECT7, DIRECT1 = NDT_DIRECT1 };
+// svn_ndt::NeighborSearchMethod (ref: extern/svn_ndt/include/svn_ndt.h:30-35)
+enum class SvnNeighborSearchMethod { KDTREE, DIRECT7, DIRECT1 };
 
-using Matrix4f = std::array<float, 16>;  // column-major, Eigen::Matrix4f layout
+// ---- value types ----------------------------------------------------------------------------
+#if NDT_HIP_WITH_EIGEN
+using Matrix4f = Eigen::Matrix<float, 4, 4>;
+using Matrix4d = Eigen::Matrix<double, 4, 4>;
+using Matrix6d = Eigen::Matrix<double, 6, 6>;
+using Matrix3d = Eigen::Matrix<double, 3, 3>;
+using Vector3d = Eigen::Matrix<double, 3, 1>;
+#else
+// column-major like Eigen's default, same accessors: data(), (r, c), [i]
+template <typename T, int R, int C>
+struct Mat {
+  T m[R * C];
+  T* data() { return m; }
+  const T* data() const { return m; }
+  T& operator()(int r, int c) { return m[c * R + r]; }
+  const T& operator()(int r, int c) const { return m[c * R + r]; }
+  T& operator[](int i) { return m[i]; }
+  const T& operator[](int i) const { return m[i]; }
+  bool operator==(const Mat& o) const { return std::equal(m, m + R * C, o.m); }
+  bool operator!=(const Mat& o) const { return !(*this == o); }
+};
+using Matrix4f = Mat<float, 4, 4>;
+using Matrix4d = Mat<double, 4, 4>;
+using Matrix6d = Mat<double, 6, 6>;
+using Matrix3d = Mat<double, 3, 3>;
+using Vector3d = Mat<double, 3, 1>;
+#endif
+
+namespace detail {
+template <class M>
+inline M from_rowmajor(const double* a, int rows, int cols) {
+  M out;
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c) out(r, c) = a[cols * r + c];
+  return out;
+}
+template <class M>
+inline void to_rowmajor(const M& in, int rows, int cols, double* a) {
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c) a[cols * r + c] = in(r, c);
+}
+template <class M, class S>
+inline M from_colmajor(const S* a, int rows, int cols) {
+  M out;
+  for (int c = 0; c < cols; ++c)
+    for (int r = 0; r < rows; ++r) out(r, c) = a[rows * c + r];
+  return out;
+}
+template <class M, class S>
+inline void to_colmajor(const M& in, int rows, int cols, S* a) {
+  for (int c = 0; c < cols; ++c)
+    for (int r = 0; r < rows; ++r) a[rows * c + r] = (S)in(r, c);
+}
+}  // namespace detail
 
 inline Matrix4f identity4f() {
-  Matrix4f m{};
-  m[0] = m[5] = m[10] = m[15] = 1.0f;
-  return m;
+  const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  return detail::from_colmajor<Matrix4f>(I, 4, 4);
 }
 
-// mirrors pclomp::NdtResult (fields the drivers read: iteration_num, hessian)
+// pclomp::NdtResult (fields the drivers read: iteration_num, hessian -- run/pipeline.cpp:567-568,
+// 594; run/pipeline_ligo_tc.cpp:536-538)
 struct NdtResult {
   Matrix4f pose = identity4f();
   float transform_probability = 0.0f;
   float nearest_voxel_transformation_likelihood = 0.0f;
   int iteration_num = 0;
-  std::array<double, 36> hessian{};  // row-major 6x6 of the maximised score
-  // -(hessian + eps I)^-1 in the block order the drivers hand to GTSAM
+  Matrix6d hessian{};  // of the maximised score: the drivers form cov = -(hessian + 1e-6 I)^-1
+  // that covariance, optionally in the block order the drivers hand to GTSAM
   // (ref: run/pipeline.cpp:594-603, src/registercallback.cpp:170-186); false if singular
-  bool covarianceForGtsam(std::array<double, 36>& cov, double eps = 1e-6, bool gtsam_order = true) const {
-    return ndt_result_covariance(hessian.data(), eps, gtsam_order ? 1 : 0, cov.data()) == NDT_OK;
+  bool covarianceForGtsam(Matrix6d& cov, double eps = 1e-6, bool gtsam_order = true) const {
+    double h[36], c[36];
+    detail::to_rowmajor(hessian, 6, 6, h);
+    if (ndt_result_covariance(h, eps, gtsam_order ? 1 : 0, c) != NDT_OK) return false;
+    cov = detail::from_rowmajor<Matrix6d>(c, 6, 6);
+    return true;
   }
-#if NDT_HIP_WITH_PCL
-  Eigen::Matrix4f poseEigen() const { return Eigen::Map<const Eigen::Matrix4f>(pose.data()); }
-  Eigen::Matrix<double, 6, 6> hessianEigen() const {
-    return Eigen::Map<const Eigen::Matrix<double, 6, 6, Eigen::RowMajor>>(hessian.data());
-  }
-#endif
 };
 
-// getTargetCells(): the accessors extractNdtData() uses (ref: include/pipeline.hpp:175-206)
+// getTargetCells(): what extractNdtData() uses (ref: include/pipeline.hpp:175-206), i.e.
+// pclomp::VoxelGridCovariance<PointT>: getLeaves() iterable as {index, leaf} in ascending index
+// order, getMinPointPerVoxel(), getLeafCenter(index); Leaf accessors returning Eigen values.
 class TargetGrid {
  public:
   struct Leaf {
     ndt_leaf d;
     int getPointCount() const { return d.point_count; }
-    const double* getMean() const { return d.mean; }
-    const double* getCov() const { return d.cov; }
-    const double* getInverseCov() const { return d.icov; }
-    const double* getEvecs() const { return d.evecs; }
-    const double* getEvals() const { return d.evals; }
+    Vector3d getMean() const { return detail::from_colmajor<Vector3d>(d.mean, 3, 1); }
+    Matrix3d getCov() const { return detail::from_rowmajor<Matrix3d>(d.cov, 3, 3); }
+    Matrix3d getInverseCov() const { return detail::from_rowmajor<Matrix3d>(d.icov, 3, 3); }
+    Matrix3d getEvecs() const { return detail::from_rowmajor<Matrix3d>(d.evecs, 3, 3); }  // columns = eigenvectors
+    Vector3d getEvals() const { return detail::from_colmajor<Vector3d>(d.evals, 3, 1); }
   };
-  struct Entry {
-    size_t first;  // voxel index
-    Leaf second;
-  };
+  using Entry = std::pair<size_t, Leaf>;  // {voxel index, leaf}
   const std::vector<Entry>& getLeaves() const { return leaves_; }
   int getMinPointPerVoxel() const { return min_points_; }
-  std::array<float, 3> getLeafCenter(size_t index) const {
-    for (const Entry& e : leaves_)
-      if (e.first == index) return {e.second.d.center[0], e.second.d.center[1], e.second.d.center[2]};
-    return {0.0f, 0.0f, 0.0f};
+  // O(log V): the leaves are kept in ascending index order
+  const Leaf* getLeaf(size_t index) const {
+    auto it = std::lower_bound(leaves_.begin(), leaves_.end(), index,
+                               [](const Entry& e, size_t i) { return e.first < i; });
+    return (it != leaves_.end() && it->first == index) ? &it->second : nullptr;
+  }
+  Vector3d getLeafCenter(size_t index) const {
+    double c[3] = {0.0, 0.0, 0.0};
+    if (const Leaf* l = getLeaf(index))
+      for (int a = 0; a < 3; ++a) c[a] = (double)l->d.center[a];
+    return detail::from_colmajor<Vector3d>(c, 3, 1);
   }
   std::vector<Entry> leaves_;
   int min_points_ = 6;
@@ -128,8 +229,16 @@ class NormalDistributionsTransform
  public:
   using PointCloudSource = PointCloud<PointSource>;
   using PointCloudTarget = PointCloud<PointTarget>;
+#if NDT_HIP_WITH_PCL
+  // whatever smart pointer this PCL uses (std:: since 1.11, boost:: before), so that
+  // `registerCallback.registration = ndt_omp;` (ref: run/pipeline.cpp:481) converts
+  using Base = pcl::Registration<PointSource, PointTarget>;
+  using Ptr = typename std::pointer_traits<typename Base::Ptr>::template rebind<NormalDistributionsTransform<PointSource, PointTarget>>;
+  using ConstPtr = typename std::pointer_traits<typename Base::Ptr>::template rebind<const NormalDistributionsTransform<PointSource, PointTarget>>;
+#else
   using Ptr = std::shared_ptr<NormalDistributionsTransform<PointSource, PointTarget>>;
   using ConstPtr = std::shared_ptr<const NormalDistributionsTransform<PointSource, PointTarget>>;
+#endif
 
   NormalDistributionsTransform() {
     ndt_default_params(&prm_);
@@ -154,69 +263,101 @@ class NormalDistributionsTransform
   void setOutlierRatio(double o) { prm_.outlier_ratio = o; push(); }
   double getOulierRatio() const { return prm_.outlier_ratio; }  // sic, the PCL spelling
   void setNeighborhoodSearchMethod(NeighborSearchMethod m) { prm_.search_method = (int)m; push(); }
+  NeighborSearchMethod getNeighborhoodSearchMethod() const { return (NeighborSearchMethod)prm_.search_method; }
   void setRegularizationScaleFactor(float k) { prm_.regularization_scale_factor = k; push(); }
   void setMinPointPerVoxel(int n) { prm_.min_points_per_voxel = n; push(); }
+  void setTransformationEpsilon(double e) {
 #if NDT_HIP_WITH_PCL
-  void setTransformationEpsilon(double e) { this->transformation_epsilon_ = e; prm_.trans_epsilon = e; push(); }
-  void setMaximumIterations(int n) { this->max_iterations_ = n; prm_.max_iterations = n; push(); }
-  void setRegularizationPose(const Eigen::Matrix4f& T) { status_ = ndt_set_regularization_pose(h_, T.data()); }
-#else
-  void setTransformationEpsilon(double e) { prm_.trans_epsilon = e; push(); }
-  void setMaximumIterations(int n) { prm_.max_iterations = n; push(); }
-  void setRegularizationPose(const Matrix4f& T) { status_ = ndt_set_regularization_pose(h_, T.data()); }
+    this->transformation_epsilon_ = e;
 #endif
-  void unsetRegularizationPose() { status_ = ndt_clear_regularization_pose(h_); }
+    prm_.trans_epsilon = e;
+    push();
+  }
+  void setMaximumIterations(int n) {
+#if NDT_HIP_WITH_PCL
+    this->max_iterations_ = n;
+#endif
+    prm_.max_iterations = n;
+    push();
+  }
+  void setRegularizationPose(const Matrix4f& T) {  // ref: run/pipeline_ligo_tc.cpp:531
+    float a[16];
+    detail::to_colmajor(T, 4, 4, a);
+    status_ = h_ ? ndt_set_regularization_pose(h_, a) : NDT_ERR_NO_DEVICE;
+  }
+  void unsetRegularizationPose() { status_ = h_ ? ndt_clear_regularization_pose(h_) : NDT_ERR_NO_DEVICE; }
+  // every engine parameter at once (hessian_mode, cov_mode, add_ridge, use_line_search, ...)
+  const ndt_params& params() const { return prm_; }
+  void setParams(const ndt_params& p) { const int dev = prm_.device_id; prm_ = p; prm_.device_id = dev; push(); }
 
   // ---- clouds ----
 #if NDT_HIP_WITH_PCL
-  void setInputTarget(const typename pcl::Registration<PointSource, PointTarget>::PointCloudTargetConstPtr& cloud) override {
-    pcl::Registration<PointSource, PointTarget>::setInputTarget(cloud);
+  void setInputTarget(const typename Base::PointCloudTargetConstPtr& cloud) override {
+    Base::setInputTarget(cloud);
+    // pcl::Registration::initCompute() would build a FLANN kd-tree over the whole target on the
+    // next align() (hundreds of ms for a 1M-point map); NDT never queries it
+    this->target_cloud_updated_ = false;
     uploadTarget(cloud.get());
   }
-  void setInputSource(const typename pcl::Registration<PointSource, PointTarget>::PointCloudSourceConstPtr& cloud) override {
-    pcl::Registration<PointSource, PointTarget>::setInputSource(cloud);
+  void setInputSource(const typename Base::PointCloudSourceConstPtr& cloud) override {
+    Base::setInputSource(cloud);
+    this->source_cloud_updated_ = false;
     uploadSource(cloud.get());
   }
 #else
   void setInputTarget(const typename PointCloudTarget::ConstPtr& cloud) { uploadTarget(cloud.get()); }
-  void setInputSource(const typename PointCloudSource::ConstPtr& cloud) { source_ = cloud; uploadSource(cloud.get()); }
+  void setInputSource(const typename PointCloudSource::ConstPtr& cloud) { uploadSource(cloud.get()); }
 #endif
 
   // ---- registration ----
+  // public in pclomp too (ref: extern/svn_ndt/test/test_svn_ndt.cpp:171); called by
+  // pcl::Registration::align(output, guess) in the PCL face
+  void computeTransformation(PointCloudSource& output, const Matrix4f& guess)
 #if NDT_HIP_WITH_PCL
-  // called by pcl::Registration::align(output, guess)
-  void computeTransformation(PointCloudSource& output, const Eigen::Matrix4f& guess) override {
-    run(guess.data());
-    this->final_transformation_ = Eigen::Map<const Eigen::Matrix4f>(res_.final_transformation);
+      override
+#endif
+  {
+    float g[16];
+    detail::to_colmajor(guess, 4, 4, g);
+    run(g);
+#if NDT_HIP_WITH_PCL
+    this->final_transformation_ = detail::from_colmajor<Matrix4f>(res_.final_transformation, 4, 4);
     this->transformation_ = this->final_transformation_;
     this->converged_ = res_.converged != 0;
     this->nr_iterations_ = res_.iterations;
+#endif
     fillOutput(output);
   }
-#else
-  void computeTransformation(PointCloudSource& output, const Matrix4f& guess) {
-    run(guess.data());
-    fillOutput(output);
-  }
+#if !NDT_HIP_WITH_PCL
   void align(PointCloudSource& output, const Matrix4f& guess = identity4f()) { computeTransformation(output, guess); }
-  Matrix4f getFinalTransformation() const {
-    Matrix4f m;
-    std::memcpy(m.data(), res_.final_transformation, sizeof(float) * 16);
-    return m;
-  }
+  Matrix4f getFinalTransformation() const { return detail::from_colmajor<Matrix4f>(res_.final_transformation, 4, 4); }
   bool hasConverged() const { return res_.converged != 0; }
 #endif
   int getFinalNumIteration() const { return res_.iterations; }
   double getTransformationProbability() const { return res_.transform_probability; }
   double getNearestVoxelTransformationLikelihood() const { return res_.nearest_voxel_transformation_likelihood; }
 
+  // scoring-only calls of pclomp: score of `cloud` under transform T against the
+  // current target, no gradient, nothing about the engine's source / result changes except the
+  // source cloud (replaced by `cloud`, as pclomp's versions take the cloud to score)
+  template <class Cloud>
+  double calculateTransformationProbability(const Cloud& cloud, const Matrix4f& T = identity4f()) {
+    ndt_score s;
+    return scoreCloud(cloud, T, &s) ? s.transform_probability : 0.0;
+  }
+  template <class Cloud>
+  double calculateNearestVoxelTransformationLikelihood(const Cloud& cloud, const Matrix4f& T = identity4f()) {
+    ndt_score s;
+    return scoreCloud(cloud, T, &s) ? s.nearest_voxel_transformation_likelihood : 0.0;
+  }
+
   NdtResult getResult() const {
     NdtResult r;
-    std::memcpy(r.pose.data(), res_.final_transformation, sizeof(float) * 16);
+    r.pose = detail::from_colmajor<Matrix4f>(res_.final_transformation, 4, 4);
     r.transform_probability = (float)res_.transform_probability;
     r.nearest_voxel_transformation_likelihood = (float)res_.nearest_voxel_transformation_likelihood;
     r.iteration_num = res_.iterations;
-    std::memcpy(r.hessian.data(), res_.hessian, sizeof(double) * 36);
+    r.hessian = detail::from_rowmajor<Matrix6d>(res_.hessian, 6, 6);
     return r;
   }
 
@@ -225,10 +366,11 @@ class NormalDistributionsTransform
     ndt_grid_info gi;
     grid_.leaves_.clear();
     grid_.min_points_ = prm_.min_points_per_voxel < 3 ? 3 : prm_.min_points_per_voxel;
-    if (ndt_get_grid_info(h_, &gi) == NDT_OK && gi.n_leaves > 0) {
+    if (h_ && ndt_get_grid_info(h_, &gi) == NDT_OK && gi.n_leaves > 0) {
       std::vector<ndt_leaf> buf((size_t)gi.n_leaves);
-      int64_t n = ndt_export_leaves(h_, buf.data(), buf.size());
-      for (int64_t i = 0; i < n; ++i) grid_.leaves_.push_back({(size_t)buf[i].index, TargetGrid::Leaf{buf[i]}});
+      const int64_t n = ndt_export_leaves(h_, buf.data(), buf.size());  // ascending index
+      grid_.leaves_.reserve(n > 0 ? (size_t)n : 0);
+      for (int64_t i = 0; i < n; ++i) grid_.leaves_.emplace_back((size_t)buf[i].index, TargetGrid::Leaf{buf[i]});
     }
     return grid_;
   }
@@ -250,13 +392,16 @@ class NormalDistributionsTransform
   }
   void setInputSourceFromKeyframe(int64_t id) {
     status_ = h_ ? ndt_set_source_from_keyframe(h_, id) : NDT_ERR_NO_DEVICE;
-    if (status_ == NDT_OK) { source_.reset(); n_src_ = 0; }  // align()'s output cloud is not filled on this path
+    if (status_ == NDT_OK) n_src_ = 0;  // align()'s output cloud is not filled on this path
   }
 
   int lastStatus() const { return status_; }
   std::string lastError() const { return h_ ? ndt_last_error(h_) : "no engine (ndt_create failed: GPU required)"; }
   const ndt_result& rawResult() const { return res_; }
   ndt_handle* handle() { return h_; }
+  // `output` of align(): the drivers never read it (ref: run/pipeline.cpp:552,561), so it is
+  // only produced (on the device) when asked for
+  void setFillOutputCloud(bool on) { fill_output_ = on; }
 
  private:
   void push() { if (h_) status_ = ndt_set_params(h_, &prm_); }
@@ -274,6 +419,16 @@ class NormalDistributionsTransform
     status_ = n_src_ ? ndt_set_source(h_, &c->points[0].x, n_src_, sizeof(c->points[0]))
                      : ndt_set_source(h_, nullptr, 0, 12);
   }
+  template <class Cloud>
+  bool scoreCloud(const Cloud& cloud, const Matrix4f& T, ndt_score* s) {
+    if (!h_) { status_ = NDT_ERR_NO_DEVICE; return false; }
+    uploadSource(&cloud);
+    if (status_ != NDT_OK) return false;
+    float a[16];
+    detail::to_colmajor(T, 4, 4, a);
+    status_ = ndt_score_transform(h_, a, s);
+    return status_ == NDT_OK;
+  }
   void run(const float* guess) {
     std::memset(&res_, 0, sizeof(res_));
     std::memcpy(res_.final_transformation, guess, sizeof(float) * 16);
@@ -284,8 +439,6 @@ class NormalDistributionsTransform
       res_.converged = 0;
     }
   }
-  // `output` of align(): the source transformed by the result.  The reference's drivers never
-  // read it (ref: run/pipeline.cpp:552,561), so it is filled on the device only when asked.
   void fillOutput(PointCloudSource& output) {
     if (!fill_output_ || !h_ || n_src_ == 0) return;
     std::vector<float> xyz(3 * n_src_);
@@ -298,10 +451,6 @@ class NormalDistributionsTransform
     }
   }
 
- public:
-  void setFillOutputCloud(bool on) { fill_output_ = on; }
-
- private:
   ndt_params prm_{};
   ndt_handle* h_ = nullptr;
   ndt_result res_{};
@@ -309,19 +458,19 @@ class NormalDistributionsTransform
   size_t n_src_ = 0;
   bool fill_output_ = false;
   TargetGrid grid_;
-#if !NDT_HIP_WITH_PCL
-  typename PointCloudSource::ConstPtr source_;
-#endif
 };
 
 // ---------------------------------------------------------------------------------------------
 // svn_ndt::SvnNormalDistributionsTransform-shaped adapter (ref: extern/svn_ndt/include/svn_ndt.h:
-// 100-182; driver run/pipeline_lo_svn.cpp:301-319,387-388).  Poses cross as 4x4 double,
-// column-major (gtsam::Pose3::matrix().data()); build a gtsam::Pose3 from SvnNdtResult::final_pose
-// on the caller's side.  Stage 1 of every SVN iteration is one batched kernel launch.
-struct SvnNdtResult {
-  std::array<double, 16> final_pose{};        // column-major 4x4
-  std::array<double, 36> final_covariance{};  // row-major, GTSAM tangent order [rot, trans]
+// 100-182; driver run/pipeline_lo_svn.cpp:299-320,387-388).  Stage 1 of every SVN iteration is
+// one batched kernel launch.
+struct SvnNdtResult {  // svn_ndt::SvnNdtResult (svn_ndt.h:40-51)
+#if NDT_HIP_WITH_GTSAM
+  gtsam::Pose3 final_pose;
+#else
+  Matrix4d final_pose{};
+#endif
+  Matrix6d final_covariance{};  // GTSAM tangent order [rot, trans]
   bool converged = false;
   int iterations = 0;
 };
@@ -329,6 +478,9 @@ struct SvnNdtResult {
 template <typename PointSource, typename PointTarget>
 class SvnNormalDistributionsTransform {
  public:
+  using PointCloudSource = PointCloud<PointSource>;
+  using PointCloudTarget = PointCloud<PointTarget>;
+
   SvnNormalDistributionsTransform() {
     ndt_default_params(&prm_);
     prm_.hessian_mode = NDT_HESSIAN_GAUSS_NEWTON;  // svn_ndt.h:314
@@ -340,18 +492,32 @@ class SvnNormalDistributionsTransform {
   SvnNormalDistributionsTransform(const SvnNormalDistributionsTransform&) = delete;
   SvnNormalDistributionsTransform& operator=(const SvnNormalDistributionsTransform&) = delete;
 
+  // clamps as the reference's setters (svn_ndt.h:118-160)
   void setResolution(float r) { prm_.resolution = r; push(); }
+  float getResolution() const { return prm_.resolution; }
   void setMinPointPerVoxel(int n) { prm_.min_points_per_voxel = n; push(); }
   void setOutlierRatio(double o) { prm_.outlier_ratio = o; push(); }
+  double getOutlierRatio() const { return prm_.outlier_ratio; }
   void setNeighborhoodSearchMethod(NeighborSearchMethod m) { prm_.search_method = (int)m; push(); }
+  void setNeighborhoodSearchMethod(SvnNeighborSearchMethod m) {
+    prm_.search_method = m == SvnNeighborSearchMethod::KDTREE ? NDT_KDTREE
+                       : m == SvnNeighborSearchMethod::DIRECT1 ? NDT_DIRECT1 : NDT_DIRECT7;
+    push();
+  }
   void setUseGaussNewtonHessian(bool on) { prm_.hessian_mode = on ? NDT_HESSIAN_GAUSS_NEWTON : NDT_HESSIAN_FULL; push(); }
-  void setNumThreads(int n) { prm_.num_threads = n; push(); }
-  void setParticleCount(int k) { svn_.particle_count = k; }
-  void setMaxIterations(int n) { svn_.max_iterations = n; }
-  void setKernelBandwidth(double h) { svn_.kernel_bandwidth = h; }
-  void setStepSize(double s) { svn_.step_size = s; }
-  void setEarlyStopThreshold(double t) { svn_.stop_threshold = t; }
-  void setParticleSeed(uint64_t seed) { seed_ = seed; }  // the reference seeds from the wall clock
+  void setNumThreads(int n) { prm_.num_threads = n > 0 ? n : 1; push(); }
+  int getNumThreads() const { return prm_.num_threads; }
+  void setParticleCount(int k) { svn_.particle_count = k > 0 ? k : 1; }
+  int getParticleCount() const { return svn_.particle_count; }
+  void setMaxIterations(int n) { svn_.max_iterations = n > 0 ? n : 1; }
+  int getMaxIterations() const { return svn_.max_iterations; }
+  void setKernelBandwidth(double h) { svn_.kernel_bandwidth = h > 1e-9 ? h : 1e-9; }
+  double getKernelBandwidth() const { return svn_.kernel_bandwidth; }
+  void setStepSize(double s) { svn_.step_size = s > 0 ? s : 1e-6; }
+  double getStepSize() const { return svn_.step_size; }
+  void setEarlyStopThreshold(double t) { svn_.stop_threshold = t >= 0 ? t : 1e-4; }
+  double getEarlyStopThreshold() const { return svn_.stop_threshold; }
+  void setParticleSeed(uint64_t seed) { seed_ = seed; }  // the reference seeds from the wall clock (:712)
 
   template <class CloudPtr>
   void setInputTarget(const CloudPtr& cloud) {
@@ -361,30 +527,51 @@ class SvnNormalDistributionsTransform {
                   : ndt_set_target(h_, nullptr, 0, 12);
   }
 
-  // align(source_cloud, prior_mean): prior_pose = gtsam::Pose3::matrix().data()
+  // align(source_cloud, prior_mean) with the prior as 16 column-major doubles
   template <class Cloud>
   SvnNdtResult align(const Cloud& source, const double prior_pose_colmajor[16]) {
-    SvnNdtResult r;
-    std::memcpy(r.final_pose.data(), prior_pose_colmajor, sizeof(double) * 16);
-    for (int i = 0; i < 6; ++i) r.final_covariance[7 * i] = 1.0;  // failure convention, ref :682-702
-    if (!h_) { status_ = NDT_ERR_NO_DEVICE; return r; }
-    status_ = source.points.empty() ? ndt_set_source(h_, nullptr, 0, 12)
-                                    : ndt_set_source(h_, &source.points[0].x, source.points.size(), sizeof(source.points[0]));
-    if (status_ != NDT_OK || svn_.particle_count <= 0) return r;
-    std::vector<double> particles(16 * (size_t)svn_.particle_count);
-    ndt_svn_sample_particles(prior_pose_colmajor, svn_.particle_count, seed_++, particles.data());
     ndt_svn_result out;
-    status_ = ndt_svn_align(h_, &svn_, prior_pose_colmajor, particles.data(), &out);
-    if (status_ != NDT_OK) return r;
-    std::memcpy(r.final_pose.data(), out.final_pose, sizeof(double) * 16);
-    std::memcpy(r.final_covariance.data(), out.final_covariance, sizeof(double) * 36);
+    std::memset(&out, 0, sizeof(out));
+    std::memcpy(out.final_pose, prior_pose_colmajor, sizeof(double) * 16);
+    for (int i = 0; i < 6; ++i) out.final_covariance[7 * i] = 1.0;  // failure convention, ref :682-702
+    if (!h_) {
+      status_ = NDT_ERR_NO_DEVICE;
+    } else {
+      status_ = source.points.empty() ? ndt_set_source(h_, nullptr, 0, 12)
+                                      : ndt_set_source(h_, &source.points[0].x, source.points.size(), sizeof(source.points[0]));
+      if (status_ == NDT_OK && svn_.particle_count > 0) {
+        std::vector<double> particles(16 * (size_t)svn_.particle_count);
+        ndt_svn_sample_particles(prior_pose_colmajor, svn_.particle_count, seed_++, particles.data());
+        ndt_svn_result tmp;
+        status_ = ndt_svn_align(h_, &svn_, prior_pose_colmajor, particles.data(), &tmp);
+        if (status_ == NDT_OK) out = tmp;
+      }
+    }
+    SvnNdtResult r;
+    const Matrix4d P = detail::from_colmajor<Matrix4d>(out.final_pose, 4, 4);
+#if NDT_HIP_WITH_GTSAM
+    r.final_pose = gtsam::Pose3(P);
+#else
+    r.final_pose = P;
+#endif
+    r.final_covariance = detail::from_rowmajor<Matrix6d>(out.final_covariance, 6, 6);
     r.converged = out.converged != 0;
     r.iterations = out.iterations;
     return r;
   }
+#if NDT_HIP_WITH_GTSAM
+  // the reference's signature (svn_ndt.h:178-181; call site run/pipeline_lo_svn.cpp:388)
+  template <class Cloud>
+  SvnNdtResult align(const Cloud& source, const gtsam::Pose3& prior_mean) {
+    double a[16];
+    detail::to_colmajor(prior_mean.matrix(), 4, 4, a);
+    return align(source, a);
+  }
+#endif
 
   int lastStatus() const { return status_; }
   std::string lastError() const { return h_ ? ndt_last_error(h_) : "no engine (ndt_create failed: GPU required)"; }
+  ndt_handle* handle() { return h_; }
 
  private:
   void push() { if (h_) status_ = ndt_set_params(h_, &prm_); }

@@ -414,9 +414,33 @@ static int kd_neighbors(const oracle_grid* g, const float p[3], int64_t out_rank
   return n;
 }
 
+// DIRECT26 [RECALLED]: pclomp's getNeighborhoodAtPoint -- the 3x3x3 block of cells around the
+// point's own cell, enumerated in INTEGER index space (ijk = floor(p * inv_leaf), displacement
+// kept when min_b <= ijk + d <= max_b), every valid leaf found there is a neighbour (27 cells,
+// the centre included; "26" counts the surrounding ones).  The reference tree only carries the
+// enum value (run/pipeline.cpp:471-480) and a commented-out stub (svn_ndt_impl.hpp:581-583);
+// the enumeration order is x fastest, then y, then z.
+static int direct26_neighbors(const oracle_grid* g, const float p[3], int64_t out_rank[27]) {
+  if (!g->built) return 0;
+  const int c[3] = {cell_coord(p[0], g->inv_leaf, g->min_b[0]), cell_coord(p[1], g->inv_leaf, g->min_b[1]),
+                    cell_coord(p[2], g->inv_leaf, g->min_b[2])};
+  int n = 0;
+  for (int dz = -1; dz <= 1; ++dz)
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int i0 = c[0] + dx, i1 = c[1] + dy, i2 = c[2] + dz;
+        if (i0 < 0 || i1 < 0 || i2 < 0 || i0 >= g->div_b[0] || i1 >= g->div_b[1] || i2 >= g->div_b[2]) continue;
+        const int64_t idx = static_cast<int64_t>(i0 * g->divb_mul[0] + i1 * g->divb_mul[1] + i2 * g->divb_mul[2]);
+        auto it = g->cell2rank.find(idx);
+        if (it != g->cell2rank.end()) out_rank[n++] = it->second;
+      }
+  return n;
+}
+
 extern "C" int oracle_grid_neighbors(const oracle_grid* g, const float p[3], int method,
                                      int64_t out_rank[27]) {
   if (method == ORACLE_KDTREE) return kd_neighbors(g, p, out_rank);
+  if (method == ORACLE_DIRECT26) return direct26_neighbors(g, p, out_rank);
   int n = 0;
   int64_t r = leaf_rank_at(g, p[0], p[1], p[2]);
   if (r >= 0) out_rank[n++] = r;

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-enum { ORACLE_DIRECT1 = 1, ORACLE_DIRECT7 = 7, ORACLE_KDTREE = 27 };
+enum { ORACLE_DIRECT1 = 1, ORACLE_DIRECT7 = 7, ORACLE_DIRECT26 = 26, ORACLE_KDTREE = 27 };
 enum { ORACLE_HESSIAN_FULL = 0, ORACLE_HESSIAN_GAUSS_NEWTON = 1 };
 /* covariance normalisation: vendored svn code uses /n then *n/(n-1)
  * (voxel_grid_covariance_impl.hpp:287-291); upstream PCL/pclomp is recalled
@@ -54,7 +54,7 @@ typedef struct oracle_params {
   double step_size;            /* More-Thuente step_max */
   double trans_epsilon;        /* convergence threshold on step length */
   int max_iterations;
-  int search_method;           /* ORACLE_DIRECT1 / ORACLE_DIRECT7 */
+  int search_method;           /* ORACLE_DIRECT1 / ORACLE_DIRECT7 / ORACLE_DIRECT26 [RECALLED] / ORACLE_KDTREE */
   int min_points_per_voxel;    /* voxel_grid_covariance.h:153 default 6 */
   double eig_inflation_ratio;  /* voxel_grid_covariance.h:154 default 0.01 */
   int hessian_mode;            /* full analytic (pclomp) or Gauss-Newton (svn default) */

@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libndt_oracle.so")
 
-DIRECT1, DIRECT7, KDTREE = 1, 7, 27
+DIRECT1, DIRECT7, DIRECT26, KDTREE = 1, 7, 26, 27
 HESSIAN_FULL, HESSIAN_GAUSS_NEWTON = 0, 1
 COV_SVN, COV_PCL_RECALLED = 0, 1
 PAIR_SVN, PAIR_PCLOMP_RECALLED = 0, 1

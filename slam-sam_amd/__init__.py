@@ -27,6 +27,8 @@ EVAL_WORDS = 32
 KDTREE, DIRECT26, DIRECT7, DIRECT1 = 0, 1, 2, 3
 HESSIAN_FULL, HESSIAN_GAUSS_NEWTON = 0, 1
 COV_SVN, COV_PCL_RECALLED = 0, 1
+WAIT_SPIN, WAIT_BLOCK = 0, 1
+PRESET_DEFAULT, PRESET_PCLOMP_RECALLED, PRESET_SVN = 0, 1, 2
 
 STATUS = {0: "NDT_OK", -1: "NDT_ERR_INVALID_ARG", -2: "NDT_ERR_NO_DEVICE", -3: "NDT_ERR_HIP",
           -4: "NDT_ERR_NO_TARGET", -5: "NDT_ERR_NO_SOURCE", -6: "NDT_ERR_GRID_OVERFLOW",
@@ -46,7 +48,7 @@ class Params(C.Structure):
         ("min_points_per_voxel", C.c_int), ("eig_inflation_ratio", C.c_double),
         ("hessian_mode", C.c_int), ("cov_mode", C.c_int), ("add_ridge", C.c_int),
         ("use_line_search", C.c_int), ("regularization_scale_factor", C.c_float),
-        ("num_threads", C.c_int), ("device_id", C.c_int),
+        ("num_threads", C.c_int), ("device_id", C.c_int), ("wait_mode", C.c_int),
     ]
 
 
@@ -57,6 +59,15 @@ class Result(C.Structure):
         ("hessian", C.c_double * 36), ("score", C.c_double), ("transform_probability", C.c_double),
         ("nearest_voxel_transformation_likelihood", C.c_double), ("n_pairs", C.c_int64),
         ("n_points_with_neighbors", C.c_int64), ("ms_total", C.c_double), ("ms_device", C.c_double),
+        ("n_evaluations_reused", C.c_int),
+    ]
+
+
+class Score(C.Structure):
+    _fields_ = [
+        ("score", C.c_double), ("transform_probability", C.c_double),
+        ("nearest_voxel_transformation_likelihood", C.c_double), ("n_pairs", C.c_int64),
+        ("n_points_with_neighbors", C.c_int64),
     ]
 
 
@@ -115,6 +126,7 @@ ABI_SYMBOLS = [
     "ndt_svn_default_params", "ndt_svn_sample_particles", "ndt_svn_align",
     "ndt_keyframe_put", "ndt_keyframe_erase", "ndt_keyframe_count", "ndt_set_target_from_keyframes",
     "ndt_result_covariance", "ndt_set_source_from_keyframe",
+    "ndt_params_preset", "ndt_score_transform", "ndt_comm_info",
 ]
 
 _lib = None
@@ -178,19 +190,33 @@ def lib():
         L.ndt_svn_sample_particles.argtypes = [dp, C.c_int, C.c_uint64, dp]
         L.ndt_svn_align.argtypes = [vp, C.POINTER(SvnParams), dp, dp, C.POINTER(SvnResult)]
         L.ndt_result_covariance.argtypes = [dp, C.c_double, C.c_int, dp]
+        L.ndt_params_preset.argtypes = [C.POINTER(Params), C.c_int]
+        L.ndt_score_transform.argtypes = [vp, fp, C.POINTER(Score)]
+        L.ndt_comm_info.argtypes = [C.c_char_p, C.c_size_t]
         L.ndt_debug_sort_pairs.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, vp]  # test seam, not in the header
         _lib = L
     return _lib
 
 
-def default_params(**kw):
+def default_params(preset=None, **kw):
     p = Params()
     lib().ndt_default_params(C.byref(p))
+    if preset is not None:
+        rc = lib().ndt_params_preset(C.byref(p), int(preset))
+        if rc != 0:
+            raise NdtError(rc, "ndt_params_preset")
     for k, v in kw.items():
         if not hasattr(p, k):
             raise AttributeError(k)
         setattr(p, k, v)
     return p
+
+
+def comm_info():
+    """(ncclGetVersion code, path of the shared object serving the nccl* symbols of the engine)."""
+    buf = C.create_string_buffer(512)
+    v = lib().ndt_comm_info(buf, 512)
+    return v, buf.value.decode()
 
 
 def backend_info():
@@ -244,7 +270,7 @@ def result_to_dict(r):
                 transform_probability=r.transform_probability,
                 nvtl=r.nearest_voxel_transformation_likelihood, n_pairs=r.n_pairs,
                 n_points_with_neighbors=r.n_points_with_neighbors, ms_total=r.ms_total,
-                ms_device=r.ms_device)
+                ms_device=r.ms_device, n_evaluations_reused=r.n_evaluations_reused)
 
 
 class NormalDistributionsTransform:
@@ -399,6 +425,26 @@ class NormalDistributionsTransform:
     def getNumEvaluations(self): return self._raw.n_evaluations
     def getTransformationProbability(self): return self._raw.transform_probability
     def getNearestVoxelTransformationLikelihood(self): return self._raw.nearest_voxel_transformation_likelihood
+
+    def scoreTransform(self, T=None):
+        """Scoring-only evaluation of the current source under T (default identity): dict(score,
+        transform_probability, nvtl, n_pairs, n_points_with_neighbors)."""
+        g = _colmajor(np.eye(4) if T is None else T)
+        sc = Score()
+        self._check(lib().ndt_score_transform(self._h, _fp(g), C.byref(sc)))
+        return dict(score=sc.score, transform_probability=sc.transform_probability,
+                    nvtl=sc.nearest_voxel_transformation_likelihood, n_pairs=sc.n_pairs,
+                    n_points_with_neighbors=sc.n_points_with_neighbors)
+
+    def calculateTransformationProbability(self, cloud, T=None):
+        """pclomp's scoring-only call [RECALLED]: score / #points of `cloud` (already transformed,
+        or moved by T) against the current target."""
+        self.setInputSource(cloud)
+        return self.scoreTransform(T)["transform_probability"]
+
+    def calculateNearestVoxelTransformationLikelihood(self, cloud, T=None):
+        self.setInputSource(cloud)
+        return self.scoreTransform(T)["nvtl"]
 
     def getResult(self):
         """pclomp::NdtResult: iteration_num, hessian, pose, transform_probability, nvtl."""

@@ -151,10 +151,12 @@ int bind_device(ndt_handle* h) {
 
 bool params_valid(const ndt_params* p, std::string* why) {
   if (!(p->resolution > 1e-6f)) { *why = "resolution must be positive"; return false; }
-  if (p->search_method != NDT_DIRECT7 && p->search_method != NDT_DIRECT1 && p->search_method != NDT_KDTREE) {
-    *why = "search method not implemented (KDTREE / DIRECT7 / DIRECT1; pclomp's DIRECT26 has no in-tree statement)";
+  if (p->search_method != NDT_DIRECT7 && p->search_method != NDT_DIRECT1 && p->search_method != NDT_KDTREE &&
+      p->search_method != NDT_DIRECT26) {
+    *why = "unknown search method (KDTREE / DIRECT26 / DIRECT7 / DIRECT1)";
     return false;
   }
+  if (p->wait_mode != NDT_WAIT_SPIN && p->wait_mode != NDT_WAIT_BLOCK) { *why = "unknown wait_mode"; return false; }
   if (!(p->outlier_ratio >= 0.0 && p->outlier_ratio < 1.0)) { *why = "outlier_ratio must be in [0,1)"; return false; }
   if (p->max_iterations < 0) { *why = "max_iterations must be >= 0"; return false; }
   return true;
@@ -316,6 +318,8 @@ EvalConsts make_eval_consts(const ndt_handle* h, bool need_h) {
   gauss_constants((double)h->prm.resolution, h->prm.outlier_ratio, &ec.d1, &ec.d2);
   ec.direct7 = h->prm.search_method == NDT_DIRECT7 ? 1 : 0;
   ec.kdtree = h->prm.search_method == NDT_KDTREE ? 1 : 0;
+  ec.direct26 = h->prm.search_method == NDT_DIRECT26 ? 1 : 0;
+  ec.score_only = 0;
   ec.kd_radius2 = (float)((double)h->prm.resolution * (double)h->prm.resolution);
   ec.need_hessian = need_h ? 1 : 0;
   ec.gauss_newton = h->prm.hessian_mode == NDT_HESSIAN_GAUSS_NEWTON ? 1 : 0;
@@ -378,11 +382,12 @@ int wait_slots(ndt_handle* h, unsigned long long seq) {
 }
 
 // one global evaluation at (p, T): local kernel + cross-rank sum
-int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, Eval* out) {
+int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, Eval* out, bool score_only = false) {
   hipStream_t s = h->stream;
   PoseConsts pc;
   fill_pose_consts(p, T, &pc);
-  const EvalConsts ec = make_eval_consts(h, need_h);
+  EvalConsts ec = make_eval_consts(h, need_h);
+  ec.score_only = score_only ? 1 : 0;
   {
     int rc = ensure_partials(h, derivs_partials_words(h->n_src, 1));
     if (rc) return rc;
@@ -399,7 +404,7 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
     if (rc) return rc;
   }
   double* d_out = dev_out ? h->dres.p : h->result.d;
-  const bool spin = !dev_out && !h->timing;
+  const bool spin = !dev_out && !h->timing && h->prm.wait_mode == NDT_WAIT_SPIN;
   const unsigned long long seq = g_launch_seq.fetch_add(1, std::memory_order_relaxed);
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, s));
   launch_derivatives(h->sx.p, h->sy.p, h->sz.p, h->n_src, h->geom, h->cell2leaf.p, h->rec.p, pc,
@@ -435,8 +440,16 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
     int rc = h->red.allreduce_host(words, EV_WORDS, &h->err);
     if (rc) return rc;
   }
+  // word 31 is zero by construction; the in-kernel final sum raises it when it gave up waiting
+  // for a partial row (a lost hand-off must not look like a converged result), and the kernel
+  // never produces a non-finite score from finite records
+  if (words[EV_FAIL] != 0.0 || !std::isfinite(words[EV_SCORE])) {
+    h->counters_zeroed = 0;  // the ticket words may be stale: re-zero them before the next launch
+    return fail(h, NDT_ERR_HIP, words[EV_FAIL] != 0.0 ? "derivative kernel: a partial row never arrived (hand-off lost)"
+                                                      : "derivative kernel returned a non-finite score");
+  }
   unpack_eval(words, out);
-  finish_eval(h->prm, h->have_reg ? h->reg_pose : nullptr, p, need_h, out);
+  if (!score_only) finish_eval(h->prm, h->have_reg ? h->reg_pose : nullptr, p, need_h, out);
   return NDT_OK;
 }
 
@@ -467,6 +480,26 @@ void ndt_default_params(ndt_params* p) {
   p->regularization_scale_factor = 0.0f;
   p->num_threads = 1;
   p->device_id = -1;
+  p->wait_mode = NDT_WAIT_SPIN;
+}
+
+int ndt_params_preset(ndt_params* p, int preset) {
+  if (!p) return NDT_ERR_INVALID_ARG;
+  switch (preset) {
+    case NDT_PRESET_DEFAULT:
+      p->cov_mode = NDT_COV_SVN; p->hessian_mode = NDT_HESSIAN_FULL; p->add_ridge = 0; p->use_line_search = 1;
+      p->min_points_per_voxel = 6;
+      return NDT_OK;
+    case NDT_PRESET_PCLOMP_RECALLED:
+      p->cov_mode = NDT_COV_PCL_RECALLED; p->hessian_mode = NDT_HESSIAN_FULL; p->add_ridge = 0; p->use_line_search = 1;
+      p->min_points_per_voxel = 6;
+      return NDT_OK;
+    case NDT_PRESET_SVN:  // ref: svn_ndt.h:314, svn_ndt_impl.hpp:650-653, voxel_grid_covariance_impl.hpp:287-291
+      p->cov_mode = NDT_COV_SVN; p->hessian_mode = NDT_HESSIAN_GAUSS_NEWTON; p->add_ridge = 1; p->use_line_search = 1;
+      p->min_points_per_voxel = 6;
+      return NDT_OK;
+  }
+  return NDT_ERR_INVALID_ARG;
 }
 
 int ndt_backend_info(char* buf, size_t cap) {
@@ -548,14 +581,22 @@ int ndt_set_params(ndt_handle* h, const ndt_params* p) {
   if (!h || !p) return NDT_ERR_INVALID_ARG;
   std::string why;
   if (!params_valid(p, &why)) return fail(h, NDT_ERR_INVALID_ARG, why);
-  const bool rebuild = h->have_grid && h->tx.p && h->n_tgt > 0 &&
-                       (std::fabs(p->resolution - h->prm.resolution) > 1e-6f ||
-                        p->min_points_per_voxel != h->prm.min_points_per_voxel ||
-                        p->eig_inflation_ratio != h->prm.eig_inflation_ratio ||
-                        p->cov_mode != h->prm.cov_mode);
+  const bool grid_changed = h->have_grid && (std::fabs(p->resolution - h->prm.resolution) > 1e-6f ||
+                                             p->min_points_per_voxel != h->prm.min_points_per_voxel ||
+                                             p->eig_inflation_ratio != h->prm.eig_inflation_ratio ||
+                                             p->cov_mode != h->prm.cov_mode);
+  const bool rebuild = grid_changed && h->tx.p && h->n_tgt > 0;
   const int dev = h->prm.device_id;
   h->prm = *p;
   h->prm.device_id = dev;  // a handle never migrates
+  if (grid_changed && !rebuild) {
+    // the target came through ndt_set_target_device and was consumed there: the grid cannot be
+    // re-voxelised, and the old one must not be evaluated with the new constants.  The next
+    // align / eval reports NDT_ERR_NO_TARGET until a target is set again.
+    h->have_grid = false;
+    h->n_valid = 0;
+    return NDT_OK;
+  }
   if (rebuild) {
     // setResolution on a loaded target re-voxelises it (ref: svn_ndt_impl.hpp:162-176)
     int rc = bind_device(h);
@@ -721,6 +762,29 @@ int ndt_align(ndt_handle* h, const float guess[16], ndt_result* out) {
   out->ms_device = h->tm.ms_eval_kernel_total - dev_ms0;
   return rc;
 }
+
+int ndt_score_transform(ndt_handle* h, const float T[16], ndt_score* out) {
+  if (!h || !T || !out) return NDT_ERR_INVALID_ARG;
+  std::memset(out, 0, sizeof(*out));
+  int rc = bind_device(h);
+  if (rc) return rc;
+  rc = ready_for_eval(h);
+  if (rc) return rc;
+  double p[6];
+  matrix_to_pose(T, p);  // only feeds the (unused) angle tables
+  Eval e;
+  rc = evaluate(h, p, T, false, &e, /*score_only=*/true);
+  if (rc) return rc;
+  const int64_t n_total = h->n_src_global >= 0 ? h->n_src_global : (int64_t)h->n_src;
+  out->score = e.score;
+  out->transform_probability = n_total > 0 ? e.score / (double)n_total : 0.0;
+  out->nearest_voxel_transformation_likelihood = e.n_with > 0 ? e.nvtl_sum / e.n_with : 0.0;
+  out->n_pairs = (int64_t)e.n_pairs;
+  out->n_points_with_neighbors = (int64_t)e.n_with;
+  return NDT_OK;
+}
+
+int ndt_comm_info(char* path_buf, size_t cap) { return Reducer::library_info(path_buf, cap); }
 
 int ndt_eval_derivatives(ndt_handle* h, const double* poses6, const float* transforms, int K,
                          int compute_hessian, double* out) {

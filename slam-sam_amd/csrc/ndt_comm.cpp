@@ -1,6 +1,7 @@
 // ndt_comm.cpp -- RCCL / shared-memory / hook reduction of evaluation partials.
 #include "ndt_comm.h"
 
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <rccl/rccl.h>
 #include <sys/mman.h>
@@ -9,6 +10,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <thread>
 
@@ -41,6 +43,18 @@ int Reducer::unique_id(void* out128) {
   static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
   std::memcpy(out128, &id, 128);
   return NDT_OK;
+}
+
+int Reducer::library_info(char* path_buf, size_t cap) {
+  int v = 0;
+  if (ncclGetVersion(&v) != ncclSuccess) return NDT_ERR_COMM;
+  if (path_buf && cap) {
+    Dl_info info;
+    const char* name = "?";
+    if (dladdr(reinterpret_cast<void*>(&ncclGetVersion), &info) && info.dli_fname) name = info.dli_fname;
+    snprintf(path_buf, cap, "%s", name);
+  }
+  return v;
 }
 
 int Reducer::init_rccl(const void* id128, int rank, int nranks, std::string* err) {

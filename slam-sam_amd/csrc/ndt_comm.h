@@ -23,6 +23,8 @@ class Reducer {
   int nranks() const { return nranks_; }
 
   static int unique_id(void* out128);
+  // ncclGetVersion() and the shared object that serves the nccl* symbols of this library
+  static int library_info(char* path_buf, size_t cap);
   int init_rccl(const void* id128, int rank, int nranks, std::string* err);
   int init_shm(const char* name, int rank, int nranks, std::string* err);
   int init_hook(ndt_allreduce_fn fn, void* ctx, int rank, int nranks);

@@ -47,7 +47,8 @@ struct PairAcc {
 };
 
 // ref: svn_ndt_impl.hpp:401-447 (guards, exp, factor); accumulation refactored
-// MODE: 0 = score + gradient only, 1 = full analytic Hessian, 2 = Gauss-Newton Hessian.
+// MODE: 0 = score + gradient only, 1 = full analytic Hessian, 2 = Gauss-Newton Hessian,
+// 3 = score only (ndt_score_transform: transform probability / NVTL, no derivatives).
 // A template parameter (not a run-time flag) so each pair is one straight-line block and
 // the compiler is free to keep several records in flight.
 template <int MODE>
@@ -78,8 +79,8 @@ __device__ __forceinline__ void pair_update(PairAcc& a, const VoxelRecord& r, fl
   // v is finite whenever it gets here: the caller replaces a non-finite transformed point by
   // the origin (it has no neighbours, so every f is 0) and stored records are finite, so
   // f * v is an exact zero for a masked pair without zeroing v itself
-  a.w[0] += f * v0; a.w[1] += f * v1; a.w[2] += f * v2;
-  if (MODE != 0) {
+  if (MODE != 3) { a.w[0] += f * v0; a.w[1] += f * v1; a.w[2] += f * v2; }
+  if (MODE == 1 || MODE == 2) {
     a.S[0] += f * r.icov[0]; a.S[1] += f * r.icov[1]; a.S[2] += f * r.icov[2];
     a.S[3] += f * r.icov[3]; a.S[4] += f * r.icov[4]; a.S[5] += f * r.icov[5];
     if (MODE == 1) {
@@ -111,6 +112,12 @@ __device__ __forceinline__ void expand_point(double acc[EV_WORDS], const PairAcc
   acc[EV_NVTL] = a.best;
   acc[EV_NWITH] = a.npairs > 0 ? 1.0 : 0.0;
   acc[EV_NPAIRS] = (double)a.npairs;
+  acc[31] = 0.0;
+  if (MODE == 3) {
+#pragma unroll
+    for (int k = 0; k < 27; ++k) acc[EV_G + k] = 0.0;
+    return;
+  }
 
   // point Jacobian, angular block A (3x3) from the ORIGINAL point (ref :339-363)
   double A10 = (double)dot3f(P.jang + 0, x, y, z), A20 = (double)dot3f(P.jang + 3, x, y, z);
@@ -125,7 +132,6 @@ __device__ __forceinline__ void expand_point(double acc[EV_WORDS], const PairAcc
   acc[EV_G + 3] = A10 * w1 + A20 * w2;
   acc[EV_G + 4] = A01 * w0 + A11 * w1 + A21 * w2;
   acc[EV_G + 5] = A02 * w0 + A12 * w1 + A22 * w2;
-  acc[31] = 0.0;
   if (MODE == 0) {
 #pragma unroll
     for (int k = 0; k < 21; ++k) acc[EV_H + k] = 0.0;
@@ -291,7 +297,9 @@ __device__ __forceinline__ bool kd_within(const VoxelRecord& r, float xt, float 
 // wave then runs max-over-lanes(count) predicated pair updates instead of 27.
 constexpr int KD_CELLS = 27;
 
-template <int MODE>
+// RADIUS = false is DIRECT26 [RECALLED] (pclomp getNeighborhoodAtPoint): the same 27-cell
+// enumeration in integer index space, every valid leaf found is a neighbour.
+template <int MODE, bool RADIUS>
 __device__ __forceinline__ void point_pairs_kd(PairAcc& a, float x, float y, float z, const GridGeom& g,
                                                const int* __restrict__ cell2leaf,
                                                const VoxelRecord* __restrict__ rec, const RigidRT& P,
@@ -334,7 +342,7 @@ __device__ __forceinline__ void point_pairs_kd(PairAcc& a, float x, float y, flo
     const bool have = j < count;
     const int sl = have ? lds_list[j * stride + (int)threadIdx.x] : 0;
     const VoxelRecord r = rec[sl];
-    const bool present = have && kd_within(r, xt, yt, zt, ec.kd_radius2);
+    const bool present = have && (!RADIUS || kd_within(r, xt, yt, zt, ec.kd_radius2));
     pair_update<MODE>(a, r, xt, yt, zt, ec, present);
   }
 }
@@ -454,7 +462,7 @@ __device__ __forceinline__ int ticket_is_last(unsigned int* counter, unsigned in
 __device__ __forceinline__ void sum_rows(__amdgpu_buffer_rsrc_t rows, unsigned int rows_off, int first, int end,
                                          unsigned long long seq, double (*lds_c)[EV_WORDS],
                                          __amdgpu_buffer_rsrc_t dst, unsigned int dst_off, bool dst_system,
-                                         double* plain_dst) {
+                                         double* plain_dst, int* s_fail) {
   const int v = threadIdx.x & 31, c = threadIdx.x >> 5;
   const int ncols = (int)blockDim.x >> 5;
   const unsigned int tag_lo = (unsigned int)seq, tag_hi = (unsigned int)(seq >> 32);
@@ -477,8 +485,10 @@ __device__ __forceinline__ void sum_rows(__amdgpu_buffer_rsrc_t rows, unsigned i
 #pragma unroll
       for (int k = 0; k < SUM_BATCH; ++k) ok = ok && t[k].x == tag_lo && t[k].y == tag_hi;
       if (ok) break;
-      if (++tries > SPIN_LIMIT) {  // cannot happen (every row was issued before its ticket); exit anyway
-        s = __longlong_as_double(0x7ff8000000000000ll);
+      if (++tries > SPIN_LIMIT) {
+        // cannot happen (every row was issued before its ticket); exit anyway and say so: word 31
+        // of an evaluation is 0 by construction, the host turns anything else into NDT_ERR_HIP
+        *s_fail = 1;
         break;
       }
       __builtin_amdgcn_s_sleep(1);
@@ -492,6 +502,7 @@ __device__ __forceinline__ void sum_rows(__amdgpu_buffer_rsrc_t rows, unsigned i
   if (threadIdx.x < EV_WORDS) {
     double t = 0.0;
     for (int k = 0; k < ncols; ++k) t += lds_c[k][threadIdx.x];
+    if (threadIdx.x == EV_WORDS - 1 && *s_fail) t += 1.0;
     if (plain_dst) plain_dst[threadIdx.x] = t;
     else store_slot(dst, dst_off + threadIdx.x * 16u, seq, t, dst_system);
   }
@@ -512,7 +523,9 @@ __device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], double
   __shared__ double lds_w[MAX_WAVES][EV_WORDS];
   __shared__ double lds_c[MAX_COLS][EV_WORDS];
   __shared__ int s_last;
+  __shared__ int s_fail;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_fail = 0;
   wave_reduce_scatter32(acc, lane);
   if ((lane & 1) == 0) lds_w[wave][lane >> 1] = acc[0];
   __syncthreads();
@@ -536,7 +549,7 @@ __device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], double
     if (threadIdx.x == 0) s_last = ticket_is_last(counters + 1 + grp, (unsigned int)(end - first));
     __syncthreads();
     if (!s_last) return;
-    sum_rows(rrows, 0u, first, end, seq, lds_c, rgroups, (unsigned int)grp * EV_WORDS * 16u, false, nullptr);
+    sum_rows(rrows, 0u, first, end, seq, lds_c, rgroups, (unsigned int)grp * EV_WORDS * 16u, false, nullptr, &s_fail);
     __syncthreads();
   }
   const bool two_level = nb > single_level_max;
@@ -546,7 +559,7 @@ __device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], double
   __syncthreads();
   if (!s_last) return;
   sum_rows(two_level ? rgroups : rrows, 0u, 0, nrows, seq, lds_c, slots_rsrc(host_slots), 0u, true,
-           host_slots ? nullptr : out);
+           host_slots ? nullptr : out, &s_fail);
   NDT_STAMP(6);
   if (threadIdx.x <= ngroups)  // leave the tickets at zero for the next launch
     __hip_atomic_store(counters + threadIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -577,7 +590,7 @@ constexpr unsigned int KERNARG_TABLES_OFFSET = offsetof(DerivKernArgs, pose) + o
 static_assert(offsetof(PoseConsts, hang) == offsetof(PoseConsts, jang) + 24 * sizeof(float) &&
               offsetof(AngleTables, hang) == 24 * sizeof(float), "jang / hang must be contiguous");
 
-// NB: neighbourhood -- 0 DIRECT1, 1 DIRECT7, 2 KDTREE
+// NB: neighbourhood -- 0 DIRECT1, 1 DIRECT7, 2 KDTREE, 3 DIRECT26
 template <bool BATCH, int MODE, int NB>
 __global__ void __launch_bounds__(MAX_BLOCK)
 k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, int n,
@@ -628,12 +641,12 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
 #pragma unroll
   for (int k = 0; k < 6; ++k) a.S[k] = 0.0;
   a.score = 0.0; a.best = 0.0; a.npairs = 0;
-  if (NB == 2) {
+  if (NB >= 2) {
     // every lane takes part (wave-wide trip count): lanes beyond n run with nothing to add
     extern __shared__ int lds_kd_list[];  // KD_CELLS x blockDim.x leaf indices
     if (i < n) { x = sx[i]; y = sy[i]; z = sz[i]; }
     NDT_STAMP(1);
-    point_pairs_kd<MODE>(a, x, y, z, g, cell2leaf, rec, rt, ec, lds_kd_list, i < n);
+    point_pairs_kd<MODE, NB == 2>(a, x, y, z, g, cell2leaf, rec, rt, ec, lds_kd_list, i < n);
   } else if (i < n) {
     x = sx[i]; y = sy[i]; z = sz[i];
     NDT_STAMP(1);
@@ -723,7 +736,7 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
                         unsigned long long seq) {
   const int blocks = derivs_grid_blocks(n_src, d_poses ? K : 1);
   const int threads = derivs_block_threads(n_src, d_poses ? K : 1);
-  const int mode = !ec.need_hessian ? 0 : (ec.gauss_newton ? 2 : 1);
+  const int mode = ec.score_only ? 3 : (!ec.need_hessian ? 0 : (ec.gauss_newton ? 2 : 1));
   EvalConsts ecl = ec;
   static const int slm = [] {
     const char* e = getenv("NDT_DERIV_SINGLE_LEVEL_MAX");  // tuning knob
@@ -731,8 +744,8 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
     return v > 0 ? v : SINGLE_LEVEL_MAX_DEFAULT;
   }();
   ecl.single_level_max = slm;
-  const int nb = ec.kdtree ? 2 : (ec.direct7 ? 1 : 0);
-  const size_t dyn_lds = nb == 2 ? (size_t)KD_CELLS * threads * sizeof(int) : 0;
+  const int nb = ec.kdtree ? 2 : (ec.direct26 ? 3 : (ec.direct7 ? 1 : 0));
+  const size_t dyn_lds = nb >= 2 ? (size_t)KD_CELLS * threads * sizeof(int) : 0;
 #define NDT_LAUNCH(B, M, NBH, GY, FLAG, SEQ)                                                              \
   hipLaunchKernelGGL((k_derivatives<B, M, NBH>), dim3(blocks, GY), dim3(threads), dyn_lds, s, sx, sy, sz,  \
                      (int)n_src, g, cell2leaf, rec, pose, d_poses, ecl, d_partials, d_counters, d_out,     \
@@ -741,13 +754,15 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
   do {                                                          \
     if (mode == 0) NDT_LAUNCH(B, 0, NBH, GY, FLAG, SEQ);        \
     else if (mode == 1) NDT_LAUNCH(B, 1, NBH, GY, FLAG, SEQ);   \
-    else NDT_LAUNCH(B, 2, NBH, GY, FLAG, SEQ);                  \
+    else if (mode == 2) NDT_LAUNCH(B, 2, NBH, GY, FLAG, SEQ);   \
+    else NDT_LAUNCH(B, 3, NBH, GY, FLAG, SEQ);                  \
   } while (0)
 #define NDT_LAUNCH_NB(B, GY, FLAG, SEQ)                        \
   do {                                                          \
     if (nb == 0) NDT_LAUNCH_MODE(B, 0, GY, FLAG, SEQ);          \
     else if (nb == 1) NDT_LAUNCH_MODE(B, 1, GY, FLAG, SEQ);     \
-    else NDT_LAUNCH_MODE(B, 2, GY, FLAG, SEQ);                  \
+    else if (nb == 2) NDT_LAUNCH_MODE(B, 2, GY, FLAG, SEQ);     \
+    else NDT_LAUNCH_MODE(B, 3, GY, FLAG, SEQ);                  \
   } while (0)
   unsigned long long* const no_flag = nullptr;
   if (d_poses) NDT_LAUNCH_NB(true, K, no_flag, seq);

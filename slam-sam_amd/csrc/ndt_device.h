@@ -61,6 +61,8 @@ struct EvalConsts {
   int need_hessian;
   int gauss_newton;
   int single_level_max;  // grids with more rows than this take the two-level final sum
+  int direct26;    // 1: every valid voxel of the 3x3x3 block around the point's cell (pclomp DIRECT26)
+  int score_only;  // 1: score / NVTL / counts only, no gradient or Hessian (ndt_score_transform)
 };
 
 // layout of one evaluation (matches NDT_EVAL_WORDS in include/ndt_hip.h)
@@ -71,6 +73,7 @@ enum {
   EV_NVTL = 28,
   EV_NWITH = 29,
   EV_NPAIRS = 30,
+  EV_FAIL = 31,    // 0; non-zero = the in-kernel final sum gave up waiting for a partial row
   EV_WORDS = 32
 };
 

@@ -98,11 +98,27 @@ int main() {
     ndt_hip::Matrix4f T2 = kf.getFinalTransformation();
     double d2 = 0;
     for (int i = 0; i < 16; ++i) d2 = std::fmax(d2, std::fabs((double)T2[i] - (double)T[i]));
-    std::array<double, 36> cov{};
+    ndt_hip::Matrix6d cov{};
     const bool cov_ok = kf.getResult().covarianceForGtsam(cov);
     std::printf("keyframes: status=%d converged=%d max|T - T_host|=%.2e cov_ok=%d cov[rot x]=%.3g\n", kf.lastStatus(),
                 (int)kf.hasConverged(), d2, (int)cov_ok, cov[0]);
     ok = ok && kf.lastStatus() == NDT_OK && kf.hasConverged() && d2 < 1e-5 && kf.keyframeCount() == 2 && cov_ok && cov[0] > 0.0;
+  }
+  // scoring-only calls + the O(log V) leaf lookup
+  {
+    const double tp = ndt.calculateTransformationProbability(*src, T);
+    const double nv = ndt.calculateNearestVoxelTransformationLikelihood(*src, T);
+    const auto& leaves = cells.getLeaves();
+    const auto& mid = leaves[leaves.size() / 2];
+    const ndt_hip::Vector3d c = cells.getLeafCenter(mid.first);
+    const ndt_hip::Vector3d mu = mid.second.getMean();
+    double off = 0;
+    for (int a = 0; a < 3; ++a) off = std::fmax(off, std::fabs(c[a] - mu[a]));
+    std::printf("score-only: tp=%.4f nvtl=%.4f (align: %.4f %.4f); leaf %zu centre-mean offset %.3f\n", tp, nv,
+                ndt.getTransformationProbability(), ndt.getNearestVoxelTransformationLikelihood(), mid.first, off);
+    ok = ok && std::fabs(tp - ndt.getTransformationProbability()) < 1e-9 * std::fabs(tp) + 1e-12 &&
+         std::fabs(nv - ndt.getNearestVoxelTransformationLikelihood()) < 1e-9 && off <= 0.5 + 1e-6 &&
+         cells.getLeaf(mid.first) == &mid.second && cells.getLeaf((size_t)-1) == nullptr;
   }
   // svn_ndt-shaped adapter: K = 8 particles, Gauss-Newton Hessian, one launch per iteration
   ndt_hip::SvnNormalDistributionsTransform<PointT, PointT> svn;

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(pkg):
     for name in declared:
         assert hasattr(L, name), "libndt_hip.so lacks %s" % name
     assert sorted(pkg.ABI_SYMBOLS) == declared  # the Python binding covers the whole ABI
-    assert L.ndt_abi_version() == 1
+    assert L.ndt_abi_version() == 2
 
 
 def test_abi_signatures_have_no_torch_types():
@@ -58,7 +58,7 @@ def test_invalid_arguments_are_rejected(pkg):
     h = C.c_void_p()
     bad = pkg.default_params(resolution=0.0)
     assert L.ndt_create(C.byref(bad), C.byref(h)) == -1
-    bad = pkg.default_params(search_method=pkg.DIRECT26)  # upstream-only mode, no in-tree statement
+    bad = pkg.default_params(search_method=17)
     assert L.ndt_create(C.byref(bad), C.byref(h)) == -1
     assert L.ndt_align(None, None, None) == -1
     assert L.ndt_get_grid_info(None, None) == -1
@@ -170,3 +170,29 @@ def test_result_covariance_matches_driver_recipe(pkg, O):
     assert np.array_equal(g[:3, 3:], c[:3, 3:]) and np.array_equal(g[:3, :3], c[3:, 3:]) and np.array_equal(g[3:, 3:], c[:3, :3])
     with pytest.raises(pkg.NdtError):
         pkg.result_covariance(np.zeros((6, 6)), 0.0)
+
+
+def test_presets_and_new_parameter_validation(pkg):
+    """ndt_params_preset: the two engines' switch sets; wait_mode / search-method checks."""
+    d = pkg.default_params()
+    assert (d.cov_mode, d.hessian_mode, d.add_ridge, d.wait_mode) == (pkg.COV_SVN, pkg.HESSIAN_FULL, 0, pkg.WAIT_SPIN)
+    p = pkg.default_params(preset=pkg.PRESET_PCLOMP_RECALLED)
+    assert (p.cov_mode, p.hessian_mode, p.add_ridge, p.use_line_search) == (pkg.COV_PCL_RECALLED, pkg.HESSIAN_FULL, 0, 1)
+    s = pkg.default_params(preset=pkg.PRESET_SVN)
+    assert (s.cov_mode, s.hessian_mode, s.add_ridge) == (pkg.COV_SVN, pkg.HESSIAN_GAUSS_NEWTON, 1)
+    with pytest.raises(pkg.NdtError):
+        pkg.default_params(preset=7)
+    L = pkg.lib()
+    h = C.c_void_p()
+    assert L.ndt_create(C.byref(pkg.default_params(wait_mode=5)), C.byref(h)) == -1
+    assert L.ndt_create(C.byref(pkg.default_params(search_method=9)), C.byref(h)) == -1
+    # DIRECT26 is a known method now: without a GPU the failure is the missing device, not the argument
+    rc = L.ndt_create(C.byref(pkg.default_params(search_method=pkg.DIRECT26)), C.byref(h))
+    assert rc in (0, -2)
+    if rc == 0:
+        L.ndt_destroy(h)
+
+
+def test_comm_info_names_the_collective_library(pkg):
+    v, path = pkg.comm_info()
+    assert v > 20000 and "rccl" in path

@@ -1,0 +1,188 @@
+"""GPU tests of the round-2 surface: DIRECT26, the scoring-only entry point, wait modes, the
+evaluation memo of the line search, parameter changes on a consumed device target, and the
+RCCL reducer on a one-rank communicator."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(resolution=1.0, step_size=0.1, trans_epsilon=1e-4, max_iterations=35)
+
+
+def _ndt(pkg, **kw):
+    base = dict(KW)
+    base.update(kw)
+    return pkg.NormalDistributionsTransform(device_id=0, **base)
+
+
+def test_direct26_search_mode(pkg, O, S):
+    """pclomp's DIRECT26 [RECALLED]: every valid voxel of the 3x3x3 block around the point's cell.
+    Neighbour counts exact, score 1e-9, g / H 1e-6 against the oracle's statement of it; a
+    superset of DIRECT7's pairs; align ends within the reference tolerance of ground truth."""
+    for cfg in (S.config_c1(), S.config_c2()):
+        grid = O.Grid(cfg["target"], O.default_params(search_method=O.DIRECT26, num_threads=8, **KW))
+        ndt = _ndt(pkg, search_method=pkg.DIRECT26)
+        ndt.setInputTarget(cfg["target"])
+        ndt.setInputSource(cfg["source"])
+        p0 = O.matrix_to_pose(cfg["guess"])
+        poses = np.stack([p0, O.matrix_to_pose(cfg["gt"]), O.matrix_to_pose(S.pose_matrix(400, 0, 0, 0, 0, 0))])
+        prm64 = O.default_params(search_method=O.DIRECT26, num_threads=8, pair_mode=2, **KW)
+        for p, e in zip(poses, ndt.evalDerivatives(poses)):
+            d = grid.derivatives(cfg["source"], p)
+            assert e["n_pairs"] == d["n_pairs"] and e["n_with_neighbors"] == d["n_with_neighbors"]
+            assert e["score"] == pytest.approx(d["score"], rel=1e-9, abs=1e-9)
+            x = grid.derivatives(cfg["source"], p, params=prm64)
+            assert np.linalg.norm(e["gradient"] - x["gradient"]) <= 1e-9 * np.linalg.norm(x["gradient"]) + 1e-9
+            assert np.linalg.norm(e["hessian"] - x["hessian"]) <= 1e-9 * np.linalg.norm(x["hessian"]) + 1e-9
+        n26 = ndt.evalDerivatives(p0)[0]["n_pairs"]
+        ndt.setNeighborhoodSearchMethod(pkg.DIRECT7)
+        assert ndt.evalDerivatives(p0)[0]["n_pairs"] <= n26
+        ndt.setNeighborhoodSearchMethod(pkg.DIRECT26)
+        T = ndt.align(cfg["guess"])
+        ref = grid.align(cfg["source"], cfg["guess"])
+        dt, dr = S.pose_error(T, ref["T"])
+        assert dt < 1e-3 and dr < 1e-4, (dt, dr)
+        assert S.pose_error(T, cfg["gt"])[0] < 0.05
+        ndt.close()
+
+
+def test_score_transform_is_the_evaluations_score(pkg, O, S):
+    """ndt_score_transform (pclomp calculateTransformationProbability / NVTL): one score-only
+    launch, the same score / NVTL / counts as a full evaluation at that transform, bit for bit."""
+    cfg = S.config_c2()
+    ndt = _ndt(pkg)
+    ndt.setInputTarget(cfg["target"])
+    ndt.setInputSource(cfg["source"])
+    for T in (cfg["guess"], cfg["gt"], np.eye(4)):
+        p = O.matrix_to_pose(T)
+        e = ndt.evalDerivatives(p, transforms=[T])[0]
+        n0 = ndt.getTiming()["n_eval_launches"]
+        sc = ndt.scoreTransform(T)
+        assert ndt.getTiming()["n_eval_launches"] == n0 + 1
+        assert sc["score"] == e["score"] and sc["n_pairs"] == e["n_pairs"]
+        assert sc["n_points_with_neighbors"] == e["n_with_neighbors"]
+        assert sc["transform_probability"] == e["score"] / len(cfg["source"])
+        assert sc["nvtl"] == e["nvtl_sum"] / e["n_with_neighbors"]
+    # against the oracle, and through pclomp's method names on a pre-transformed cloud
+    grid = O.Grid(cfg["target"], O.default_params(num_threads=8, **KW))
+    d = grid.derivatives(cfg["source"], O.matrix_to_pose(cfg["gt"]), T=cfg["gt"])
+    moved = ndt.transformSource(cfg["gt"])
+    tp = ndt.calculateTransformationProbability(moved)
+    nv = ndt.calculateNearestVoxelTransformationLikelihood(moved)
+    assert tp == pytest.approx(d["score"] / len(moved), rel=1e-6)
+    assert nv == pytest.approx(d["nvtl_sum"] / d["n_with_neighbors"], rel=1e-6)
+    # after align(): the result's TP / NVTL are those of the final transformation
+    ndt.setInputSource(cfg["source"])
+    T = ndt.align(cfg["guess"])
+    r = ndt.getResult()
+    sc = ndt.scoreTransform(T)
+    assert sc["transform_probability"] == pytest.approx(r["transform_probability"], rel=1e-12)
+    assert sc["nvtl"] == pytest.approx(r["nvtl"], rel=1e-12)
+
+
+def test_wait_modes_agree_bit_for_bit(pkg, S):
+    cfg = S.config_c2()
+    out = []
+    for mode in (pkg.WAIT_SPIN, pkg.WAIT_BLOCK):
+        ndt = _ndt(pkg, wait_mode=mode)
+        ndt.setInputTarget(cfg["target"])
+        ndt.setInputSource(cfg["source"])
+        T = ndt.align(cfg["guess"])
+        r = ndt.getResult()
+        out.append((T, r["hessian"], r["iterations"], r["n_evaluations"], r["score"]))
+        ndt.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert out[0][2:] == out[1][2:]
+
+
+def test_line_search_memo_changes_no_number(pkg, O, S):
+    """A More-Thuente step clamped to its lower bound is re-tried up to 10 times at the same pose
+    (and the reference re-evaluates at the accepted step for the Hessian): the engine answers
+    those from the last result.  Driving the same host loop with the engine as an EXTERNAL
+    evaluator (no memo: ndt_newton_align) must give the identical result with more launches."""
+    cfg = S.config_c2()
+    ndt = _ndt(pkg)
+    ndt.setInputTarget(cfg["target"])
+    ndt.setInputSource(cfg["source"])
+    T = ndt.align(cfg["guess"])
+    r = ndt.getResult()
+    calls = []
+
+    def ev(pose, Tm, need_h):
+        e = ndt.evalDerivatives(pose, transforms=[Tm], compute_hessian=True)[0]
+        calls.append(pose.copy())
+        return pkg.pack_eval(e["score"], e["gradient"], e["hessian"], e["nvtl_sum"], e["n_with_neighbors"], e["n_pairs"])
+
+    r2 = pkg.newton_align(pkg.default_params(**KW), len(cfg["source"]), cfg["guess"], ev)
+    assert np.array_equal(r2["T"], T) and r2["iterations"] == r["iterations"]
+    assert np.array_equal(r2["hessian"], r["hessian"]) and r2["score"] == r["score"]
+    distinct = sum(1 for i, p in enumerate(calls) if i == 0 or not np.array_equal(p, calls[i - 1]))
+    assert r["n_evaluations"] == distinct
+    assert r["n_evaluations"] + r["n_evaluations_reused"] >= distinct
+    assert len(calls) > r["n_evaluations"]   # C2 ends with a clamped step: launches were saved
+
+
+def test_grid_parameter_change_on_a_consumed_device_target(pkg, S):
+    """ndt_set_target_device keeps no copy of the target; a later change of resolution (or of any
+    other grid-affecting parameter) cannot re-voxelise it and must not evaluate the old grid with
+    the new constants: the next align reports NDT_ERR_NO_TARGET (pclomp's setResolution
+    re-voxelises; with a host target, ndt_set_target, this engine does too)."""
+    import torch
+    cfg = S.config_c1()
+    dev = torch.device("cuda:0")
+    t = torch.from_numpy(np.ascontiguousarray(cfg["target"].T)).to(dev)
+    ndt = _ndt(pkg)
+    ndt.setInputTargetDevice(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t.shape[1])
+    ndt.setInputSource(cfg["source"])
+    ndt.align(cfg["guess"])
+    assert ndt.hasConverged()
+    ndt.setStepSize(0.05)          # not a grid parameter: still fine
+    ndt.align(cfg["guess"])
+    ndt.setResolution(2.0)
+    with pytest.raises(pkg.NdtError) as ei:
+        ndt.align(cfg["guess"])
+    assert ei.value.code == -4
+    with pytest.raises(pkg.NdtError):
+        ndt.getGridInfo()
+    ndt.setInputTargetDevice(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t.shape[1])
+    ndt.align(cfg["guess"])
+    assert ndt.hasConverged() and ndt.getGridInfo()["leaf_size"] == 2.0
+    # a host target is kept and re-voxelised
+    ndt2 = _ndt(pkg)
+    ndt2.setInputTarget(cfg["target"])
+    n1 = ndt2.getGridInfo()["n_leaves"]
+    ndt2.setResolution(2.0)
+    assert ndt2.getGridInfo()["n_leaves"] < n1
+
+
+def test_rccl_reducer_on_a_one_rank_communicator(pkg, S):
+    """The RCCL leg end to end on one GPU: ncclCommInitRank(nranks = 1) + one ncclAllReduce per
+    evaluation on the engine's stream, with PyTorch (and its bundled librccl) loaded first, as in
+    bench.py.  Must reproduce the reducer-free align bit for bit.  Prints which librccl serves it."""
+    import torch  # noqa: F401  (loads torch/lib/librccl.so before the engine's reducer is used)
+    version, path = pkg.comm_info()
+    print("ncclGetVersion = %d from %s" % (version, path))
+    assert version > 20000
+    cfg = S.config_c2()
+    plain = _ndt(pkg)
+    plain.setInputTarget(cfg["target"])
+    plain.setInputSource(cfg["source"])
+    T0 = plain.align(cfg["guess"])
+    r0 = plain.getResult()
+    ndt = _ndt(pkg)
+    ndt.commInitRccl(pkg.comm_unique_id(), 0, 1)
+    ndt.setInputTarget(cfg["target"])
+    ndt.setInputSource(cfg["source"])
+    T1 = ndt.align(cfg["guess"])
+    r1 = ndt.getResult()
+    assert np.array_equal(T0, T1) and np.array_equal(r0["hessian"], r1["hessian"])
+    assert (r0["iterations"], r0["n_evaluations"], r0["score"]) == (r1["iterations"], r1["n_evaluations"], r1["score"])
+    # batched evaluations go through the same reducer
+    p = r1["pose"]
+    a = plain.evalDerivatives(np.stack([p, p + 0.01]))
+    b = ndt.evalDerivatives(np.stack([p, p + 0.01]))
+    for x, y in zip(a, b):
+        assert x["score"] == y["score"] and np.array_equal(x["hessian"], y["hessian"])
+    ndt.commDestroy()
+    T2 = ndt.align(cfg["guess"])
+    assert np.array_equal(T0, T2)

@@ -97,7 +97,8 @@ def test_random_cloud_parity(pkg, O, S, case):
         return
     p0 = O.matrix_to_pose(dT)
     poses = np.stack([p0, p0 + rng.normal(0, 0.02, 6), np.zeros(6)])
-    for method, omethod in ((pkg.DIRECT7, O.DIRECT7), (pkg.DIRECT1, O.DIRECT1), (pkg.KDTREE, O.KDTREE)):
+    for method, omethod in ((pkg.DIRECT7, O.DIRECT7), (pkg.DIRECT1, O.DIRECT1), (pkg.KDTREE, O.KDTREE),
+                            (pkg.DIRECT26, O.DIRECT26)):
         for hmode in (pkg.HESSIAN_FULL, pkg.HESSIAN_GAUSS_NEWTON):
             ndt.setParams(search_method=method, hessian_mode=hmode)
             okw = dict(num_threads=4, search_method=omethod,
@@ -124,3 +125,8 @@ def test_random_cloud_parity(pkg, O, S, case):
             # score + gradient only (the line search's cheap evaluation) agrees with the full one
             e0 = ndt.evalDerivatives(poses[0], compute_hessian=False)[0]
             assert e0["score"] == got[0]["score"] and np.array_equal(e0["gradient"], got[0]["gradient"])
+            # ... and so does the score-only kernel (ndt_score_transform), bit for bit
+            sc = ndt.scoreTransform(O.pose_to_matrix(poses[0]))
+            assert sc["score"] == got[0]["score"] and sc["n_pairs"] == got[0]["n_pairs"]
+            if got[0]["n_with_neighbors"]:
+                assert sc["nvtl"] == got[0]["nvtl_sum"] / got[0]["n_with_neighbors"]
