@@ -1,0 +1,51 @@
+// TEST DOUBLE of pcl::Registration -- see tests/cpp/mock/README.md.  Members and virtuals as
+// the adapter's PCL face uses them (PCL 1.14: registration.h).
+#pragma once
+#include <Eigen/Core>
+#include <string>
+#include "../point_cloud.h"
+namespace pcl {
+template <typename PointSource, typename PointTarget, typename Scalar = float>
+class Registration {
+ public:
+  using Matrix4 = Eigen::Matrix<Scalar, 4, 4>;
+  using Ptr = shared_ptr<Registration<PointSource, PointTarget, Scalar>>;
+  using ConstPtr = shared_ptr<const Registration<PointSource, PointTarget, Scalar>>;
+  using PointCloudSource = pcl::PointCloud<PointSource>;
+  using PointCloudSourcePtr = typename PointCloudSource::Ptr;
+  using PointCloudSourceConstPtr = typename PointCloudSource::ConstPtr;
+  using PointCloudTarget = pcl::PointCloud<PointTarget>;
+  using PointCloudTargetPtr = typename PointCloudTarget::Ptr;
+  using PointCloudTargetConstPtr = typename PointCloudTarget::ConstPtr;
+
+  Registration() { final_transformation_ = Matrix4::Identity(); transformation_ = Matrix4::Identity(); }
+  virtual ~Registration() = default;
+  virtual void setInputSource(const PointCloudSourceConstPtr& cloud) { input_ = cloud; source_cloud_updated_ = true; }
+  virtual void setInputTarget(const PointCloudTargetConstPtr& cloud) { target_ = cloud; target_cloud_updated_ = true; }
+  Matrix4 getFinalTransformation() { return final_transformation_; }
+  bool hasConverged() const { return converged_; }
+  void setMaximumIterations(int n) { max_iterations_ = n; }
+  void setTransformationEpsilon(double e) { transformation_epsilon_ = e; }
+  void align(PointCloudSource& output) { align(output, Matrix4::Identity()); }
+  void align(PointCloudSource& output, const Matrix4& guess) {
+    if (!target_ || !input_) return;          // initCompute()
+    kdtree_builds_ += target_cloud_updated_;  // the real one builds a FLANN tree over the target here
+    target_cloud_updated_ = false;
+    converged_ = false;
+    final_transformation_ = transformation_ = Matrix4::Identity();
+    computeTransformation(output, guess);
+  }
+  int kdtree_builds_ = 0;  // mock-only probe
+
+ protected:
+  virtual void computeTransformation(PointCloudSource& output, const Matrix4& guess) = 0;
+  std::string reg_name_;
+  int nr_iterations_ = 0, max_iterations_ = 10;
+  PointCloudSourceConstPtr input_;
+  PointCloudTargetConstPtr target_;
+  Matrix4 final_transformation_, transformation_;
+  double transformation_epsilon_ = 0.0;
+  bool converged_ = false;
+  bool target_cloud_updated_ = true, source_cloud_updated_ = true;
+};
+}  // namespace pcl

@@ -122,17 +122,16 @@ def test_line_search_memo_changes_no_number(pkg, O, S):
     assert len(calls) > r["n_evaluations"]   # C2 ends with a clamped step: launches were saved
 
 
-def test_grid_parameter_change_on_a_consumed_device_target(pkg, S):
+def test_grid_parameter_change_on_a_consumed_device_target(pkg, S, hipmem):
     """ndt_set_target_device keeps no copy of the target; a later change of resolution (or of any
     other grid-affecting parameter) cannot re-voxelise it and must not evaluate the old grid with
     the new constants: the next align reports NDT_ERR_NO_TARGET (pclomp's setResolution
     re-voxelises; with a host target, ndt_set_target, this engine does too)."""
-    import torch
     cfg = S.config_c1()
-    dev = torch.device("cuda:0")
-    t = torch.from_numpy(np.ascontiguousarray(cfg["target"].T)).to(dev)
+    n = len(cfg["target"])
+    t = [hipmem.upload(cfg["target"][:, a]) for a in range(3)]
     ndt = _ndt(pkg)
-    ndt.setInputTargetDevice(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t.shape[1])
+    ndt.setInputTargetDevice(t[0], t[1], t[2], n)
     ndt.setInputSource(cfg["source"])
     ndt.align(cfg["guess"])
     assert ndt.hasConverged()
@@ -144,9 +143,14 @@ def test_grid_parameter_change_on_a_consumed_device_target(pkg, S):
     assert ei.value.code == -4
     with pytest.raises(pkg.NdtError):
         ndt.getGridInfo()
-    ndt.setInputTargetDevice(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t.shape[1])
+    ndt.setInputTargetDevice(t[0], t[1], t[2], n)
     ndt.align(cfg["guess"])
     assert ndt.hasConverged() and ndt.getGridInfo()["leaf_size"] == 2.0
+    # device-resident source arrays agree with the host hand-off
+    s = [hipmem.upload(cfg["source"][:, a]) for a in range(3)]
+    T_host = ndt.align(cfg["guess"])
+    ndt.setInputSourceDevice(s[0], s[1], s[2], len(cfg["source"]))
+    assert np.array_equal(ndt.align(cfg["guess"]), T_host)
     # a host target is kept and re-voxelised
     ndt2 = _ndt(pkg)
     ndt2.setInputTarget(cfg["target"])
@@ -159,7 +163,7 @@ def test_rccl_reducer_on_a_one_rank_communicator(pkg, S):
     """The RCCL leg end to end on one GPU: ncclCommInitRank(nranks = 1) + one ncclAllReduce per
     evaluation on the engine's stream, with PyTorch (and its bundled librccl) loaded first, as in
     bench.py.  Must reproduce the reducer-free align bit for bit.  Prints which librccl serves it."""
-    import torch  # noqa: F401  (loads torch/lib/librccl.so before the engine's reducer is used)
+    import torch  # noqa: F401  (torch/lib/librccl.so is on the process' library list before the reducer runs)
     version, path = pkg.comm_info()
     print("ncclGetVersion = %d from %s" % (version, path))
     assert version > 20000
