@@ -29,7 +29,14 @@ def test_bench_line_schema():
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0 < rf["frac"] < 1
-    assert rf["traffic"] is None or rf["traffic"] > 0
+    assert rf["traffic"] is None or (rf["traffic"] > 0 and rf["traffic_source"].startswith("static: profiles/"))
+    rb = d["roofline_build"]
+    assert rb["bound"] == "hbm" and rb["algorithmic_bytes"] > 6e7 and 0 < rb["frac"] < 1
+    assert abs(rb["achieved"] - rb["algorithmic_bytes"] / (rb["ms_device"] * 1e-3) / 1e9) < 1e-6 * rb["achieved"]
+    hc = d["host_cloud"]
+    assert hc["unit"] == "iterations/s" and 0 < hc["value"] < d["value"] and hc["ms_scan"] > d["ms_per_step"]
+    assert d["evaluations_reused_per_align"] >= 0 and d["config"]["rccl"]["version"] > 20000
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "iterations/s" and cb["sample"]
+    assert cb["nproc"] >= cb["cores"] and "-O" in cb["build_flags"] and cb["threads_8"]["threads"] <= 8
     assert d["final_error_vs_ground_truth"]["m"] < 0.05
