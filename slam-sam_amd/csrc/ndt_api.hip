@@ -85,7 +85,10 @@ struct ndt_handle {
   DevBuf<char> sort_tmp;
   DevBuf<int> nleaf;                 // [0] slots, [1] valid
   DevBuf<int> leaf_start, leaf_cnt, run_counts, run_offsets;
-  DevBuf<double> leaf_sums;
+  DevBuf<int> brows;                 // per-block bounds rows
+  DevBuf<unsigned int> tickets;      // [0] bounds kernel, [1] run-count kernel; zero between launches
+  DevBuf<BuildGeom> gd;              // geometry + sort plan of the build, derived on the device
+  PinBuf<BuildGeom> gdh;             // ... and its host-visible copy
   DevBuf<float> xyz4;                // packed float4 copy of the target for the gather
   DevBuf<int> cell2leaf;
   DevBuf<VoxelRecord> rec;
@@ -204,95 +207,103 @@ int upload_soa(ndt_handle* h, const float* xyz, const float* x, const float* y, 
   return NDT_OK;
 }
 
-// the voxel-grid build proper; x/y/z are device pointers
+// The voxel-grid build proper; x/y/z are device pointers.
+//
+// Steady state ("optimistic"): the dense grid and every scratch buffer exist from an earlier
+// build, so the whole chain of launches is enqueued without waiting for the bounds -- the
+// geometry and the sort plan are derived on the device (BuildGeom) and checked against the
+// capacities the host assumed; ONE synchronisation at the end.  First build, or a cloud that
+// outgrew the buffers: the host waits for the geometry once, allocates, and goes on (as
+// before).  A refused optimistic build (BG_CAPACITY / BG_PASSES) is repeated that way.
 int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, size_t n) {
   h->have_grid = false;
   h->n_tgt = n;
   h->n_slots = h->n_valid = 0;
-  const int dirty_slots = h->grid_dirty_slots;
-  const size_t clean_cap = h->grid_clean_cap;
+  int dirty_slots = h->grid_dirty_slots;
+  size_t clean_cap = h->grid_clean_cap;
   h->grid_clean_cap = 0;  // pessimistic until this build has gone through
   h->grid_dirty_slots = 0;
   if (n == 0) return fail(h, NDT_ERR_NO_TARGET, "empty target cloud");
   if (n > (size_t)std::numeric_limits<int>::max() / 2) return fail(h, NDT_ERR_INVALID_ARG, "target too large");
   hipStream_t s = h->stream;
   const int nrows = bounds_rows(n);
-  HIP_TRY(h, h->small.ensure(16 + 8 * (size_t)nrows));
-  HIP_TRY(h, hipEventRecord(h->ev0, s));
-  launch_bounds(x, y, z, n, h->small.d + 16, s);  // rows land in pinned host memory
-  HIP_TRY(h, hipStreamSynchronize(s));
-  fold_bounds(h->small.h + 16, nrows, h->small.h);
-  if (h->small.h[6] == 0) return fail(h, NDT_ERR_NO_TARGET, "target has no finite point");
-
-  // grid geometry in f32, as the reference computes it
-  // (ref: voxel_grid_covariance_impl.hpp:108-140)
-  GridGeom g{};
-  g.leaf = h->prm.resolution;
-  g.inv_leaf = 1.0f / h->prm.resolution;
-  float mn[3], mx[3];
-  for (int a = 0; a < 3; ++a) { mn[a] = decode_ordered(h->small.h[a]); mx[a] = decode_ordered(h->small.h[3 + a]); }
-  int64_t d[3];
-  for (int a = 0; a < 3; ++a) d[a] = (int64_t)((mx[a] - mn[a]) * g.inv_leaf) + 1;
-  const int64_t lim = std::numeric_limits<int32_t>::max();
-  if (d[0] < 0 || d[1] < 0 || d[2] < 0 || d[0] > lim || d[1] > lim || d[2] > lim ||
-      d[0] * d[1] > lim || d[0] * d[1] * d[2] > lim)
-    return fail(h, NDT_ERR_GRID_OVERFLOW, "leaf size too small for the target extent (index overflow)");
-  int64_t ncells = 1;
-  for (int a = 0; a < 3; ++a) {
-    g.min_b[a] = (int)std::floor(mn[a] * g.inv_leaf);
-    h->max_b[a] = (int)std::floor(mx[a] * g.inv_leaf);
-    g.div_b[a] = h->max_b[a] - g.min_b[a] + 1;
-    g.lo[a] = (float)g.min_b[a] * g.leaf;
-    g.hi[a] = (float)(h->max_b[a] + 1) * g.leaf;
-    ncells *= g.div_b[a];
-  }
-  if (ncells >= lim) return fail(h, NDT_ERR_GRID_OVERFLOW, "voxel index grid too large");
-  g.mul1 = g.div_b[0];
-  g.mul2 = g.div_b[0] * g.div_b[1];
-  g.ncells = (int)ncells;
-  h->geom = g;
-
   const int min_pts = std::max(3, h->prm.min_points_per_voxel);  // ref: voxel_grid_covariance.h:176-184
   const int max_leaves = (int)(n / (size_t)min_pts) + 1;
-  if (clean_cap != 0 && clean_cap == h->cell2leaf.cap && (size_t)g.ncells <= clean_cap) {
-    launch_clear_cells(h->stats.p, dirty_slots, h->cell2leaf.p, h->cell2leaf.cap, s);  // before `stats` can be re-allocated
-  } else {
-    HIP_TRY(h, h->cell2leaf.ensure((size_t)g.ncells));
-    HIP_TRY(h, hipMemsetAsync(h->cell2leaf.p, 0xFF, h->cell2leaf.cap * sizeof(int), s));
+  const float leaf = h->prm.resolution, inv_leaf = 1.0f / h->prm.resolution;
+
+  HIP_TRY(h, h->small.ensure(16));
+  HIP_TRY(h, h->brows.ensure(8 * (size_t)nrows));
+  HIP_TRY(h, h->gd.ensure(1));
+  HIP_TRY(h, h->gdh.ensure(1));
+  if (!h->tickets.p) {
+    HIP_TRY(h, h->tickets.ensure(2));
+    HIP_TRY(h, hipMemsetAsync(h->tickets.p, 0, h->tickets.cap * sizeof(unsigned int), s));
   }
+  HIP_TRY(h, h->nleaf.ensure(2));
+  // a re-allocation of `stats` would lose the cells the previous build published
+  if ((size_t)max_leaves > h->stats.cap) clean_cap = 0;
   HIP_TRY(h, h->keys.ensure(n));
   HIP_TRY(h, h->xyz4.ensure(4 * n));
   HIP_TRY(h, h->vals.ensure(n));
   HIP_TRY(h, h->keys2.ensure(n));
   HIP_TRY(h, h->vals2.ensure(n));
-  HIP_TRY(h, h->nleaf.ensure(2));
   HIP_TRY(h, h->leaf_start.ensure((size_t)max_leaves));
   HIP_TRY(h, h->leaf_cnt.ensure((size_t)max_leaves));
   HIP_TRY(h, h->rec.ensure((size_t)max_leaves));
-  HIP_TRY(h, h->stats.ensure((size_t)max_leaves));
-  HIP_TRY(h, h->leaf_sums.ensure((size_t)max_leaves * 9));
   HIP_TRY(h, h->run_counts.ensure((size_t)runs_blocks(n)));
   HIP_TRY(h, h->run_offsets.ensure((size_t)runs_blocks(n)));
-  const size_t tmp_bytes = sort_temp_bytes(n);
-  HIP_TRY(h, h->sort_tmp.ensure(tmp_bytes));
+  HIP_TRY(h, h->sort_tmp.ensure(sort_temp_bytes(n)));
 
-  HIP_TRY(h, hipMemsetAsync(h->nleaf.p, 0, 2 * sizeof(int), s));
-  int bits = 1;
-  while (bits < 32 && (1ull << bits) <= (unsigned long long)g.ncells) ++bits;  // sentinel = ncells
-  launch_cell_keys(x, y, z, n, g, h->keys.p, h->xyz4.p, bits, h->sort_tmp.p, s);
-  bool in_b = false;
-  HIP_TRY(h, sort_pairs(h->sort_tmp.p, h->keys.p, h->keys2.p, h->vals.p, h->vals2.p, n, bits, s, &in_b));
-  const uint32_t* keys_sorted = in_b ? h->keys2.p : h->keys.p;
-  const uint32_t* vals_sorted = in_b ? h->vals2.p : h->vals.p;
-  launch_find_runs(keys_sorted, n, g.ncells, min_pts, h->nleaf.p, h->run_counts.p, h->run_offsets.p,
-                   h->leaf_start.p, h->leaf_cnt.p, s);
-  FinalizeParams fp{h->prm.eig_inflation_ratio, h->prm.cov_mode};
-  launch_finalize_leaves(h->xyz4.p, keys_sorted, vals_sorted, h->nleaf.p, h->leaf_start.p, h->leaf_cnt.p,
-                         max_leaves, fp, h->leaf_sums.p, h->rec.p, h->stats.p, h->cell2leaf.p, s);
-  HIP_TRY(h, hipGetLastError());
-  HIP_TRY(h, hipMemcpyAsync(h->small.h + 8, h->nleaf.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-  HIP_TRY(h, hipEventRecord(h->ev1, s));
-  HIP_TRY(h, hipStreamSynchronize(s));
+  HIP_TRY(h, hipEventRecord(h->ev0, s));
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const bool optimistic = attempt == 0 && clean_cap != 0 && clean_cap == h->cell2leaf.cap;
+    const long long lim = std::numeric_limits<int32_t>::max();
+    const long long cap_cells = optimistic ? (long long)h->cell2leaf.cap : lim;
+    int passes = optimistic ? sort_passes_for_cells(cap_cells) : 0;
+    h->gdh.h->status = -1;
+    launch_bounds_geometry(x, y, z, n, leaf, inv_leaf, cap_cells, passes, h->brows.p, h->tickets.p, h->gd.p, h->gdh.d,
+                           optimistic ? h->stats.p : nullptr, optimistic ? dirty_slots : 0, h->cell2leaf.p,
+                           h->cell2leaf.cap, h->nleaf.p, s);
+    if (!optimistic) {
+      HIP_TRY(h, hipStreamSynchronize(s));
+      const BuildGeom& bg = *h->gdh.h;
+      if (bg.status == BG_NO_FINITE) return fail(h, NDT_ERR_NO_TARGET, "target has no finite point");
+      if (bg.status != BG_OK)
+        return fail(h, NDT_ERR_GRID_OVERFLOW, "leaf size too small for the target extent (index overflow)");
+      passes = bg.passes;
+      HIP_TRY(h, h->cell2leaf.ensure((size_t)bg.g.ncells));
+      HIP_TRY(h, hipMemsetAsync(h->cell2leaf.p, 0xFF, h->cell2leaf.cap * sizeof(int), s));
+    }
+    HIP_TRY(h, h->stats.ensure((size_t)max_leaves));
+    launch_cell_keys(x, y, z, n, h->gd.p, h->keys.p, h->xyz4.p, h->sort_tmp.p, s);
+    bool in_b = false;
+    HIP_TRY(h, sort_pairs(h->sort_tmp.p, h->keys.p, h->keys2.p, h->vals.p, h->vals2.p, n, passes, h->gd.p, s, &in_b));
+    const uint32_t* keys_sorted = in_b ? h->keys2.p : h->keys.p;
+    const uint32_t* vals_sorted = in_b ? h->vals2.p : h->vals.p;
+    launch_find_runs(keys_sorted, n, h->gd.p, min_pts, h->nleaf.p, h->run_counts.p, h->run_offsets.p, h->tickets.p + 1,
+                     h->leaf_start.p, h->leaf_cnt.p, s);
+    FinalizeParams fp{h->prm.eig_inflation_ratio, h->prm.cov_mode};
+    launch_finalize_leaves(h->xyz4.p, keys_sorted, vals_sorted, h->nleaf.p, h->leaf_start.p, h->leaf_cnt.p, max_leaves,
+                           fp, h->rec.p, h->stats.p, h->cell2leaf.p, s);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(h->small.h + 8, h->nleaf.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipEventRecord(h->ev1, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    const BuildGeom& bg = *h->gdh.h;
+    if (optimistic && (bg.status == BG_CAPACITY || bg.status == BG_PASSES)) {
+      // the cloud outgrew the dense grid (or the enqueued sort passes): nothing after the bounds
+      // kernel ran; the old cells were reset by it.  Once more, waiting for the geometry.
+      clean_cap = 0;
+      dirty_slots = 0;
+      continue;
+    }
+    if (bg.status == BG_NO_FINITE) return fail(h, NDT_ERR_NO_TARGET, "target has no finite point");
+    if (bg.status != BG_OK)
+      return fail(h, NDT_ERR_GRID_OVERFLOW, "leaf size too small for the target extent (index overflow)");
+    h->geom = bg.g;
+    for (int a = 0; a < 3; ++a) h->max_b[a] = bg.max_b[a];
+    break;
+  }
   float ms = 0;
   HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
   h->ms_build = ms;
@@ -555,7 +566,8 @@ int ndt_destroy(ndt_handle* h) {
   h->keys.release(); h->vals.release(); h->keys2.release(); h->vals2.release();
   h->sort_tmp.release(); h->nleaf.release(); h->leaf_start.release(); h->leaf_cnt.release();
   h->cell2leaf.release(); h->rec.release(); h->stats.release();
-  h->run_counts.release(); h->run_offsets.release(); h->leaf_sums.release(); h->xyz4.release();
+  h->run_counts.release(); h->run_offsets.release(); h->xyz4.release();
+  h->brows.release(); h->tickets.release(); h->gd.release(); h->gdh.release();
   for (auto& kv : h->keyframes) { kv.second.x.release(); kv.second.y.release(); kv.second.z.release(); }
   h->keyframes.clear();
   h->sx.release(); h->sy.release(); h->sz.release();
@@ -1009,10 +1021,15 @@ int ndt_debug_sort_pairs(ndt_handle* h, const uint32_t* keys, size_t n, int end_
   HIP_TRY(h, h->keys2.ensure(n));
   HIP_TRY(h, h->vals2.ensure(n));
   HIP_TRY(h, h->sort_tmp.ensure(sort_temp_bytes(n)));
+  HIP_TRY(h, h->gd.ensure(1));
+  BuildGeom plan{};
+  fill_sort_plan(&plan, end_bit);
+  plan.status = BG_OK;
+  HIP_TRY(h, hipMemcpyAsync(h->gd.p, &plan, sizeof(plan), hipMemcpyHostToDevice, s));
   HIP_TRY(h, hipMemcpyAsync(h->keys.p, keys, n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-  launch_sort_first_count(h->keys.p, n, end_bit, h->sort_tmp.p, s);
+  launch_sort_first_count(h->keys.p, n, h->gd.p, h->sort_tmp.p, s);
   bool in_b = false;
-  HIP_TRY(h, sort_pairs(h->sort_tmp.p, h->keys.p, h->keys2.p, h->vals.p, h->vals2.p, n, end_bit, s, &in_b));
+  HIP_TRY(h, sort_pairs(h->sort_tmp.p, h->keys.p, h->keys2.p, h->vals.p, h->vals2.p, n, plan.passes, h->gd.p, s, &in_b));
   HIP_TRY(h, hipMemcpyAsync(keys_out, in_b ? h->keys2.p : h->keys.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   HIP_TRY(h, hipMemcpyAsync(vals_out, in_b ? h->vals2.p : h->vals.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   HIP_TRY(h, hipStreamSynchronize(s));

@@ -410,6 +410,9 @@ __device__ unsigned int g_hwid[4096 * 2];
 #define NDT_STAMP(k) do {} while (0)
 #endif
 
+#ifndef NDT_DERIV_SUMMER_DEFAULT
+#define NDT_DERIV_SUMMER_DEFAULT 0
+#endif
 constexpr int NGROUPS = 32;          // second-level fan-in (only for grids above SINGLE_LEVEL_MAX rows)
 constexpr int SINGLE_LEVEL_MAX_DEFAULT = 2048;  // rows one block adds directly
 constexpr int COUNTERS_PER_POSE = 1 + NGROUPS;
@@ -519,7 +522,7 @@ __device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], double
                                                     unsigned int* __restrict__ counters,
                                                     double* __restrict__ out,
                                                     unsigned long long* host_slots, unsigned long long seq,
-                                                    int single_level_max) {
+                                                    int single_level_max, bool fixed_summer) {
   __shared__ double lds_w[MAX_WAVES][EV_WORDS];
   __shared__ double lds_c[MAX_COLS][EV_WORDS];
   __shared__ int s_last;
@@ -554,14 +557,24 @@ __device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], double
   }
   const bool two_level = nb > single_level_max;
   const int nrows = two_level ? ngroups : nb;
-  if (threadIdx.x == 0) s_last = ticket_is_last(counters, (unsigned int)nrows);
-  NDT_STAMP(5);
-  __syncthreads();
-  if (!s_last) return;
+  if (fixed_summer && !two_level) {
+    // Variant without tickets: the rows validate themselves (tag == this launch's sequence
+    // number), so a FIXED block can add them -- block 0, the first one dispatched -- by polling
+    // the tags; every other block is done once its row store is issued.  Takes the ticket's
+    // atomic round trip out of the launch's critical path.  Block 0 depends on the others, never
+    // the other way round, so a grid larger than the machine cannot dead-lock on it.
+    if (blockIdx.x != 0) return;
+    NDT_STAMP(5);
+  } else {
+    if (threadIdx.x == 0) s_last = ticket_is_last(counters, (unsigned int)nrows);
+    NDT_STAMP(5);
+    __syncthreads();
+    if (!s_last) return;
+  }
   sum_rows(two_level ? rgroups : rrows, 0u, 0, nrows, seq, lds_c, slots_rsrc(host_slots), 0u, true,
            host_slots ? nullptr : out, &s_fail);
   NDT_STAMP(6);
-  if (threadIdx.x <= ngroups)  // leave the tickets at zero for the next launch
+  if (threadIdx.x <= ngroups && !(fixed_summer && !two_level))  // leave the tickets at zero for the next launch
     __hip_atomic_store(counters + threadIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   NDT_STAMP(7);
 }
@@ -669,7 +682,8 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
   NDT_STAMP(3);
   double* base = partials + (size_t)blockIdx.y * (gridDim.x + NGROUPS) * ROW_WORDS;
   block_reduce_finish(acc, base + (size_t)NGROUPS * ROW_WORDS, base, counters + blockIdx.y * COUNTERS_PER_POSE,
-                      out + (size_t)blockIdx.y * EV_WORDS, BATCH ? nullptr : flag, seq, ec.single_level_max);
+                      out + (size_t)blockIdx.y * EV_WORDS, BATCH ? nullptr : flag, seq, ec.single_level_max,
+                      ec.fixed_summer != 0);
 }
 
 __global__ void __launch_bounds__(256) k_transform(const float* __restrict__ sx, const float* __restrict__ sy,
@@ -744,6 +758,11 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
     return v > 0 ? v : SINGLE_LEVEL_MAX_DEFAULT;
   }();
   ecl.single_level_max = slm;
+  static const int summer = [] {
+    const char* e = getenv("NDT_DERIV_SUMMER");  // A/B knob: 0 = ticket + last block, 1 = block 0 polls the rows
+    return e ? atoi(e) : NDT_DERIV_SUMMER_DEFAULT;
+  }();
+  ecl.fixed_summer = summer;
   const int nb = ec.kdtree ? 2 : (ec.direct26 ? 3 : (ec.direct7 ? 1 : 0));
   const size_t dyn_lds = nb >= 2 ? (size_t)KD_CELLS * threads * sizeof(int) : 0;
 #define NDT_LAUNCH(B, M, NBH, GY, FLAG, SEQ)                                                              \

@@ -23,6 +23,21 @@ struct GridGeom {
   int ncells;   // div_b[0] * div_b[1] * div_b[2]
 };
 
+// Geometry + sort plan of one target build, computed ON THE DEVICE by the last block of the
+// bounds kernel (the host used to stop mid-build for it) and read by every later build kernel
+// from device memory; the host gets a copy through pinned memory at the end of the build.
+enum { BG_OK = 0, BG_NO_FINITE = 1, BG_OVERFLOW = 2, BG_CAPACITY = 3, BG_PASSES = 4 };
+struct BuildGeom {
+  GridGeom g;
+  int max_b[3];
+  int bits;       // bits of a cell key, the sentinel `ncells` included
+  int passes;     // digit passes of the radix sort
+  int width[4];   // bits per pass
+  int shift[4];   // first bit of each pass
+  int n_finite;
+  int status;     // BG_*
+};
+
 // What the derivative kernel reads per (point, voxel) pair: 80 B, five 16-B
 // loads.  mean + upper triangle of the inverse covariance in f64 -- the
 // reference keeps both in f64 and forms the Mahalanobis distance in f64
@@ -63,6 +78,7 @@ struct EvalConsts {
   int single_level_max;  // grids with more rows than this take the two-level final sum
   int direct26;    // 1: every valid voxel of the 3x3x3 block around the point's cell (pclomp DIRECT26)
   int score_only;  // 1: score / NVTL / counts only, no gradient or Hessian (ndt_score_transform)
+  int fixed_summer;  // 1: block 0 adds the partial rows (polls their tags), no tickets (single-level grids)
 };
 
 // layout of one evaluation (matches NDT_EVAL_WORDS in include/ndt_hip.h)

@@ -6,46 +6,53 @@
 namespace ndt {
 
 // ---- target voxel-grid build (ndt_target.hip) ------------------------------
-// rows: bounds_rows(n) x 8 ints = ordered-int encoded {min x,y,z, max x,y,z}, #finite, 0
-// per block (device-visible memory); fold_bounds() merges them on the host.
+// One launch: per-block bounds rows (device memory, bounds_rows(n) x 8 ints), the fold of the
+// rows + the grid geometry + the sort plan by the block that draws the last ticket (into *gd,
+// device memory, and *gd_host, a pinned copy for the host to read at the end of the build),
+// the reset of the cells the previous build published (old_stats / dirty_slots), and the
+// zeroing of d_nleaf[0..1].  cell_capacity: cells the dense grid can hold (BG_CAPACITY beyond);
+// planned_passes: digit passes the host has enqueued (0 = the device decides, host reads it).
+// *ticket: zero-initialised, left at zero.
 int bounds_rows(size_t n);
-void launch_bounds(const float* x, const float* y, const float* z, size_t n, int* rows, hipStream_t s);
-void fold_bounds(const int* rows, int nrows, int out[8]);
-float decode_ordered(int enc);
+int sort_passes_for_cells(long long ncells);
+void launch_bounds_geometry(const float* x, const float* y, const float* z, size_t n, float leaf, float inv_leaf,
+                            long long cell_capacity, int planned_passes, int* rows, unsigned int* ticket,
+                            BuildGeom* gd, BuildGeom* gd_host, const LeafStats* old_stats, int dirty_slots,
+                            int* cell2leaf, size_t c2l_cap, int* d_nleaf, hipStream_t s);
 
 // Cell key per point + xyz4 (n x 4 floats, 16-byte aligned: packed copy of the cloud for the
-// per-voxel gather) + the first sort digit's tile histograms into sort_temp.
-void launch_cell_keys(const float* x, const float* y, const float* z, size_t n, const GridGeom& g,
-                      uint32_t* keys, float* xyz4, int end_bit, void* sort_temp, hipStream_t s);
+// per-voxel gather) + the first sort digit's tile histograms into sort_temp.  Geometry and
+// sort plan are read from *gd (device memory); nothing runs if gd->status != BG_OK.
+void launch_cell_keys(const float* x, const float* y, const float* z, size_t n, const BuildGeom* gd,
+                      uint32_t* keys, float* xyz4, void* sort_temp, hipStream_t s);
 
-// Stable LSD radix sort of (key, point index) on the low end_bit bits; values start as the
-// identity.  Ping-pongs between the a and b buffers; *result_in_b tells where the result is.
+// Stable LSD radix sort of (key, point index) on the key bits of the plan in *gd; values start
+// as the identity.  Ping-pongs between the a and b buffers; *result_in_b tells where the result is.
 size_t sort_temp_bytes(size_t n);
 hipError_t sort_pairs(void* temp, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
-                      size_t n, int end_bit, hipStream_t s, bool* result_in_b);
-// test seam: the first digit's histograms for keys that did not come from launch_cell_keys
-void launch_sort_first_count(const uint32_t* keys, size_t n, int end_bit, void* sort_temp, hipStream_t s);
+                      size_t n, int passes, const BuildGeom* gd, hipStream_t s, bool* result_in_b);
+// test seam: a plan for keys of end_bit bits (host struct), and the first digit's histograms
+// for keys that did not come from launch_cell_keys
+void fill_sort_plan(BuildGeom* b, int end_bit);
+void launch_sort_first_count(const uint32_t* keys, size_t n, const BuildGeom* gd, void* sort_temp, hipStream_t s);
 
 // runs of equal cell key with >= min_pts points get a leaf slot (ascending cell order);
 // block_counts / block_offsets: runs_blocks(n) ints each; d_nleaf[0] receives the total
+// (count pass; its last block also scans the counts); *ticket as above
 int runs_blocks(size_t n);
-void launch_find_runs(const uint32_t* keys_sorted, size_t n, int ncells, int min_pts, int* d_nleaf,
-                      int* block_counts, int* block_offsets, int* leaf_start, int* leaf_cnt,
+void launch_find_runs(const uint32_t* keys_sorted, size_t n, const BuildGeom* gd, int min_pts, int* d_nleaf,
+                      int* block_counts, int* block_offsets, unsigned int* ticket, int* leaf_start, int* leaf_cnt,
                       hipStream_t s);
-
-// resets cell2leaf[stats[slot].cell] = -1 for slot < n_slots (the cells the last build published)
-void launch_clear_cells(const LeafStats* stats, int n_slots, int* cell2leaf, size_t cap, hipStream_t s);
 
 struct FinalizeParams {
   double eig_ratio;
   int cov_mode;  // 0 svn, 1 pcl (recalled)
 };
-// sums: 9 doubles per leaf slot (scratch)
-void launch_finalize_leaves(const float* xyz4,
-                            const uint32_t* keys_sorted, const uint32_t* vals_sorted,
-                            int* d_nleaf /* [0]=slots, [1]=valid */, const int* leaf_start,
-                            const int* leaf_cnt, int max_leaves, FinalizeParams fp, double* sums,
-                            VoxelRecord* rec, LeafStats* stats, int* cell2leaf, hipStream_t s);
+// per-leaf sums + statistics in one launch
+void launch_finalize_leaves(const float* xyz4, const uint32_t* keys_sorted, const uint32_t* vals_sorted,
+                            int* d_nleaf /* [0]=slots, [1]=valid */, const int* leaf_start, const int* leaf_cnt,
+                            int max_leaves, FinalizeParams fp, VoxelRecord* rec, LeafStats* stats, int* cell2leaf,
+                            hipStream_t s);
 
 // out[i] = (float)(R x + t) in f64 (sliding-window target assembly); out arrays hold n floats
 // device-to-device copy of three SoA arrays in one launch

@@ -6,17 +6,19 @@
 // inflation, inverse covariance, validity filtering.  How it computes it is
 // MI355X-first and shares nothing with the reference's single-threaded
 // hash-map loop:
-//   1. bounds        : one streaming pass, wave-shuffle min/max, 6 int atomics/block
+//   1. bounds        : one streaming pass, wave-shuffle min/max, one row per block; the block that
+//                      draws the last ticket folds the rows and derives the grid geometry and the
+//                      sort plan ON THE DEVICE (BuildGeom) -- no host round trip in mid-build; the
+//                      same launch resets the cells the previous build published
 //   2. cell keys     : one streaming pass (f32 floor, bit-compatible with the ref)
 //   3. stable LSD radix sort of (cell, point index), hand-written (count / scan /
 //                      scatter per 8-bit digit, wave-ballot ranking) -- points of one
 //                      voxel become contiguous and stay in input order (deterministic sums)
 //   4. run detection : run tails find their head through a wave ballot; leaf slots by
-//                      count / scan / emit (ascending cell order, no atomics)
-//   5. leaf sums     : 8 lanes per voxel gather + reduce sum(x), sum(x x^T) in f64
-//   6. leaf finalise : one thread per voxel: 3x3 Jacobi eigen-solve / inflation /
-//                      inverse; publishes an 80-byte VoxelRecord and the dense
-//                      cell -> leaf index.
+//                      count (+ scan by the last block) / emit (ascending cell order)
+//   5. leaf sums + finalise : 8 lanes per voxel gather + reduce sum(x), sum(x x^T) in f64, then
+//                      the 3x3 Jacobi eigen-solve / inflation / inverse in the same lanes;
+//                      publishes an 80-byte VoxelRecord and the dense cell -> leaf index.
 // Compiled with -ffp-contract=off: f32 index arithmetic must round as written.
 #include "ndt_kernels.h"
 
@@ -38,14 +40,109 @@ __device__ __forceinline__ bool finite3(float a, float b, float c) {
 
 constexpr int BOUNDS_BLOCKS = 512;
 
+__device__ __forceinline__ float decode_ordered_dev(int enc) {
+  return __int_as_float(enc >= 0 ? enc : enc ^ 0x7fffffff);
+}
+
+// Agent-scope accesses for the "last block finishes the job" hand-offs of the build kernels:
+// a block publishes its partial with agent-scope stores by ONE thread, that thread then takes
+// a ticket with release/acquire semantics, and the block that draws the last ticket reads the
+// partials with agent-scope loads.  (Once per block and off the critical path of anything hot:
+// the cost that ruled fences out of k_derivatives does not matter here.)
+__device__ __forceinline__ void st_agent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool last_ticket(unsigned int* ticket, unsigned int nblocks) {
+  const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  return t == nblocks - 1u;
+}
+
+// Grid geometry in f32 exactly as the reference computes it on the host
+// (ref: voxel_grid_covariance_impl.hpp:108-140), plus the sort plan.  planned_passes > 0: the
+// host has already enqueued that many digit passes (sized for `cell_capacity` cells).
+__device__ void derive_geometry(const int mnmx[6], int n_finite, float leaf, float inv_leaf, long long cell_capacity,
+                                int planned_passes, BuildGeom* out) {
+  BuildGeom b;
+  GridGeom& g = b.g;
+  g.leaf = leaf;
+  g.inv_leaf = inv_leaf;
+  b.n_finite = n_finite;
+  b.status = BG_OK;
+  b.bits = 1;
+  b.passes = planned_passes > 0 ? planned_passes : 1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { b.width[i] = 0; b.shift[i] = 0; }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { g.min_b[a] = 0; g.div_b[a] = 0; g.lo[a] = 0.0f; g.hi[a] = 0.0f; b.max_b[a] = 0; }
+  g.mul1 = g.mul2 = g.ncells = 0;
+  if (n_finite == 0) {
+    b.status = BG_NO_FINITE;
+  } else {
+    float mn[3], mx[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { mn[a] = decode_ordered_dev(mnmx[a]); mx[a] = decode_ordered_dev(mnmx[3 + a]); }
+    long long d[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) d[a] = (long long)((mx[a] - mn[a]) * inv_leaf) + 1;
+    const long long lim = 2147483647ll;
+    if (d[0] < 0 || d[1] < 0 || d[2] < 0 || d[0] > lim || d[1] > lim || d[2] > lim || d[0] * d[1] > lim ||
+        d[0] * d[1] * d[2] > lim) {
+      b.status = BG_OVERFLOW;
+    } else {
+      long long ncells = 1;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        g.min_b[a] = (int)floorf(mn[a] * inv_leaf);
+        b.max_b[a] = (int)floorf(mx[a] * inv_leaf);
+        g.div_b[a] = b.max_b[a] - g.min_b[a] + 1;
+        g.lo[a] = (float)g.min_b[a] * leaf;
+        g.hi[a] = (float)(b.max_b[a] + 1) * leaf;
+        ncells *= g.div_b[a];
+      }
+      if (ncells >= lim) {
+        b.status = BG_OVERFLOW;
+      } else {
+        g.mul1 = g.div_b[0];
+        g.mul2 = g.div_b[0] * g.div_b[1];
+        g.ncells = (int)ncells;
+        if (ncells > cell_capacity) b.status = BG_CAPACITY;
+        int bits = 1;
+        while (bits < 32 && (1ull << bits) <= (unsigned long long)ncells) ++bits;  // the sentinel key is `ncells`
+        b.bits = bits;
+        const int need = (bits + 7) / 8;
+        if (planned_passes <= 0) b.passes = need;
+        else if (need > planned_passes && b.status == BG_OK) b.status = BG_PASSES;
+        const int base = bits / b.passes, rem = bits % b.passes;
+        int sh = 0;
+        for (int i = 0; i < b.passes && i < 4; ++i) {
+          b.width[i] = base + (i < rem ? 1 : 0);
+          b.shift[i] = sh;
+          sh += b.width[i];
+        }
+      }
+    }
+  }
+  *out = b;
+}
+
 // ref: pcl::getMinMax3D at voxel_grid_covariance_impl.hpp:103 (non-finite skipped).
-// One row of 8 ints per block {min xyz, max xyz, #finite, 0} written straight into
-// device-mapped pinned host memory; the host (which needs the bounds anyway to size
-// the grid) folds the <= 512 rows.  No atomics: every block contending on the same
-// 7 words cost 0.65 ms for 1M points.
+// One row of 8 ints per block {min xyz, max xyz, #finite, 0}; no atomics on the values (every
+// block contending on the same 7 words cost 0.65 ms for 1M points).  The block that draws the
+// last ticket folds the <= 512 rows, derives the geometry and zeroes the leaf counters; every
+// block also resets its share of the cells the PREVIOUS build published (the dense grid is
+// filled with -1 once per allocation, not per build).
 __global__ void __launch_bounds__(256) k_bounds(const float* __restrict__ x, const float* __restrict__ y,
-                                               const float* __restrict__ z, size_t n, int* __restrict__ rows) {
+                                               const float* __restrict__ z, size_t n, int* __restrict__ rows,
+                                               unsigned int* __restrict__ ticket, float leaf, float inv_leaf,
+                                               long long cell_capacity, int planned_passes,
+                                               BuildGeom* __restrict__ gd, BuildGeom* __restrict__ gd_host,
+                                               const LeafStats* __restrict__ old_stats, int dirty_slots,
+                                               int* __restrict__ cell2leaf, size_t c2l_cap, int* __restrict__ nleaf) {
   __shared__ int lds[4][8];
+  __shared__ int s_last;
+  for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < dirty_slots; slot += gridDim.x * blockDim.x) {
+    const int cell = old_stats[slot].cell;
+    if (cell >= 0 && (size_t)cell < c2l_cap) cell2leaf[cell] = -1;
+  }
   int mn[3] = {INT_MAX, INT_MAX, INT_MAX};
   int mx[3] = {INT_MIN, INT_MIN, INT_MIN};
   int cnt = 0;
@@ -85,14 +182,61 @@ __global__ void __launch_bounds__(256) k_bounds(const float* __restrict__ x, con
     lds[wave][6] = cnt;
   }
   __syncthreads();
-  if (threadIdx.x < 8) {
-    const int t = threadIdx.x;
-    int v = lds[0][t];
-    for (int w = 1; w < 4; ++w) {
-      int o = lds[w][t];
-      v = t < 3 ? min(v, o) : (t < 6 ? max(v, o) : v + o);
+  if (threadIdx.x == 0) {
+    for (int t = 0; t < 7; ++t) {
+      int v = lds[0][t];
+      for (int w = 1; w < 4; ++w) {
+        const int o = lds[w][t];
+        v = t < 3 ? min(v, o) : (t < 6 ? max(v, o) : v + o);
+      }
+      st_agent(rows + blockIdx.x * 8 + t, v);
     }
-    rows[blockIdx.x * 8 + t] = t == 7 ? 0 : v;
+    s_last = last_ticket(ticket, gridDim.x) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  // ---- the last block: fold the rows, derive the geometry ----
+  int fm[6] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN};
+  int fc = 0;
+  for (int r = threadIdx.x; r < (int)gridDim.x; r += blockDim.x) {
+    const int* p = rows + r * 8;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      fm[a] = min(fm[a], ld_agent(p + a));
+      fm[3 + a] = max(fm[3 + a], ld_agent(p + 3 + a));
+    }
+    fc += ld_agent(p + 6);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      fm[a] = min(fm[a], __shfl_xor(fm[a], off));
+      fm[3 + a] = max(fm[3 + a], __shfl_xor(fm[3 + a], off));
+    }
+    fc += __shfl_xor(fc, off);
+  }
+  __syncthreads();  // lds is reused
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 6; ++a) lds[wave][a] = fm[a];
+    lds[wave][6] = fc;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int out[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      int v = lds[0][a];
+      for (int w = 1; w < 4; ++w) v = a < 3 ? min(v, lds[w][a]) : max(v, lds[w][a]);
+      out[a] = v;
+    }
+    const int total = lds[0][6] + lds[1][6] + lds[2][6] + lds[3][6];
+    derive_geometry(out, total, leaf, inv_leaf, cell_capacity, planned_passes, gd);
+    *gd_host = *gd;
+    nleaf[0] = 0;
+    nleaf[1] = 0;
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next build
   }
 }
 
@@ -127,10 +271,14 @@ __device__ __forceinline__ int sort_index(int tile, int wave, int round, int lan
 // Cell key per point (+ the packed float4 copy the per-voxel gather reads) and, in the same
 // pass, the tile histograms of the first sort digit.
 __global__ void __launch_bounds__(SORT_THREADS) k_cell_keys(const float* __restrict__ x, const float* __restrict__ y,
-                                                           const float* __restrict__ z, int n, GridGeom g,
+                                                           const float* __restrict__ z, int n,
+                                                           const BuildGeom* __restrict__ gd,
                                                            uint32_t* __restrict__ keys, float4* __restrict__ xyz4,
-                                                           uint32_t digit_mask, int ntiles, int* __restrict__ hist) {
+                                                           int ntiles, int* __restrict__ hist) {
   __shared__ int h[SORT_BINS];
+  if (gd->status != BG_OK) return;  // uniform: nothing below runs on a refused geometry
+  const GridGeom g = gd->g;
+  const uint32_t digit_mask = (1u << gd->width[0]) - 1u;
   h[threadIdx.x] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -159,9 +307,13 @@ __global__ void __launch_bounds__(SORT_THREADS) k_cell_keys(const float* __restr
   hist[threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
 }
 
-__global__ void __launch_bounds__(SORT_THREADS) k_sort_count(const uint32_t* __restrict__ keys, int n, int shift,
-                                                            uint32_t digit_mask, int ntiles, int* __restrict__ hist) {
+__global__ void __launch_bounds__(SORT_THREADS) k_sort_count(const uint32_t* __restrict__ keys, int n, int pass,
+                                                            const BuildGeom* __restrict__ gd, int ntiles,
+                                                            int* __restrict__ hist) {
   __shared__ int h[SORT_BINS];
+  if (gd->status != BG_OK) return;
+  const int shift = gd->shift[pass];
+  const uint32_t digit_mask = (1u << gd->width[pass]) - 1u;
   h[threadIdx.x] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -214,8 +366,8 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_scan(int* __restrict__ hi
 // FIRST: the values are the identity permutation and are synthesised instead of read
 template <bool FIRST>
 __global__ void __launch_bounds__(SORT_THREADS) k_sort_scatter(const uint32_t* __restrict__ keys_in,
-                                                              const uint32_t* __restrict__ vals_in, int n, int shift,
-                                                              uint32_t digit_mask, int ntiles,
+                                                              const uint32_t* __restrict__ vals_in, int n, int pass,
+                                                              const BuildGeom* __restrict__ gd, int ntiles,
                                                               const int* __restrict__ hist,
                                                               const int* __restrict__ totals,
                                                               uint32_t* __restrict__ keys_out,
@@ -223,6 +375,9 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_scatter(const uint32_t* _
   __shared__ int cnt[SORT_WAVES][SORT_BINS];
   __shared__ int gbase[SORT_BINS];
   __shared__ int wsum[SORT_WAVES];
+  if (gd->status != BG_OK) return;
+  const int shift = gd->shift[pass];
+  const uint32_t digit_mask = (1u << gd->width[pass]) - 1u;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   {  // first output slot of every digit for this tile: bins before it + same bin in earlier tiles
     const int t = totals[threadIdx.x];
@@ -296,12 +451,16 @@ constexpr int RUN_KEYS = 8;
 constexpr int RUN_TILE = 256 * RUN_KEYS;
 
 template <bool EMIT>
-__global__ void __launch_bounds__(256) k_runs(const uint32_t* __restrict__ keys, int n, int ncells, int min_pts,
-                                             int* __restrict__ block_counts,
-                                             const int* __restrict__ block_offsets,
+__global__ void __launch_bounds__(256) k_runs(const uint32_t* __restrict__ keys, int n,
+                                             const BuildGeom* __restrict__ gd, int min_pts,
+                                             int* __restrict__ block_counts, int* __restrict__ block_offsets,
+                                             unsigned int* __restrict__ ticket, int* __restrict__ nleaf_out,
                                              int* __restrict__ leaf_start, int* __restrict__ leaf_cnt) {
   __shared__ int wave_head[4];
   __shared__ int wave_total[4];
+  __shared__ int s_last;
+  if (gd->status != BG_OK) return;
+  const int ncells = gd->g.ncells;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int s0 = blockIdx.x * RUN_TILE + threadIdx.x * RUN_KEYS;
   const uint32_t sentinel = 0xFFFFFFFFu;
@@ -389,7 +548,42 @@ __global__ void __launch_bounds__(256) k_runs(const uint32_t* __restrict__ keys,
   if (lane == 63) wave_total[wave] = lincl;
   __syncthreads();
   if (!EMIT) {
-    if (threadIdx.x == 0) block_counts[blockIdx.x] = wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3];
+    // count pass: publish the block's leaf count; the block that draws the last ticket turns the
+    // counts into exclusive offsets (a separate one-block scan kernel cost a launch: 4.8 us for
+    // 489 values) and writes the total
+    if (threadIdx.x == 0) {
+      st_agent(block_counts + blockIdx.x, wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3]);
+      s_last = last_ticket(ticket, gridDim.x) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __shared__ int wsum[4];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int nblocks = (int)gridDim.x;
+    for (int base = 0; base < nblocks; base += 256) {
+      const int i = base + (int)threadIdx.x;
+      const int v = i < nblocks ? ld_agent(block_counts + i) : 0;
+      int incl = v;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+      }
+      if (lane == 63) wsum[wave] = incl;
+      __syncthreads();
+      int before = carry;
+      for (int w = 0; w < wave; ++w) before += wsum[w];
+      if (i < nblocks) block_offsets[i] = before + incl - v;
+      __syncthreads();
+      if (threadIdx.x == 255) carry = before + incl;
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      nleaf_out[0] = carry;
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     return;
   }
   if (nleaf == 0) return;
@@ -403,35 +597,6 @@ __global__ void __launch_bounds__(256) k_runs(const uint32_t* __restrict__ keys,
       ++slot;
     }
   }
-}
-
-// exclusive scan of the per-block leaf counts (one block; a few thousand values)
-__global__ void __launch_bounds__(1024) k_scan_counts(const int* __restrict__ counts, int nblocks,
-                                                     int* __restrict__ offsets, int* __restrict__ total) {
-  __shared__ int wsum[16];
-  __shared__ int carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int base = 0; base < nblocks; base += 1024) {
-    const int i = base + threadIdx.x;
-    const int v = i < nblocks ? counts[i] : 0;
-    int incl = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      int t = __shfl_up(incl, off);
-      if (lane >= off) incl += t;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    int before = carry;
-    for (int w = 0; w < wave; ++w) before += wsum[w];
-    if (i < nblocks) offsets[i] = before + incl - v;
-    __syncthreads();
-    if (threadIdx.x == 1023) carry = before + incl;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) total[0] = carry;
 }
 
 // one Jacobi rotation of the symmetric 3x3 A (full storage) in the (P,Q) plane
@@ -503,92 +668,14 @@ __device__ __forceinline__ void moments_xor_tree(Moments& m) {
   }
 }
 
-__global__ void __launch_bounds__(256) k_leaf_sums(const float4* __restrict__ xyz4, const uint32_t* __restrict__ vals,
-                                                  const int* __restrict__ nleaf_p,
-                                                  const int* __restrict__ leaf_start,
-                                                  const int* __restrict__ leaf_cnt, double* __restrict__ sums) {
-  const int nleaf = nleaf_p[0];
-  const int lane = threadIdx.x & 63;
-  const int sub = lane & (LANES_PER_LEAF - 1);
-  const int per_block = 256 / LANES_PER_LEAF;
-  // Wave W takes the leaves W, W + rows, W + 2 rows, ... (rows = ceil(nleaf / 8)): crowded voxels
-  // are neighbours in cell order (a wall, the road), and eight of them in one wave would
-  // serialise.  The loop bound is wave-uniform: all 8 leaves of a wave step together.
-  const int rows = (nleaf + 7) >> 3;
-  for (int row = blockIdx.x * (per_block / 8) + (threadIdx.x >> 6); row < rows; row += gridDim.x * (per_block / 8)) {
-    const int slot = row + (lane >> 3) * rows;
-    const bool have = slot < nleaf;
-    const int start = have ? leaf_start[slot] : 0, cnt = have ? leaf_cnt[slot] : 0;
-    Moments m{};
-    // four gathers in flight per lane (index load -> point load is a dependent pair);
-    // the adds stay in point order, masked lanes add exact zeros
-    const int head = cnt < LEAF_HEAD ? cnt : LEAF_HEAD;
-    for (int j0 = sub; j0 < head; j0 += 4 * LANES_PER_LEAF) {
-      float4 p[4];
-      bool live[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int j = j0 + u * LANES_PER_LEAF;
-        live[u] = j < head;
-        p[u] = xyz4[vals[start + (live[u] ? j : 0)]];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) moments_add(m, p[u], live[u]);
-    }
-    moments_xor_tree<LANES_PER_LEAF>(m);
-    // crowded leaves: the whole wave gathers the rest
-    unsigned long long crowded = __ballot(cnt > LEAF_HEAD);
-    while (crowded) {
-      const int src = __ffsll((long long)crowded) - 1;  // first lane of that leaf's group
-      crowded &= ~(0xFFull << (src & ~7));
-      const int bstart = __shfl(start, src), bcnt = __shfl(cnt, src);
-      Moments t{};
-      for (int j0 = LEAF_HEAD + lane; j0 < bcnt; j0 += 4 * 64) {
-        float4 p[4];
-        bool live[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int j = j0 + u * 64;
-          live[u] = j < bcnt;
-          p[u] = xyz4[vals[bstart + (live[u] ? j : LEAF_HEAD)]];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) moments_add(t, p[u], live[u]);
-      }
-      moments_xor_tree<64>(t);
-      if ((lane >> 3) == (src >> 3)) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) m.s[a] += t.s[a];
-#pragma unroll
-        for (int a = 0; a < 6; ++a) m.ss[a] += t.ss[a];
-      }
-    }
-    if (!have) continue;
-    // the 8 lanes hold identical sums; lane k writes word k, lane 0 also word 8
-    double* o = sums + (size_t)slot * 9;
-    const double mine = sub == 0 ? m.s[0] : sub == 1 ? m.s[1] : sub == 2 ? m.s[2] : sub == 3 ? m.ss[0]
-                      : sub == 4 ? m.ss[1] : sub == 5 ? m.ss[2] : sub == 6 ? m.ss[3] : m.ss[4];
-    o[sub] = mine;
-    if (sub == 0) o[8] = m.ss[5];
-  }
-}
-
-// ref: voxel_grid_covariance_impl.hpp:265-343 -- one thread per leaf: mean, covariance,
-// eigen-decomposition, eigenvalue inflation, inverse, validity checks.
-__global__ void __launch_bounds__(64) k_leaf_finalize(const uint32_t* __restrict__ keys,
-                                                      int* __restrict__ nleaf_p,
-                                                      const int* __restrict__ leaf_start,
-                                                      const int* __restrict__ leaf_cnt,
-                                                      const double* __restrict__ sums, FinalizeParams fp,
-                                                      VoxelRecord* __restrict__ rec, LeafStats* __restrict__ stats,
-                                                      int* __restrict__ cell2leaf) {
-  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot >= nleaf_p[0]) return;
-  const int start = leaf_start[slot], cnt = leaf_cnt[slot];
-  const double* in = sums + (size_t)slot * 9;
-  const double s[3] = {in[0], in[1], in[2]};
-  const double ss[6] = {in[3], in[4], in[5], in[6], in[7], in[8]};
-  const int cell = (int)keys[start];
+// ref: voxel_grid_covariance_impl.hpp:265-343 -- per leaf: mean, covariance, eigen-decomposition,
+// eigenvalue inflation, inverse, validity checks.  Runs in the 8 lanes that just summed the
+// leaf (they hold identical sums and compute identical results; `writer` publishes them), so the
+// sums never travel through memory and the build is one launch shorter.
+__device__ __forceinline__ void finalize_leaf(int slot, int cell, int cnt, const double s[3], const double ss[6],
+                                              bool writer, int* __restrict__ nleaf_p, FinalizeParams fp,
+                                              VoxelRecord* __restrict__ rec, LeafStats* __restrict__ stats,
+                                              int* __restrict__ cell2leaf) {
   const double n = (double)cnt;
   double mean[3] = {s[0] / n, s[1] / n, s[2] / n};  // ref :278
   double C[9];
@@ -679,6 +766,7 @@ __global__ void __launch_bounds__(64) k_leaf_finalize(const uint32_t* __restrict
 #pragma unroll
   for (int a = 0; a < 3; ++a) L.evals[a] = d[a];
   if (!ok) L.count = -cnt;
+  if (!writer) return;
   stats[slot] = L;
   // Every slot gets a finite record: the derivative kernel reads record 0 for an absent
   // neighbour (masked by f = 0, but 0 * NaN would still poison the sums), and slot 0 may well be
@@ -695,12 +783,71 @@ __global__ void __launch_bounds__(64) k_leaf_finalize(const uint32_t* __restrict
   }
 }
 
-__global__ void __launch_bounds__(256) k_clear_cells(const LeafStats* __restrict__ stats, int n_slots,
-                                                    int* __restrict__ cell2leaf, size_t cap) {
-  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot >= n_slots) return;
-  const int cell = stats[slot].cell;
-  if (cell >= 0 && (size_t)cell < cap) cell2leaf[cell] = -1;
+__global__ void __launch_bounds__(256) k_leaf_sums(const float4* __restrict__ xyz4, const uint32_t* __restrict__ keys,
+                                                  const uint32_t* __restrict__ vals, int* __restrict__ nleaf_p,
+                                                  const int* __restrict__ leaf_start,
+                                                  const int* __restrict__ leaf_cnt, FinalizeParams fp,
+                                                  VoxelRecord* __restrict__ rec, LeafStats* __restrict__ stats,
+                                                  int* __restrict__ cell2leaf) {
+  const int nleaf = nleaf_p[0];
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & (LANES_PER_LEAF - 1);
+  const int per_block = 256 / LANES_PER_LEAF;
+  // Wave W takes the leaves W, W + rows, W + 2 rows, ... (rows = ceil(nleaf / 8)): crowded voxels
+  // are neighbours in cell order (a wall, the road), and eight of them in one wave would
+  // serialise.  The loop bound is wave-uniform: all 8 leaves of a wave step together.
+  const int rows = (nleaf + 7) >> 3;
+  for (int row = blockIdx.x * (per_block / 8) + (threadIdx.x >> 6); row < rows; row += gridDim.x * (per_block / 8)) {
+    const int slot = row + (lane >> 3) * rows;
+    const bool have = slot < nleaf;
+    const int start = have ? leaf_start[slot] : 0, cnt = have ? leaf_cnt[slot] : 0;
+    Moments m{};
+    // four gathers in flight per lane (index load -> point load is a dependent pair);
+    // the adds stay in point order, masked lanes add exact zeros
+    const int head = cnt < LEAF_HEAD ? cnt : LEAF_HEAD;
+    for (int j0 = sub; j0 < head; j0 += 4 * LANES_PER_LEAF) {
+      float4 p[4];
+      bool live[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = j0 + u * LANES_PER_LEAF;
+        live[u] = j < head;
+        p[u] = xyz4[vals[start + (live[u] ? j : 0)]];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) moments_add(m, p[u], live[u]);
+    }
+    moments_xor_tree<LANES_PER_LEAF>(m);
+    // crowded leaves: the whole wave gathers the rest
+    unsigned long long crowded = __ballot(cnt > LEAF_HEAD);
+    while (crowded) {
+      const int src = __ffsll((long long)crowded) - 1;  // first lane of that leaf's group
+      crowded &= ~(0xFFull << (src & ~7));
+      const int bstart = __shfl(start, src), bcnt = __shfl(cnt, src);
+      Moments t{};
+      for (int j0 = LEAF_HEAD + lane; j0 < bcnt; j0 += 4 * 64) {
+        float4 p[4];
+        bool live[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = j0 + u * 64;
+          live[u] = j < bcnt;
+          p[u] = xyz4[vals[bstart + (live[u] ? j : LEAF_HEAD)]];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) moments_add(t, p[u], live[u]);
+      }
+      moments_xor_tree<64>(t);
+      if ((lane >> 3) == (src >> 3)) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) m.s[a] += t.s[a];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) m.ss[a] += t.ss[a];
+      }
+    }
+    if (!have) continue;
+    finalize_leaf(slot, (int)keys[start], cnt, m.s, m.ss, sub == 0, nleaf_p, fp, rec, stats, cell2leaf);
+  }
 }
 
 // Sliding-window target assembly: one archived body-frame scan moved into the
@@ -761,13 +908,6 @@ void launch_transform_append(const float* x, const float* y, const float* z, siz
                      ox, oy, oz);
 }
 
-float decode_ordered(int enc) {
-  int i = enc >= 0 ? enc : enc ^ 0x7fffffff;
-  float f;
-  memcpy(&f, &i, sizeof(f));
-  return f;
-}
-
 int bounds_rows(size_t n) {
   size_t blocks = (n + 255) / 256;
   if (blocks > (size_t)BOUNDS_BLOCKS) blocks = BOUNDS_BLOCKS;
@@ -775,21 +915,18 @@ int bounds_rows(size_t n) {
   return (int)blocks;
 }
 
-void launch_bounds(const float* x, const float* y, const float* z, size_t n, int* rows, hipStream_t s) {
-  hipLaunchKernelGGL(k_bounds, dim3((unsigned)bounds_rows(n)), dim3(256), 0, s, x, y, z, n, rows);
+int sort_passes_for_cells(long long ncells) {
+  int bits = 1;
+  while (bits < 32 && (1ull << bits) <= (unsigned long long)ncells) ++bits;
+  return (bits + 7) / 8;
 }
 
-void fold_bounds(const int* rows, int nrows, int out[8]) {
-  for (int a = 0; a < 3; ++a) { out[a] = INT_MAX; out[3 + a] = INT_MIN; }
-  out[6] = out[7] = 0;
-  for (int r = 0; r < nrows; ++r) {
-    const int* p = rows + 8 * r;
-    for (int a = 0; a < 3; ++a) {
-      out[a] = p[a] < out[a] ? p[a] : out[a];
-      out[3 + a] = p[3 + a] > out[3 + a] ? p[3 + a] : out[3 + a];
-    }
-    out[6] += p[6];
-  }
+void launch_bounds_geometry(const float* x, const float* y, const float* z, size_t n, float leaf, float inv_leaf,
+                            long long cell_capacity, int planned_passes, int* rows, unsigned int* ticket,
+                            BuildGeom* gd, BuildGeom* gd_host, const LeafStats* old_stats, int dirty_slots,
+                            int* cell2leaf, size_t c2l_cap, int* d_nleaf, hipStream_t s) {
+  hipLaunchKernelGGL(k_bounds, dim3((unsigned)bounds_rows(n)), dim3(256), 0, s, x, y, z, n, rows, ticket, leaf, inv_leaf,
+                     cell_capacity, planned_passes, gd, gd_host, old_stats, dirty_slots, cell2leaf, c2l_cap, d_nleaf);
 }
 
 int sort_tiles(size_t n) { return (int)((n + SORT_TILE - 1) / SORT_TILE); }
@@ -797,107 +934,85 @@ int sort_tiles(size_t n) { return (int)((n + SORT_TILE - 1) / SORT_TILE); }
 // scratch of the sort: the bin-major tile histograms + the bin totals
 size_t sort_temp_bytes(size_t n) { return ((size_t)SORT_BINS * sort_tiles(n) + SORT_BINS) * sizeof(int); }
 
-namespace {
-struct SortPlan {
-  int passes;
-  int width[4];
-};
-// ceil(bits / 8) digit passes of near-equal width (23 bits: 8 + 8 + 7)
-SortPlan sort_plan(int end_bit) {
-  SortPlan p{};
+void fill_sort_plan(BuildGeom* b, int end_bit) {
   if (end_bit < 1) end_bit = 1;
   if (end_bit > 32) end_bit = 32;
-  p.passes = (end_bit + 7) / 8;
-  const int base = end_bit / p.passes, rem = end_bit % p.passes;
-  for (int i = 0; i < p.passes; ++i) p.width[i] = base + (i < rem ? 1 : 0);
-  return p;
+  b->bits = end_bit;
+  b->passes = (end_bit + 7) / 8;
+  const int base = end_bit / b->passes, rem = end_bit % b->passes;
+  int sh = 0;
+  for (int i = 0; i < 4; ++i) {
+    b->width[i] = i < b->passes ? base + (i < rem ? 1 : 0) : 0;
+    b->shift[i] = sh;
+    sh += b->width[i];
+  }
 }
-}  // namespace
 
-void launch_cell_keys(const float* x, const float* y, const float* z, size_t n, const GridGeom& g,
-                      uint32_t* keys, float* xyz4, int end_bit, void* sort_temp, hipStream_t s) {
+void launch_cell_keys(const float* x, const float* y, const float* z, size_t n, const BuildGeom* gd,
+                      uint32_t* keys, float* xyz4, void* sort_temp, hipStream_t s) {
   if (n == 0) return;
   const int ntiles = sort_tiles(n);
-  const SortPlan plan = sort_plan(end_bit);
-  hipLaunchKernelGGL(k_cell_keys, dim3((unsigned)ntiles), dim3(SORT_THREADS), 0, s, x, y, z, (int)n, g, keys,
-                     reinterpret_cast<float4*>(xyz4), (1u << plan.width[0]) - 1u, ntiles,
+  hipLaunchKernelGGL(k_cell_keys, dim3((unsigned)ntiles), dim3(SORT_THREADS), 0, s, x, y, z, (int)n, gd, keys,
+                     reinterpret_cast<float4*>(xyz4), ntiles, static_cast<int*>(sort_temp));
+}
+
+void launch_sort_first_count(const uint32_t* keys, size_t n, const BuildGeom* gd, void* sort_temp, hipStream_t s) {
+  if (n == 0) return;
+  const int ntiles = sort_tiles(n);
+  hipLaunchKernelGGL(k_sort_count, dim3((unsigned)ntiles), dim3(SORT_THREADS), 0, s, keys, (int)n, 0, gd, ntiles,
                      static_cast<int*>(sort_temp));
 }
 
-void launch_sort_first_count(const uint32_t* keys, size_t n, int end_bit, void* sort_temp, hipStream_t s) {
-  if (n == 0) return;
-  const int ntiles = sort_tiles(n);
-  const SortPlan plan = sort_plan(end_bit);
-  hipLaunchKernelGGL(k_sort_count, dim3((unsigned)ntiles), dim3(SORT_THREADS), 0, s, keys, (int)n, 0,
-                     (1u << plan.width[0]) - 1u, ntiles, static_cast<int*>(sort_temp));
-}
-
-// Sorts (keys_a, identity) by the low end_bit bits of the key, stable.  The first digit's tile
-// histograms must already be in `temp` (launch_cell_keys).  The passes ping-pong between the
-// a and b buffers; *result_in_b says where the sorted pairs ended up.
+// Sorts (keys_a, identity) by the key bits of the plan in *gd (device memory), stable, in
+// `passes` digit passes.  The first digit's tile histograms must already be in `temp`
+// (launch_cell_keys).  The passes ping-pong between the a and b buffers; *result_in_b says
+// where the sorted pairs ended up.
 hipError_t sort_pairs(void* temp, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
-                      size_t n, int end_bit, hipStream_t s, bool* result_in_b) {
+                      size_t n, int passes, const BuildGeom* gd, hipStream_t s, bool* result_in_b) {
   *result_in_b = false;
   if (n == 0) return hipSuccess;
   const int ntiles = sort_tiles(n);
   int* hist = static_cast<int*>(temp);
   int* totals = hist + (size_t)SORT_BINS * ntiles;
-  const SortPlan plan = sort_plan(end_bit);
   uint32_t *kin = keys_a, *kout = keys_b, *vin = vals_a, *vout = vals_b;
-  int shift = 0;
-  for (int p = 0; p < plan.passes; ++p) {
-    const uint32_t mask = (1u << plan.width[p]) - 1u;
+  for (int p = 0; p < passes; ++p) {
     if (p > 0)
-      hipLaunchKernelGGL(k_sort_count, dim3((unsigned)ntiles), dim3(SORT_THREADS), 0, s, kin, (int)n, shift, mask,
-                         ntiles, hist);
+      hipLaunchKernelGGL(k_sort_count, dim3((unsigned)ntiles), dim3(SORT_THREADS), 0, s, kin, (int)n, p, gd, ntiles, hist);
     hipLaunchKernelGGL(k_sort_scan, dim3(SORT_BINS), dim3(SORT_THREADS), 0, s, hist, ntiles, totals);
     if (p == 0)
-      hipLaunchKernelGGL(k_sort_scatter<true>, dim3((unsigned)ntiles), dim3(SORT_THREADS), 0, s, kin, vin, (int)n,
-                         shift, mask, ntiles, hist, totals, kout, vout);
+      hipLaunchKernelGGL(k_sort_scatter<true>, dim3((unsigned)ntiles), dim3(SORT_THREADS), 0, s, kin, vin, (int)n, p, gd,
+                         ntiles, hist, totals, kout, vout);
     else
-      hipLaunchKernelGGL(k_sort_scatter<false>, dim3((unsigned)ntiles), dim3(SORT_THREADS), 0, s, kin, vin, (int)n,
-                         shift, mask, ntiles, hist, totals, kout, vout);
-    shift += plan.width[p];
+      hipLaunchKernelGGL(k_sort_scatter<false>, dim3((unsigned)ntiles), dim3(SORT_THREADS), 0, s, kin, vin, (int)n, p, gd,
+                         ntiles, hist, totals, kout, vout);
     uint32_t* t = kin; kin = kout; kout = t;
     t = vin; vin = vout; vout = t;
   }
-  *result_in_b = (plan.passes & 1) != 0;
+  *result_in_b = (passes & 1) != 0;
   return hipGetLastError();
 }
 
 int runs_blocks(size_t n) { return (int)((n + RUN_TILE - 1) / RUN_TILE); }
 
-void launch_find_runs(const uint32_t* keys_sorted, size_t n, int ncells, int min_pts, int* d_nleaf,
-                      int* block_counts, int* block_offsets, int* leaf_start, int* leaf_cnt,
+void launch_find_runs(const uint32_t* keys_sorted, size_t n, const BuildGeom* gd, int min_pts, int* d_nleaf,
+                      int* block_counts, int* block_offsets, unsigned int* ticket, int* leaf_start, int* leaf_cnt,
                       hipStream_t s) {
   if (n == 0) return;
   const int blocks = runs_blocks(n);
-  hipLaunchKernelGGL(k_runs<false>, dim3(blocks), dim3(256), 0, s, keys_sorted, (int)n, ncells, min_pts,
-                     block_counts, (const int*)nullptr, leaf_start, leaf_cnt);
-  hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, block_counts, blocks, block_offsets, d_nleaf);
-  hipLaunchKernelGGL(k_runs<true>, dim3(blocks), dim3(256), 0, s, keys_sorted, (int)n, ncells, min_pts,
-                     block_counts, block_offsets, leaf_start, leaf_cnt);
+  hipLaunchKernelGGL(k_runs<false>, dim3(blocks), dim3(256), 0, s, keys_sorted, (int)n, gd, min_pts, block_counts,
+                     block_offsets, ticket, d_nleaf, leaf_start, leaf_cnt);
+  hipLaunchKernelGGL(k_runs<true>, dim3(blocks), dim3(256), 0, s, keys_sorted, (int)n, gd, min_pts, block_counts,
+                     block_offsets, ticket, d_nleaf, leaf_start, leaf_cnt);
 }
 
-void launch_clear_cells(const LeafStats* stats, int n_slots, int* cell2leaf, size_t cap, hipStream_t s) {
-  if (n_slots <= 0) return;
-  hipLaunchKernelGGL(k_clear_cells, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, s, stats, n_slots, cell2leaf,
-                     cap);
-}
-
-void launch_finalize_leaves(const float* xyz4,
-                            const uint32_t* keys_sorted, const uint32_t* vals_sorted,
-                            int* d_nleaf, const int* leaf_start, const int* leaf_cnt,
-                            int max_leaves, FinalizeParams fp, double* sums, VoxelRecord* rec,
-                            LeafStats* stats, int* cell2leaf, hipStream_t s) {
+void launch_finalize_leaves(const float* xyz4, const uint32_t* keys_sorted, const uint32_t* vals_sorted,
+                            int* d_nleaf, const int* leaf_start, const int* leaf_cnt, int max_leaves,
+                            FinalizeParams fp, VoxelRecord* rec, LeafStats* stats, int* cell2leaf, hipStream_t s) {
   if (max_leaves <= 0) return;
   size_t blocks = ((size_t)max_leaves * LANES_PER_LEAF + 255) / 256;
   if (blocks > (size_t)SUMS_BLOCKS_MAX) blocks = SUMS_BLOCKS_MAX;
-  hipLaunchKernelGGL(k_leaf_sums, dim3((unsigned)blocks), dim3(256), 0, s,
-                     reinterpret_cast<const float4*>(xyz4), vals_sorted, d_nleaf,
-                     leaf_start, leaf_cnt, sums);
-  hipLaunchKernelGGL(k_leaf_finalize, dim3((unsigned)((max_leaves + 63) / 64)), dim3(64), 0, s,
-                     keys_sorted, d_nleaf, leaf_start, leaf_cnt, sums, fp, rec, stats, cell2leaf);
+  hipLaunchKernelGGL(k_leaf_sums, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(xyz4),
+                     keys_sorted, vals_sorted, d_nleaf, leaf_start, leaf_cnt, fp, rec, stats, cell2leaf);
 }
 
 }  // namespace ndt
