@@ -85,6 +85,7 @@ struct ndt_handle {
   DevBuf<char> sort_tmp;
   DevBuf<int> nleaf;                 // [0] slots, [1] valid
   DevBuf<int> leaf_start, leaf_cnt, run_counts, run_offsets;
+  DevBuf<double> leaf_sums;
   DevBuf<int> brows;                 // per-block bounds rows
   DevBuf<unsigned int> tickets;      // [0] bounds kernel, [1] run-count kernel; zero between launches
   DevBuf<BuildGeom> gd;              // geometry + sort plan of the build, derived on the device
@@ -250,6 +251,7 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
   HIP_TRY(h, h->leaf_start.ensure((size_t)max_leaves));
   HIP_TRY(h, h->leaf_cnt.ensure((size_t)max_leaves));
   HIP_TRY(h, h->rec.ensure((size_t)max_leaves));
+  HIP_TRY(h, h->leaf_sums.ensure((size_t)max_leaves * 9));
   HIP_TRY(h, h->run_counts.ensure((size_t)runs_blocks(n)));
   HIP_TRY(h, h->run_offsets.ensure((size_t)runs_blocks(n)));
   HIP_TRY(h, h->sort_tmp.ensure(sort_temp_bytes(n)));
@@ -284,7 +286,7 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
                      h->leaf_start.p, h->leaf_cnt.p, s);
     FinalizeParams fp{h->prm.eig_inflation_ratio, h->prm.cov_mode};
     launch_finalize_leaves(h->xyz4.p, keys_sorted, vals_sorted, h->nleaf.p, h->leaf_start.p, h->leaf_cnt.p, max_leaves,
-                           fp, h->rec.p, h->stats.p, h->cell2leaf.p, s);
+                           fp, h->leaf_sums.p, h->rec.p, h->stats.p, h->cell2leaf.p, s);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(h->small.h + 8, h->nleaf.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipEventRecord(h->ev1, s));
@@ -566,7 +568,7 @@ int ndt_destroy(ndt_handle* h) {
   h->keys.release(); h->vals.release(); h->keys2.release(); h->vals2.release();
   h->sort_tmp.release(); h->nleaf.release(); h->leaf_start.release(); h->leaf_cnt.release();
   h->cell2leaf.release(); h->rec.release(); h->stats.release();
-  h->run_counts.release(); h->run_offsets.release(); h->xyz4.release();
+  h->run_counts.release(); h->run_offsets.release(); h->xyz4.release(); h->leaf_sums.release();
   h->brows.release(); h->tickets.release(); h->gd.release(); h->gdh.release();
   for (auto& kv : h->keyframes) { kv.second.x.release(); kv.second.y.release(); kv.second.z.release(); }
   h->keyframes.clear();

@@ -411,7 +411,7 @@ __device__ unsigned int g_hwid[4096 * 2];
 #endif
 
 #ifndef NDT_DERIV_SUMMER_DEFAULT
-#define NDT_DERIV_SUMMER_DEFAULT 0
+#define NDT_DERIV_SUMMER_DEFAULT 1
 #endif
 constexpr int NGROUPS = 32;          // second-level fan-in (only for grids above SINGLE_LEVEL_MAX rows)
 constexpr int SINGLE_LEVEL_MAX_DEFAULT = 2048;  // rows one block adds directly
@@ -720,10 +720,11 @@ int derivs_read_stamps(unsigned long long* out, int nblocks) {
 // 126 VGPRs two such blocks fill a CU (4 waves/SIMD); smaller blocks multiply the partial
 // rows of the in-kernel final sum, larger ones make every wave wait on wider barriers
 // (sweep 128..832 in profiles/r01_block_sweep.txt).  One exception, single-pose launches of
-// 164k..262k points (the 200k-point scan of the headline workload): 1024-thread blocks still
-// put at most one block on every CU (same 4 waves/SIMD on the busiest) and leave <= 256 rows,
-// which the final sum reads in ONE round trip (a 512-thread final block covers 16 x SUM_BATCH =
-// 320 rows per trip): 23.4 vs 24.4 us per evaluation.  NDT_DERIV_BLOCK overrides it for tuning.
+// 131k..262k points (the 200k-point scan of the headline workload): the block is sized so that
+// the grid is at most one block per CU (256 CUs) -- 200 000 points: 832 threads, 241 blocks --
+// which keeps every CU at <= 4 waves/SIMD and leaves <= 256 rows for the final sum
+// (profiles/r02_block_sweep.txt: 16.6 us at 832, 17.2 at 1024, 20.3 at 512).
+// NDT_DERIV_BLOCK overrides it for tuning.
 int derivs_block_threads(size_t n_src, int K) {
   static const int forced = [] {
     const char* e = getenv("NDT_DERIV_BLOCK");  // multiple of 64, 64..1024
@@ -731,7 +732,11 @@ int derivs_block_threads(size_t n_src, int K) {
     return (v >= 64 && v <= MAX_BLOCK && v % 64 == 0) ? v : 0;
   }();
   if (forced) return forced;
-  if (K == 1 && n_src > (size_t)512 * 16 * SUM_BATCH && n_src <= (size_t)1024 * 256) return 1024;
+  constexpr size_t kCUs = 256;
+  if (K == 1 && n_src > (size_t)512 * kCUs && n_src <= (size_t)MAX_BLOCK * kCUs) {
+    const size_t per_cu = (n_src + kCUs - 1) / kCUs;
+    return (int)(((per_cu + 63) / 64) * 64);
+  }
   return 512;
 }
 

@@ -48,11 +48,11 @@ struct FinalizeParams {
   double eig_ratio;
   int cov_mode;  // 0 svn, 1 pcl (recalled)
 };
-// per-leaf sums + statistics in one launch
+// per-leaf sums, then per-leaf statistics; sums: 9 doubles per leaf slot (scratch)
 void launch_finalize_leaves(const float* xyz4, const uint32_t* keys_sorted, const uint32_t* vals_sorted,
                             int* d_nleaf /* [0]=slots, [1]=valid */, const int* leaf_start, const int* leaf_cnt,
-                            int max_leaves, FinalizeParams fp, VoxelRecord* rec, LeafStats* stats, int* cell2leaf,
-                            hipStream_t s);
+                            int max_leaves, FinalizeParams fp, double* sums, VoxelRecord* rec, LeafStats* stats,
+                            int* cell2leaf, hipStream_t s);
 
 // out[i] = (float)(R x + t) in f64 (sliding-window target assembly); out arrays hold n floats
 // device-to-device copy of three SoA arrays in one launch

@@ -16,9 +16,10 @@
 //                      voxel become contiguous and stay in input order (deterministic sums)
 //   4. run detection : run tails find their head through a wave ballot; leaf slots by
 //                      count (+ scan by the last block) / emit (ascending cell order)
-//   5. leaf sums + finalise : 8 lanes per voxel gather + reduce sum(x), sum(x x^T) in f64, then
-//                      the 3x3 Jacobi eigen-solve / inflation / inverse in the same lanes;
-//                      publishes an 80-byte VoxelRecord and the dense cell -> leaf index.
+//   5. leaf sums     : 8 lanes per voxel gather + reduce sum(x), sum(x x^T) in f64
+//   6. leaf finalise : one thread per voxel: 3x3 Jacobi eigen-solve / inflation /
+//                      inverse; publishes an 80-byte VoxelRecord and the dense
+//                      cell -> leaf index.
 // Compiled with -ffp-contract=off: f32 index arithmetic must round as written.
 #include "ndt_kernels.h"
 
@@ -45,14 +46,17 @@ __device__ __forceinline__ float decode_ordered_dev(int enc) {
 }
 
 // Agent-scope accesses for the "last block finishes the job" hand-offs of the build kernels:
-// a block publishes its partial with agent-scope stores by ONE thread, that thread then takes
-// a ticket with release/acquire semantics, and the block that draws the last ticket reads the
-// partials with agent-scope loads.  (Once per block and off the critical path of anything hot:
-// the cost that ruled fences out of k_derivatives does not matter here.)
+// a block publishes its partial with agent-scope stores by ONE thread, that thread waits for
+// them to be acknowledged and takes a relaxed ticket, and the block that draws the last ticket
+// reads the partials with agent-scope loads (cdna_hip_programming.md Guideline 16).
 __device__ __forceinline__ void st_agent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ bool last_ticket(unsigned int* ticket, unsigned int nblocks) {
-  const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  // the partial was written with agent-scope (write-through) stores by THIS thread: once they are
+  // acknowledged (vmcnt drained) a relaxed ticket is enough -- no release fence, whose L2
+  // write-back cost ~7 us per kernel here -- and the reader uses agent-scope loads
+  __builtin_amdgcn_s_waitcnt(0);
+  const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return t == nblocks - 1u;
 }
 
@@ -668,14 +672,24 @@ __device__ __forceinline__ void moments_xor_tree(Moments& m) {
   }
 }
 
-// ref: voxel_grid_covariance_impl.hpp:265-343 -- per leaf: mean, covariance, eigen-decomposition,
-// eigenvalue inflation, inverse, validity checks.  Runs in the 8 lanes that just summed the
-// leaf (they hold identical sums and compute identical results; `writer` publishes them), so the
-// sums never travel through memory and the build is one launch shorter.
-__device__ __forceinline__ void finalize_leaf(int slot, int cell, int cnt, const double s[3], const double ss[6],
-                                              bool writer, int* __restrict__ nleaf_p, FinalizeParams fp,
-                                              VoxelRecord* __restrict__ rec, LeafStats* __restrict__ stats,
-                                              int* __restrict__ cell2leaf) {
+// ref: voxel_grid_covariance_impl.hpp:265-343 -- one thread per leaf: mean, covariance,
+// eigen-decomposition, eigenvalue inflation, inverse, validity checks.  (Fusing this into the
+// 8 lanes that sum a leaf was tried in round 2: 48 us against 20 + 12 -- the Jacobi state on top
+// of the moments spills, and 8 of 64 lanes do distinct work.)
+__global__ void __launch_bounds__(64) k_leaf_finalize(const uint32_t* __restrict__ keys,
+                                                      int* __restrict__ nleaf_p,
+                                                      const int* __restrict__ leaf_start,
+                                                      const int* __restrict__ leaf_cnt,
+                                                      const double* __restrict__ sums, FinalizeParams fp,
+                                                      VoxelRecord* __restrict__ rec, LeafStats* __restrict__ stats,
+                                                      int* __restrict__ cell2leaf) {
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= nleaf_p[0]) return;
+  const int start = leaf_start[slot], cnt = leaf_cnt[slot];
+  const double* in = sums + (size_t)slot * 9;
+  const double s[3] = {in[0], in[1], in[2]};
+  const double ss[6] = {in[3], in[4], in[5], in[6], in[7], in[8]};
+  const int cell = (int)keys[start];
   const double n = (double)cnt;
   double mean[3] = {s[0] / n, s[1] / n, s[2] / n};  // ref :278
   double C[9];
@@ -766,7 +780,6 @@ __device__ __forceinline__ void finalize_leaf(int slot, int cell, int cnt, const
 #pragma unroll
   for (int a = 0; a < 3; ++a) L.evals[a] = d[a];
   if (!ok) L.count = -cnt;
-  if (!writer) return;
   stats[slot] = L;
   // Every slot gets a finite record: the derivative kernel reads record 0 for an absent
   // neighbour (masked by f = 0, but 0 * NaN would still poison the sums), and slot 0 may well be
@@ -783,12 +796,10 @@ __device__ __forceinline__ void finalize_leaf(int slot, int cell, int cnt, const
   }
 }
 
-__global__ void __launch_bounds__(256) k_leaf_sums(const float4* __restrict__ xyz4, const uint32_t* __restrict__ keys,
-                                                  const uint32_t* __restrict__ vals, int* __restrict__ nleaf_p,
+__global__ void __launch_bounds__(256) k_leaf_sums(const float4* __restrict__ xyz4, const uint32_t* __restrict__ vals,
+                                                  const int* __restrict__ nleaf_p,
                                                   const int* __restrict__ leaf_start,
-                                                  const int* __restrict__ leaf_cnt, FinalizeParams fp,
-                                                  VoxelRecord* __restrict__ rec, LeafStats* __restrict__ stats,
-                                                  int* __restrict__ cell2leaf) {
+                                                  const int* __restrict__ leaf_cnt, double* __restrict__ sums) {
   const int nleaf = nleaf_p[0];
   const int lane = threadIdx.x & 63;
   const int sub = lane & (LANES_PER_LEAF - 1);
@@ -846,7 +857,12 @@ __global__ void __launch_bounds__(256) k_leaf_sums(const float4* __restrict__ xy
       }
     }
     if (!have) continue;
-    finalize_leaf(slot, (int)keys[start], cnt, m.s, m.ss, sub == 0, nleaf_p, fp, rec, stats, cell2leaf);
+    // the 8 lanes hold identical sums; lane k writes word k, lane 0 also word 8
+    double* o = sums + (size_t)slot * 9;
+    const double mine = sub == 0 ? m.s[0] : sub == 1 ? m.s[1] : sub == 2 ? m.s[2] : sub == 3 ? m.ss[0]
+                      : sub == 4 ? m.ss[1] : sub == 5 ? m.ss[2] : sub == 6 ? m.ss[3] : m.ss[4];
+    o[sub] = mine;
+    if (sub == 0) o[8] = m.ss[5];
   }
 }
 
@@ -1007,12 +1023,15 @@ void launch_find_runs(const uint32_t* keys_sorted, size_t n, const BuildGeom* gd
 
 void launch_finalize_leaves(const float* xyz4, const uint32_t* keys_sorted, const uint32_t* vals_sorted,
                             int* d_nleaf, const int* leaf_start, const int* leaf_cnt, int max_leaves,
-                            FinalizeParams fp, VoxelRecord* rec, LeafStats* stats, int* cell2leaf, hipStream_t s) {
+                            FinalizeParams fp, double* sums, VoxelRecord* rec, LeafStats* stats, int* cell2leaf,
+                            hipStream_t s) {
   if (max_leaves <= 0) return;
   size_t blocks = ((size_t)max_leaves * LANES_PER_LEAF + 255) / 256;
   if (blocks > (size_t)SUMS_BLOCKS_MAX) blocks = SUMS_BLOCKS_MAX;
   hipLaunchKernelGGL(k_leaf_sums, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(xyz4),
-                     keys_sorted, vals_sorted, d_nleaf, leaf_start, leaf_cnt, fp, rec, stats, cell2leaf);
+                     vals_sorted, d_nleaf, leaf_start, leaf_cnt, sums);
+  hipLaunchKernelGGL(k_leaf_finalize, dim3((unsigned)((max_leaves + 63) / 64)), dim3(64), 0, s, keys_sorted, d_nleaf,
+                     leaf_start, leaf_cnt, sums, fp, rec, stats, cell2leaf);
 }
 
 }  // namespace ndt
