@@ -265,3 +265,57 @@ def _config_c3(n_map=1000000, n_src=200000, seed=7, cols=1024):
     guess = Ts @ pose_matrix(0.25, -0.15, 0.06, 0.0, 0.0, np.deg2rad(2.0))
     return dict(name="C3 %dk scan into %dk-pt map, 0.5 m" % (n_src // 1000, n_map // 1000), source=s,
                 target=m, gt=Ts, guess=guess, resolution=0.5)
+
+
+# --------------------------------------------------------------------------- C3-wide
+def _terrain(x, y):
+    """Gentle hills: a few metres of relief over tens of metres."""
+    return 3.0 * np.sin(x / 37.0) * np.cos(y / 53.0) + 1.5 * np.sin((x + y) / 17.0) + 0.01 * x
+
+
+def _wide_surfaces(rng, n_ground, n_wall, half, boxes):
+    """Random points on the terrain and on the vertical faces of `boxes` (cx, cy, sx, sy, h)."""
+    gx, gy = rng.uniform(-half, half, n_ground), rng.uniform(-half, half, n_ground)
+    ground = np.stack([gx, gy, _terrain(gx, gy)], 1)
+    b = boxes[rng.integers(0, len(boxes), n_wall)]
+    face = rng.integers(0, 4, n_wall)
+    u = rng.uniform(-1.0, 1.0, n_wall)
+    wx = np.where(face < 2, b[:, 0] + np.where(face == 0, -1.0, 1.0) * b[:, 2], b[:, 0] + u * b[:, 2])
+    wy = np.where(face < 2, b[:, 1] + u * b[:, 3], b[:, 1] + np.where(face == 2, -1.0, 1.0) * b[:, 3])
+    wz = _terrain(b[:, 0], b[:, 1]) + rng.uniform(0.0, 1.0, n_wall) * b[:, 4]
+    return np.concatenate([ground, np.stack([wx, wy, wz], 1)])
+
+
+def config_c3_wide(n_map=4000000, n_src=200000, seed=21):
+    return _cached("c3wide_v3_%d_%d_%d" % (n_map, n_src, seed), lambda: _config_c3_wide(n_map, n_src, seed))
+
+
+def _config_c3_wide(n_map, n_src, seed):
+    """C3-wide: the C3 shape (200k-point scan into a voxelised map, 0.5 m voxel) on a map whose
+    voxel table does NOT fit a cache level that C3's does: open terrain of 260 m x 260 m with 60
+    buildings, 4M map points -> ~2.9e5 valid leaves (23 MB of records, 70 MB dense index grid)
+    against C3's 2.1e4 (1.7 MB).  The map is in random order (no scan coherence); the source is a
+    fresh sample of the same surfaces within 100 m of the sensor, in the sensor frame."""
+    rng = np.random.default_rng(seed)
+    half = 130.0
+    nb = 60
+    boxes = np.stack([rng.uniform(-half + 10, half - 10, nb), rng.uniform(-half + 10, half - 10, nb),
+                      rng.uniform(2.0, 9.0, nb), rng.uniform(2.0, 9.0, nb), rng.uniform(4.0, 12.0, nb)], 1)
+    n_wall = n_map // 5
+    m = _wide_surfaces(rng, n_map - n_wall, n_wall, half, boxes)
+    m = (m + rng.normal(0.0, 0.02, m.shape)).astype(np.float32)
+    m = m[rng.permutation(len(m))]
+    z0 = float(_terrain(5.0, -3.0)) + 2.0
+    Ts = pose_matrix(5.0, -3.0, z0, 0.01, -0.015, 0.35)
+    rs = np.random.default_rng(seed + 1)
+    cand = _wide_surfaces(rs, 6 * n_src, 2 * n_src, half, boxes)
+    d = np.hypot(cand[:, 0] - 5.0, cand[:, 1] + 3.0)
+    cand = cand[d < 100.0]
+    if len(cand) < n_src:
+        raise RuntimeError("wide source has only %d points" % len(cand))
+    cand = cand[np.sort(rs.choice(len(cand), size=n_src, replace=False))]
+    cand = cand + rs.normal(0.0, 0.02, cand.shape)
+    s = transform(np.linalg.inv(Ts), cand).astype(np.float32)
+    guess = Ts @ pose_matrix(0.22, -0.12, 0.05, 0.0, 0.0, np.deg2rad(1.5))
+    return dict(name="C3-wide %dk scan into %dk-pt open-terrain map, 0.5 m" % (n_src // 1000, n_map // 1000),
+                source=s, target=m, gt=Ts, guess=guess, resolution=0.5)

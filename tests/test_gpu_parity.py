@@ -532,3 +532,43 @@ def test_full_size_leaf_invariants(c3_ndt):
     ev = L["evals"]
     assert (ev[:, 0] <= ev[:, 1] + 1e-15).all() and (ev[:, 1] <= ev[:, 2] + 1e-15).all()
     assert (ev[:, 0] >= 0.01 * ev[:, 2] * (1 - 1e-9)).all()      # inflation floor (ref :311-323)
+
+
+# ---------------------------------------------------------------------------------------
+# C3-wide: the same scan-to-map shape on a voxel table that is NOT cache-resident
+# (3.2e5 valid leaves = 26 MB of records + a 42 MB dense index grid, against C3's 1.7 MB)
+# ---------------------------------------------------------------------------------------
+def test_c3_wide_parity(pkg, O, S):
+    cfg = S.config_c3_wide()
+    prm = O.default_params(resolution=0.5, step_size=0.1, trans_epsilon=1e-4, max_iterations=35, num_threads=16)
+    grid = O.Grid(cfg["target"], prm)
+    assert grid.n_leaves >= 150000
+    ndt = make_ndt(pkg, resolution=0.5, max_iterations=35)
+    ndt.setInputTarget(cfg["target"])
+    gi = ndt.getGridInfo()
+    assert gi["n_leaves"] == grid.n_leaves and gi["n_leaves"] * 80 >= 12e6
+    assert_leaves_match(ndt.getLeaves(), grid.export())
+    ndt.setInputSource(cfg["source"])
+    prm64 = O.default_params(resolution=0.5, step_size=0.1, trans_epsilon=1e-4, max_iterations=35, num_threads=16,
+                             pair_mode=2)
+    for T in (cfg["guess"], cfg["gt"]):
+        p = O.matrix_to_pose(T)
+        e = ndt.evalDerivatives(p)[0]
+        assert_derivs_match(e, grid.derivatives(cfg["source"], p))
+        assert_derivs_match(e, grid.derivatives(cfg["source"], p, params=prm64), 1e-9)
+    T = ndt.align(cfg["guess"])
+    ref = grid.align(cfg["source"], cfg["guess"], params=prm64)
+    dt, dr = S.pose_error(T, ref["T"])
+    assert dt < ALIGN_TOL_M and dr < ALIGN_TOL_RAD, (dt, dr)
+    assert ndt.getResult()["iterations"] == ref["iterations"]
+    assert S.pose_error(T, cfg["gt"])[0] < 0.05
+    # a second, different target through the same engine (the steady-state build path that derives
+    # its geometry on the device), then back: bit-identical leaves both times
+    L1 = ndt.getLeaves()
+    c3 = S.config_c3()
+    ndt.setInputTarget(c3["target"])
+    assert_leaves_match(ndt.getLeaves(), O.Grid(c3["target"], prm).export())
+    ndt.setInputTarget(cfg["target"])
+    L2 = ndt.getLeaves()
+    for k in ("cell", "count", "mean", "cov", "icov"):
+        assert np.array_equal(L1[k], L2[k]), k
