@@ -87,6 +87,15 @@ typedef enum ndt_wait_mode {
                           for hosts that cannot spare a core: the drivers run 6-7 threads + OpenMP) */
 } ndt_wait_mode;
 
+typedef enum ndt_source_order {
+  NDT_SOURCE_ORDER_AUTO = 0, /* sort when the voxel table is larger than one L2 (records > 6 MB) and the
+                                source has >= 32768 points */
+  NDT_SOURCE_ORDER_KEEP = 1, /* evaluate the source in the order it was handed over */
+  NDT_SOURCE_ORDER_SORT = 2  /* always: once per align, the source is stably sorted by the block of target
+                                voxels its points fall into under the initial guess (a wavefront then touches
+                                few distinct voxel records; only the f64 summation order changes) */
+} ndt_source_order;
+
 /* Named parameter sets.  ndt_default_params() is the vendored-code hybrid the parity tests pin
  * (svn covariance, full Hessian, no ridge, More-Thuente); the presets restate the two engines. */
 typedef enum ndt_preset {
@@ -116,6 +125,7 @@ typedef struct ndt_params {
   int num_threads;               /* setNumThreads; recorded only -- there is no CPU path */
   int device_id;                 /* HIP device ordinal; -1 = current device */
   int wait_mode;                 /* ndt_wait_mode */
+  int source_order;              /* ndt_source_order */
 } ndt_params;
 
 typedef struct ndt_handle ndt_handle;

@@ -28,6 +28,7 @@ KDTREE, DIRECT26, DIRECT7, DIRECT1 = 0, 1, 2, 3
 HESSIAN_FULL, HESSIAN_GAUSS_NEWTON = 0, 1
 COV_SVN, COV_PCL_RECALLED = 0, 1
 WAIT_SPIN, WAIT_BLOCK = 0, 1
+SOURCE_ORDER_AUTO, SOURCE_ORDER_KEEP, SOURCE_ORDER_SORT = 0, 1, 2
 PRESET_DEFAULT, PRESET_PCLOMP_RECALLED, PRESET_SVN = 0, 1, 2
 
 STATUS = {0: "NDT_OK", -1: "NDT_ERR_INVALID_ARG", -2: "NDT_ERR_NO_DEVICE", -3: "NDT_ERR_HIP",
@@ -48,7 +49,7 @@ class Params(C.Structure):
         ("min_points_per_voxel", C.c_int), ("eig_inflation_ratio", C.c_double),
         ("hessian_mode", C.c_int), ("cov_mode", C.c_int), ("add_ridge", C.c_int),
         ("use_line_search", C.c_int), ("regularization_scale_factor", C.c_float),
-        ("num_threads", C.c_int), ("device_id", C.c_int), ("wait_mode", C.c_int),
+        ("num_threads", C.c_int), ("device_id", C.c_int), ("wait_mode", C.c_int), ("source_order", C.c_int),
     ]
 
 

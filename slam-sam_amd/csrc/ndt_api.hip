@@ -104,6 +104,13 @@ struct ndt_handle {
   // source
   DevBuf<float> sx, sy, sz;
   size_t n_src = 0;
+  // the same points in block order of the target grid (see sort_source_by_blocks); valid until
+  // the source or the target changes
+  DevBuf<float> ox, oy, oz;
+  DevBuf<uint32_t> skeys, skeys2, svals, svals2;
+  DevBuf<char> ssort_tmp;
+  DevBuf<BuildGeom> splan;
+  bool src_sorted = false;
   int64_t n_src_global = -1;
 
   // staging
@@ -161,6 +168,7 @@ bool params_valid(const ndt_params* p, std::string* why) {
     return false;
   }
   if (p->wait_mode != NDT_WAIT_SPIN && p->wait_mode != NDT_WAIT_BLOCK) { *why = "unknown wait_mode"; return false; }
+  if (p->source_order < NDT_SOURCE_ORDER_AUTO || p->source_order > NDT_SOURCE_ORDER_SORT) { *why = "unknown source_order"; return false; }
   if (!(p->outlier_ratio >= 0.0 && p->outlier_ratio < 1.0)) { *why = "outlier_ratio must be in [0,1)"; return false; }
   if (p->max_iterations < 0) { *why = "max_iterations must be >= 0"; return false; }
   return true;
@@ -218,6 +226,7 @@ int upload_soa(ndt_handle* h, const float* xyz, const float* x, const float* y, 
 // before).  A refused optimistic build (BG_CAPACITY / BG_PASSES) is repeated that way.
 int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, size_t n) {
   h->have_grid = false;
+  h->src_sorted = false;
   h->n_tgt = n;
   h->n_slots = h->n_valid = 0;
   int dirty_slots = h->grid_dirty_slots;
@@ -353,6 +362,37 @@ int ready_for_eval(ndt_handle* h) {
   return NDT_OK;
 }
 
+// The source in block order of the target grid under T, when the engine's parameters ask for it
+// (NDT_SOURCE_ORDER_*).  Done once per (source, target): the copy stays a valid permutation of the
+// source whatever the later poses are.
+int maybe_sort_source(ndt_handle* h, const float T[16]) {
+  if (h->src_sorted || h->n_src == 0 || !h->have_grid) return NDT_OK;
+  const int mode = h->prm.source_order;
+  if (mode == NDT_SOURCE_ORDER_KEEP) return NDT_OK;
+  if (mode == NDT_SOURCE_ORDER_AUTO &&
+      ((size_t)h->n_valid * sizeof(VoxelRecord) <= (size_t)6 << 20 || h->n_src < 32768))
+    return NDT_OK;
+  const size_t n = h->n_src;
+  HIP_TRY(h, h->ox.ensure(n));
+  HIP_TRY(h, h->oy.ensure(n));
+  HIP_TRY(h, h->oz.ensure(n));
+  HIP_TRY(h, h->skeys.ensure(n));
+  HIP_TRY(h, h->skeys2.ensure(n));
+  HIP_TRY(h, h->svals.ensure(n));
+  HIP_TRY(h, h->svals2.ensure(n));
+  HIP_TRY(h, h->ssort_tmp.ensure(sort_temp_bytes(n)));
+  HIP_TRY(h, h->splan.ensure(1));
+  PoseConsts pc{};
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) pc.R[3 * i + j] = T[4 * j + i];
+    pc.t[i] = T[12 + i];
+  }
+  HIP_TRY(h, sort_source_by_blocks(h->sx.p, h->sy.p, h->sz.p, n, h->geom, pc, h->splan.p, h->ssort_tmp.p, h->skeys.p,
+                                   h->skeys2.p, h->svals.p, h->svals2.p, h->ox.p, h->oy.p, h->oz.p, h->stream));
+  h->src_sorted = true;
+  return NDT_OK;
+}
+
 // Launch sequence numbers tag every partial / result slot the derivative kernel writes; they
 // must never repeat within the process (a freed partials buffer of one handle can become
 // another's), hence one counter for all handles, starting at 1 (zeroed memory never matches).
@@ -420,7 +460,8 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
   const bool spin = !dev_out && !h->timing && h->prm.wait_mode == NDT_WAIT_SPIN;
   const unsigned long long seq = g_launch_seq.fetch_add(1, std::memory_order_relaxed);
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, s));
-  launch_derivatives(h->sx.p, h->sy.p, h->sz.p, h->n_src, h->geom, h->cell2leaf.p, h->rec.p, pc,
+  launch_derivatives(h->src_sorted ? h->ox.p : h->sx.p, h->src_sorted ? h->oy.p : h->sy.p,
+                     h->src_sorted ? h->oz.p : h->sz.p, h->n_src, h->geom, h->cell2leaf.p, h->rec.p, pc,
                      nullptr, 1, ec, h->partials.p, h->counters.p, d_out, s, spin ? h->flag.d : nullptr, seq);
   HIP_TRY(h, hipGetLastError());
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, s));
@@ -494,6 +535,7 @@ void ndt_default_params(ndt_params* p) {
   p->num_threads = 1;
   p->device_id = -1;
   p->wait_mode = NDT_WAIT_SPIN;
+  p->source_order = NDT_SOURCE_ORDER_AUTO;
 }
 
 int ndt_params_preset(ndt_params* p, int preset) {
@@ -573,6 +615,8 @@ int ndt_destroy(ndt_handle* h) {
   for (auto& kv : h->keyframes) { kv.second.x.release(); kv.second.y.release(); kv.second.z.release(); }
   h->keyframes.clear();
   h->sx.release(); h->sy.release(); h->sz.release();
+  h->ox.release(); h->oy.release(); h->oz.release(); h->skeys.release(); h->skeys2.release();
+  h->svals.release(); h->svals2.release(); h->ssort_tmp.release(); h->splan.release();
   h->stage.release(); h->result.release(); h->small.release(); h->partials.release();
   h->dres.release(); h->dposes.release(); h->hposes.release(); h->counters.release(); h->flag.release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -601,6 +645,7 @@ int ndt_set_params(ndt_handle* h, const ndt_params* p) {
                                              p->cov_mode != h->prm.cov_mode);
   const bool rebuild = grid_changed && h->tx.p && h->n_tgt > 0;
   const int dev = h->prm.device_id;
+  if (p->source_order != h->prm.source_order) h->src_sorted = false;
   h->prm = *p;
   h->prm.device_id = dev;  // a handle never migrates
   if (grid_changed && !rebuild) {
@@ -655,6 +700,7 @@ int ndt_set_source(ndt_handle* h, const float* xyz, size_t n, size_t stride_byte
   rc = upload_soa(h, xyz, nullptr, nullptr, nullptr, n, stride_bytes, h->sx, h->sy, h->sz);
   if (rc) return rc;
   h->n_src = n;
+  h->src_sorted = false;
   return NDT_OK;
 }
 
@@ -665,6 +711,7 @@ int ndt_set_source_soa(ndt_handle* h, const float* x, const float* y, const floa
   rc = upload_soa(h, nullptr, x, y, z, n, 0, h->sx, h->sy, h->sz);
   if (rc) return rc;
   h->n_src = n;
+  h->src_sorted = false;
   return NDT_OK;
 }
 
@@ -681,6 +728,7 @@ int ndt_set_source_device(ndt_handle* h, const float* dx, const float* dy, const
     HIP_TRY(h, hipStreamSynchronize(h->stream));  // the caller's arrays are consumed during the call
   }
   h->n_src = n;
+  h->src_sorted = false;
   return NDT_OK;
 }
 
@@ -769,6 +817,8 @@ int ndt_align(ndt_handle* h, const float guess[16], ndt_result* out) {
     std::memcpy(out->final_transformation, guess, sizeof(float) * 16);
     return rc;
   }
+  rc = maybe_sort_source(h, guess);
+  if (rc) return rc;
   const double dev_ms0 = h->tm.ms_eval_kernel_total;
   EvalFn fn = [h](const double* p, const float* T, bool need_h, Eval* e) { return evaluate(h, p, T, need_h, e); };
   const int64_t n_total = h->n_src_global >= 0 ? h->n_src_global : (int64_t)h->n_src;
@@ -807,6 +857,12 @@ int ndt_eval_derivatives(ndt_handle* h, const double* poses6, const float* trans
   if (rc) return rc;
   rc = ready_for_eval(h);
   if (rc) return rc;
+  {  // source ordering, by the first pose of the batch (the particles of an SVN iteration are close)
+    float T0[16];
+    if (!transforms) pose_to_matrix(poses6, T0);
+    rc = maybe_sort_source(h, transforms ? transforms : T0);
+    if (rc) return rc;
+  }
   hipStream_t s = h->stream;
   HIP_TRY(h, h->hposes.ensure((size_t)K));
   HIP_TRY(h, h->dposes.ensure((size_t)K));
@@ -825,7 +881,8 @@ int ndt_eval_derivatives(ndt_handle* h, const double* poses6, const float* trans
   if (rc) return rc;
   HIP_TRY(h, hipMemcpyAsync(h->dposes.p, h->hposes.h, (size_t)K * sizeof(PoseConsts), hipMemcpyHostToDevice, s));
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, s));
-  launch_derivatives(h->sx.p, h->sy.p, h->sz.p, h->n_src, h->geom, h->cell2leaf.p, h->rec.p,
+  launch_derivatives(h->src_sorted ? h->ox.p : h->sx.p, h->src_sorted ? h->oy.p : h->sy.p,
+                     h->src_sorted ? h->oz.p : h->sz.p, h->n_src, h->geom, h->cell2leaf.p, h->rec.p,
                      h->hposes.h[0], h->dposes.p, K, ec, h->partials.p, h->counters.p, h->dres.p, s, nullptr,
                      g_launch_seq.fetch_add(1, std::memory_order_relaxed));
   HIP_TRY(h, hipGetLastError());

@@ -62,6 +62,16 @@ void launch_transform_append(const float* x, const float* y, const float* z, siz
                              const double pose_colmajor[16], float* ox, float* oy, float* oz,
                              hipStream_t s);
 
+// Source ordering: the source cloud stably sorted by the 8 x 8 x 4-voxel block of the target grid
+// its points fall into under the transform P (keys + first histogram, the digit passes, gather).
+// keys/vals a, b: n uint32 each; temp: sort_temp_bytes(n); plan: one BuildGeom of scratch in
+// device memory; ox/oy/oz: the sorted copy.
+int source_sort_passes(const GridGeom& g);
+hipError_t sort_source_by_blocks(const float* x, const float* y, const float* z, size_t n, const GridGeom& g,
+                                 const PoseConsts& P, BuildGeom* plan, void* temp, uint32_t* keys_a,
+                                 uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, float* ox, float* oy,
+                                 float* oz, hipStream_t s);
+
 // ---- derivative evaluation (ndt_derivs.hip) ---------------------------------
 int derivs_grid_blocks(size_t n_src, int K);
 int derivs_block_threads(size_t n_src, int K);
