@@ -32,6 +32,11 @@ struct ShmSeg {
   int nranks;
   char pad[52];
   SeqWord seq[kMaxRanks];
+  // attach handshake: rank r writes a value unique to this attempt, only a LIVE rank 0 echoes it.
+  // A segment left behind by a crashed run (same name, magic set, large sequence words) never
+  // answers, so nobody can start summing its garbage.
+  SeqWord attach[kMaxRanks];
+  SeqWord ack[kMaxRanks];
   double slot[2][kMaxRanks][NDT_EVAL_WORDS];
 };
 
@@ -80,53 +85,74 @@ int Reducer::init_shm(const char* name, int rank, int nranks, std::string* err) 
   if (!name || nranks < 1 || nranks > kMaxRanks || rank < 0 || rank >= nranks)
     return NDT_ERR_INVALID_ARG;
   const size_t bytes = sizeof(ShmSeg);
-  int fd = -1;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto expired = [&](int seconds) { return std::chrono::steady_clock::now() - t_start > std::chrono::seconds(seconds); };
+  void* p = MAP_FAILED;
   if (rank == 0) {
     shm_unlink(name);
-    fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
     if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) {
       if (err) *err = std::string("shm_open/ftruncate failed for ") + name;
       if (fd >= 0) close(fd);
       return NDT_ERR_COMM;
     }
-  } else {
-    // wait for rank 0 to create and size the segment (bounded: 60 s)
-    const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
-      fd = shm_open(name, O_RDWR, 0600);
-      if (fd >= 0) {
-        struct stat st;
-        if (fstat(fd, &st) == 0 && (size_t)st.st_size >= bytes) break;
-        close(fd);
-        fd = -1;
-      }
-      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
-        if (err) *err = std::string("timed out waiting for shm segment ") + name;
-        return NDT_ERR_COMM;
-      }
-      std::this_thread::sleep_for(std::chrono::milliseconds(2));
+    p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) {
+      if (err) *err = "mmap of shm segment failed";
+      return NDT_ERR_COMM;
     }
-  }
-  void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-  close(fd);
-  if (p == MAP_FAILED) {
-    if (err) *err = "mmap of shm segment failed";
-    return NDT_ERR_COMM;
-  }
-  ShmSeg* seg = static_cast<ShmSeg*>(p);
-  if (rank == 0) {
+    ShmSeg* seg = static_cast<ShmSeg*>(p);  // fresh pages: all zero
     seg->nranks = nranks;
-    for (int r = 0; r < kMaxRanks; ++r) seg->seq[r].v.store(0, std::memory_order_relaxed);
     seg->magic.store(kMagic, std::memory_order_release);
+    for (int r = 1; r < nranks; ++r) {  // echo every rank's attach word
+      uint64_t v;
+      while ((v = seg->attach[r].v.load(std::memory_order_acquire)) == 0) {
+        if (expired(60)) {
+          munmap(p, bytes);
+          shm_unlink(name);
+          if (err) *err = "timed out waiting for the other ranks to attach to the shm segment";
+          return NDT_ERR_COMM;
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+      }
+      seg->ack[r].v.store(v, std::memory_order_release);
+    }
   } else {
-    const auto t0 = std::chrono::steady_clock::now();
-    while (seg->magic.load(std::memory_order_acquire) != kMagic) {
-      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
-        munmap(p, bytes);
-        if (err) *err = "timed out waiting for shm segment initialisation";
+    // unique to this init call (pid, rank, clock): no segment of an earlier run can hold it
+    const uint64_t mine = (((uint64_t)getpid() << 32) ^ ((uint64_t)rank << 24) ^
+                           (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count() ^ 0x9e3779b97f4a7c15ull) | 1ull;
+    for (;;) {
+      if (expired(60)) {
+        if (err) *err = std::string("timed out attaching to shm segment ") + name;
         return NDT_ERR_COMM;
       }
-      std::this_thread::sleep_for(std::chrono::milliseconds(1));
+      int fd = shm_open(name, O_RDWR, 0600);
+      struct stat st;
+      if (fd < 0 || fstat(fd, &st) != 0 || (size_t)st.st_size < bytes) {
+        if (fd >= 0) close(fd);
+        std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        continue;
+      }
+      p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+      close(fd);
+      if (p == MAP_FAILED) {
+        if (err) *err = "mmap of shm segment failed";
+        return NDT_ERR_COMM;
+      }
+      ShmSeg* seg = static_cast<ShmSeg*>(p);
+      bool live = false;
+      const auto t_try = std::chrono::steady_clock::now();
+      while (std::chrono::steady_clock::now() - t_try < std::chrono::milliseconds(500)) {
+        if (seg->magic.load(std::memory_order_acquire) == kMagic && seg->nranks == nranks) {
+          seg->attach[rank].v.store(mine, std::memory_order_release);
+          if (seg->ack[rank].v.load(std::memory_order_acquire) == mine) { live = true; break; }
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+      }
+      if (live) break;
+      munmap(p, bytes);  // a stale segment, or rank 0 is not there yet: open the name again
+      p = MAP_FAILED;
     }
   }
   shm_ = p;

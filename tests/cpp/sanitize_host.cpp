@@ -6,6 +6,10 @@
 //   * the 6x6 solve (Cholesky fast path and eigen route), result_covariance, pose <-> matrix;
 //   * the shared-memory reducer with 4 threads x 2000 rounds (bit-identical sums on every rank);
 //   * SE(3) exp / log round trips.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -137,6 +141,51 @@ int main() {
     double want = 0;
     for (int k = 0; k < R; ++k) want += (k + 1) * 0.1 * 1 + (rounds - 1) * 1e-3;
     CHECK(std::fabs(last[0][0] - want) < 1e-9);
+  }
+
+  // ---- a stale segment of a crashed run under the same name (magic set, large sequence words) ------
+  // rank 1 starts FIRST and finds it; it must not be fooled into summing its garbage: only a live
+  // rank 0 answers the attach handshake
+  {
+    const std::string name = "/ndt_sanitize_stale_" + std::to_string((long)getpid());
+    {
+      ndt::Reducer r0, r1;
+      std::string err;
+      std::thread t([&] { (void)r1.init_shm(name.c_str(), 1, 2, &err); });
+      std::string err0;
+      CHECK(r0.init_shm(name.c_str(), 0, 2, &err0) == NDT_OK);
+      t.join();
+      double w[NDT_EVAL_WORDS] = {0};
+      std::thread t2([&] { double v[NDT_EVAL_WORDS] = {0}; for (int i = 0; i < 1000; ++i) (void)r1.allreduce_host(v, NDT_EVAL_WORDS, &err); });
+      for (int i = 0; i < 1000; ++i) (void)r0.allreduce_host(w, NDT_EVAL_WORDS, &err0);
+      t2.join();
+      // simulate the crash: keep the name alive by re-linking a copy of the used segment
+      int fd = shm_open(name.c_str(), O_RDWR, 0600);
+      CHECK(fd >= 0);
+      std::vector<char> image(1 << 20);
+      const ssize_t got = pread(fd, image.data(), image.size(), 0);
+      close(fd);
+      r1.destroy();
+      r0.destroy();  // unlinks
+      fd = shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+      CHECK(fd >= 0 && got > 0);
+      CHECK(ftruncate(fd, (off_t)(1 << 20)) == 0 && pwrite(fd, image.data(), (size_t)got, 0) == got);
+      close(fd);
+    }
+    ndt::Reducer a, b;
+    std::string ea, eb;
+    int rc_b = -1;
+    std::thread late([&] { rc_b = b.init_shm(name.c_str(), 1, 2, &eb); });   // meets the stale segment first
+    std::this_thread::sleep_for(std::chrono::milliseconds(50));
+    CHECK(a.init_shm(name.c_str(), 0, 2, &ea) == NDT_OK);
+    late.join();
+    CHECK(rc_b == NDT_OK);
+    double wa[NDT_EVAL_WORDS], wb[NDT_EVAL_WORDS];
+    for (int i = 0; i < NDT_EVAL_WORDS; ++i) { wa[i] = 1.0 + i; wb[i] = 100.0; }
+    std::thread tb([&] { (void)b.allreduce_host(wb, NDT_EVAL_WORDS, &eb); });
+    CHECK(a.allreduce_host(wa, NDT_EVAL_WORDS, &ea) == NDT_OK);
+    tb.join();
+    for (int i = 0; i < NDT_EVAL_WORDS; ++i) CHECK(wa[i] == 101.0 + i && wb[i] == wa[i]);
   }
 
   // ---- SE(3) ---------------------------------------------------------------------------------------
