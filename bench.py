@@ -149,7 +149,11 @@ def main():
         os.environ.setdefault("NDT_BENCH_REDUCE", "shm")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # NDT_BENCH_FORCE_DIST=1: run the multi-rank code path (process group, both reducers, watchdog)
+    # even with one rank -- the only way to execute the RCCL leg end to end on a 1-GPU box
+    force_dist = os.environ.get("NDT_BENCH_FORCE_DIST", "0") == "1"
+    multi = world > 1 or force_dist
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -186,7 +190,7 @@ def main():
         return ndt, t1 - t0, t2 - t1
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -207,7 +211,7 @@ def main():
             t_align += ta
         fence()
         elapsed = time.perf_counter() - t0
-        if world > 1:
+        if multi:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -370,7 +374,7 @@ def main():
         bb, cb = pkg.shard_range(nb, rank, world)
         bsrc = [torch.from_numpy(np.ascontiguousarray(big[bb:bb + cb, a])).to(dev) for a in range(3)]
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             ndt.setGlobalSourceSize(nb)
 
         def pstep():
@@ -390,7 +394,7 @@ def main():
             evals += r["n_evaluations"]
         fence()
         el = time.perf_counter() - t0
-        if world > 1:
+        if multi:
             t = torch.tensor([el], dtype=torch.float64, device="cpu" if rehearsal else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
@@ -404,7 +408,7 @@ def main():
 
     variants = {}
     shm_name = {"name": None}
-    if world == 1:
+    if not multi:
         res = timed_region()
         out = instrumented(res, "none", variants)
         headline(out, res, "none")
@@ -481,6 +485,9 @@ def main():
                 dog.cancel()
         if best is None:
             raise SystemExit("no cross-rank reducer could be created")
+        if out is not None and "config" in out:
+            v, path = pkg.comm_info()
+            out["config"]["rccl"] = {"version": v, "library": path}
         if rank != 0:
             out = None
         dist.barrier()
