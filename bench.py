@@ -85,15 +85,40 @@ def build_fast_oracle():
         return O, exact_flags
 
 
+def usable_cpus():
+    """CPUs this job may actually use: the affinity mask, cut down to the cgroup CPU quota (a 1-GPU
+    box shows all 256 host CPUs to a job that is allowed 16 of them; 256 OpenMP threads on a
+    16-CPU quota ran the baseline 10x slower than 8 threads)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:  # cgroup v2
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        pass
+    if quota is None:
+        try:  # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n
+
+
 def cpu_baseline(cfg, params, seconds):
     """The oracle timed on this box's host cores; step = grid build + align, like the GPU step.
     Two thread settings: every core this job may use, and the 8 of config/register_config.json:3."""
     O, flags = build_fast_oracle()
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    nproc = os.cpu_count() or avail
+    nproc = os.cpu_count() or 1
+    avail = usable_cpus()
 
     def run(threads):
         prm = O.default_params(num_threads=threads, **params)
@@ -118,11 +143,16 @@ def cpu_baseline(cfg, params, seconds):
 
     cores = max(1, min(avail, int(os.environ.get("NDT_BENCH_CPU_THREADS", str(avail)))))
     full = run(cores)
+    if cores > 16:
+        # no quota was visible, yet a 1-GPU box grants a 16-CPU share of the host: keep the faster of the two
+        alt = run(16)
+        if alt["value"] > full["value"]:
+            full, cores = alt, 16
     eight = run(min(8, avail)) if cores != min(8, avail) else full
     return {"value": full["value"], "unit": "iterations/s", "cores": cores, "kind": "port",
             "sample": "%d full steps (oracle grid build + align) of the same C3 workload in %.1f s on %d OpenMP "
                       "threads (the grid build is single-threaded like the reference's)" % (full["steps"], full["seconds"], cores),
-            "build_flags": flags, "nproc": nproc, "cpus_available": avail,
+            "build_flags": flags, "nproc": nproc, "cpus_usable": avail,
             "ms_per_step": full["ms_per_step"], "ms_build": full["ms_build"], "ms_align": full["ms_align"],
             "iterations_per_step": full["iterations_per_step"],
             "threads_8": {k: eight[k] for k in ("value", "threads", "steps", "ms_per_step", "ms_build", "ms_align")}}

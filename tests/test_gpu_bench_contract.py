@@ -38,5 +38,5 @@ def test_bench_line_schema():
     assert d["evaluations_reused_per_align"] >= 0 and d["config"]["rccl"]["version"] > 20000
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "iterations/s" and cb["sample"]
-    assert cb["nproc"] >= cb["cores"] and "-O" in cb["build_flags"] and cb["threads_8"]["threads"] <= 8
+    assert cb["nproc"] >= cb["cores"] and cb["cpus_usable"] >= 1 and "-O" in cb["build_flags"] and cb["threads_8"]["threads"] <= 8
     assert d["final_error_vs_ground_truth"]["m"] < 0.05
