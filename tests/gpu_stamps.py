@@ -11,7 +11,7 @@ L = pkg.lib()
 L.ndt_debug_read_stamps.argtypes = [C.c_void_p, C.c_int]
 for n in (1000, 200000):
     ndt.setInputSource(cfg["source"][:n])
-    bt = int(os.environ.get("NDT_DERIV_BLOCK", "0")) or (1024 if 163840 < n <= 262144 else 512)
+    bt = int(os.environ.get("NDT_DERIV_BLOCK", "0")) or ((((n + 255) // 256 + 63) // 64) * 64 if 131072 < n <= 262144 else 512)
     nb = (n + bt - 1) // bt
     for _ in range(5): ndt.align(cfg["gt"])
     raw = np.zeros(nb * 9, np.uint64)
