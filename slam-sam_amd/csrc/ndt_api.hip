@@ -174,7 +174,10 @@ bool params_valid(const ndt_params* p, std::string* why) {
   return true;
 }
 
-// host AoS / SoA -> device SoA through the pinned staging buffer
+// host AoS / SoA -> device SoA through the pinned staging buffer.  Large clouds go in chunks:
+// a few host threads repack chunk after chunk into pinned memory while the calling thread hands
+// every finished chunk to the copy engine, so the PCIe transfer runs under the repack instead of
+// after it (a 1M-point PointXYZI map: repack ~0.6 ms + upload ~0.3 ms serial before).
 int upload_soa(ndt_handle* h, const float* xyz, const float* x, const float* y, const float* z,
                size_t n, size_t stride, DevBuf<float>& dx, DevBuf<float>& dy, DevBuf<float>& dz) {
   HIP_TRY(h, dx.ensure(n));
@@ -183,8 +186,6 @@ int upload_soa(ndt_handle* h, const float* xyz, const float* x, const float* y, 
   if (n == 0) return NDT_OK;
   HIP_TRY(h, h->stage.ensure(3 * n));
   float* s = h->stage.h;
-  // AoS -> SoA repack into pinned memory, split over a few host threads for large clouds
-  // (a single thread needs ~1 ms per million PointXYZI points, more than the 12 MB upload)
   auto repack = [=](size_t lo, size_t hi) {
     if (xyz) {
       const char* base = reinterpret_cast<const char*>(xyz);
@@ -200,18 +201,42 @@ int upload_soa(ndt_handle* h, const float* xyz, const float* x, const float* y, 
       std::memcpy(s + 2 * n + lo, z + lo, (hi - lo) * sizeof(float));
     }
   };
-  const unsigned nthreads = n >= 200000 ? 4u : 1u;
-  if (nthreads == 1) {
+  auto copy_chunk = [&](size_t lo, size_t hi) -> hipError_t {
+    const size_t bytes = (hi - lo) * sizeof(float);
+    hipError_t e = hipMemcpyAsync(dx.p + lo, s + lo, bytes, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dy.p + lo, s + n + lo, bytes, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dz.p + lo, s + 2 * n + lo, bytes, hipMemcpyHostToDevice, h->stream);
+    return e;
+  };
+  constexpr size_t kChunk = 131072;
+  if (n < 2 * kChunk) {
     repack(0, n);
+    HIP_TRY(h, copy_chunk(0, n));
   } else {
-    std::thread pool[3];
-    for (unsigned t = 1; t < nthreads; ++t) pool[t - 1] = std::thread(repack, n * t / nthreads, n * (t + 1) / nthreads);
-    repack(0, n / nthreads);
-    for (unsigned t = 1; t < nthreads; ++t) pool[t - 1].join();
+    const size_t nchunks = (n + kChunk - 1) / kChunk;
+    const unsigned nthreads = (unsigned)std::min<size_t>(n >= (size_t)1 << 19 ? 6 : 3, nchunks);
+    std::vector<std::atomic<int>> done(nchunks);
+    for (auto& d : done) d.store(0, std::memory_order_relaxed);
+    std::atomic<size_t> next{0};
+    auto worker = [&] {
+      for (;;) {
+        const size_t c = next.fetch_add(1, std::memory_order_relaxed);
+        if (c >= nchunks) return;
+        repack(c * kChunk, std::min(n, (c + 1) * kChunk));
+        done[c].store(1, std::memory_order_release);
+      }
+    };
+    std::vector<std::thread> pool;
+    pool.reserve(nthreads);
+    for (unsigned t = 0; t < nthreads; ++t) pool.emplace_back(worker);
+    hipError_t err = hipSuccess;
+    for (size_t c = 0; c < nchunks; ++c) {
+      while (!done[c].load(std::memory_order_acquire)) std::this_thread::yield();
+      if (err == hipSuccess) err = copy_chunk(c * kChunk, std::min(n, (c + 1) * kChunk));
+    }
+    for (auto& t : pool) t.join();
+    HIP_TRY(h, err);
   }
-  HIP_TRY(h, hipMemcpyAsync(dx.p, s, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(dy.p, s + n, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(dz.p, s + 2 * n, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));  // staging buffer is reused
   return NDT_OK;
 }
