@@ -87,7 +87,7 @@ struct ndt_handle {
   DevBuf<int> leaf_start, leaf_cnt, run_counts, run_offsets;
   DevBuf<double> leaf_sums;
   DevBuf<int> brows;                 // per-block bounds rows
-  DevBuf<unsigned int> tickets;      // [0] bounds kernel, [1] run-count kernel; zero between launches
+  DevBuf<unsigned int> tickets;      // [0] bounds, [1] run-count, [2] finalize kernel; zero between launches
   DevBuf<BuildGeom> gd;              // geometry + sort plan of the build, derived on the device
   PinBuf<BuildGeom> gdh;             // ... and its host-visible copy
   DevBuf<float> xyz4;                // packed float4 copy of the target for the gather
@@ -271,7 +271,7 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
   HIP_TRY(h, h->gd.ensure(1));
   HIP_TRY(h, h->gdh.ensure(1));
   if (!h->tickets.p) {
-    HIP_TRY(h, h->tickets.ensure(2));
+    HIP_TRY(h, h->tickets.ensure(3));
     HIP_TRY(h, hipMemsetAsync(h->tickets.p, 0, h->tickets.cap * sizeof(unsigned int), s));
   }
   HIP_TRY(h, h->nleaf.ensure(2));
@@ -320,9 +320,8 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
                      h->leaf_start.p, h->leaf_cnt.p, s);
     FinalizeParams fp{h->prm.eig_inflation_ratio, h->prm.cov_mode};
     launch_finalize_leaves(h->xyz4.p, keys_sorted, vals_sorted, h->nleaf.p, h->leaf_start.p, h->leaf_cnt.p, max_leaves,
-                           fp, h->leaf_sums.p, h->rec.p, h->stats.p, h->cell2leaf.p, s);
+                           fp, h->leaf_sums.p, h->rec.p, h->stats.p, h->cell2leaf.p, h->tickets.p + 2, h->small.d + 8, s);
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipMemcpyAsync(h->small.h + 8, h->nleaf.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipEventRecord(h->ev1, s));
     HIP_TRY(h, hipStreamSynchronize(s));
     const BuildGeom& bg = *h->gdh.h;

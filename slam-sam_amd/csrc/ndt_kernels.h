@@ -52,7 +52,8 @@ struct FinalizeParams {
 void launch_finalize_leaves(const float* xyz4, const uint32_t* keys_sorted, const uint32_t* vals_sorted,
                             int* d_nleaf /* [0]=slots, [1]=valid */, const int* leaf_start, const int* leaf_cnt,
                             int max_leaves, FinalizeParams fp, double* sums, VoxelRecord* rec, LeafStats* stats,
-                            int* cell2leaf, hipStream_t s);
+                            int* cell2leaf, unsigned int* ticket /* zero, left at zero */,
+                            int* nleaf_host /* pinned: receives d_nleaf[0..1] */, hipStream_t s);
 
 // out[i] = (float)(R x + t) in f64 (sliding-window target assembly); out arrays hold n floats
 // device-to-device copy of three SoA arrays in one launch

@@ -267,10 +267,15 @@ constexpr int SORT_ROUNDS = 8;
 constexpr int SORT_WAVES = SORT_THREADS / 64;
 constexpr int SORT_TILE = SORT_THREADS * SORT_ROUNDS;
 constexpr int SORT_BINS = 256;
+// (Round 2 tried to let scatter pass p count the tile histogram of pass p + 1 with integer atomics
+// on a global table -- one launch per pass less.  A million device-scope atomicAdds spread over
+// 125 k counters took 88-248 us per pass: across eight XCDs they are served at the memory side.
+// Reverted; the per-tile LDS histogram of k_sort_count costs 6 us.)
 
 __device__ __forceinline__ int sort_index(int tile, int wave, int round, int lane) {
   return tile * SORT_TILE + wave * (SORT_TILE / SORT_WAVES) + round * 64 + lane;
 }
+
 
 // Cell key per point (+ the packed float4 copy the per-voxel gather reads) and, in the same
 // pass, the tile histograms of the first sort digit.
@@ -672,6 +677,20 @@ __device__ __forceinline__ void moments_xor_tree(Moments& m) {
   }
 }
 
+__device__ __forceinline__ void finalize_one(int slot, const uint32_t* __restrict__ keys, int* __restrict__ nleaf_p,
+                                             const int* __restrict__ leaf_start, const int* __restrict__ leaf_cnt,
+                                             const double* __restrict__ sums, FinalizeParams fp,
+                                             VoxelRecord* __restrict__ rec, LeafStats* __restrict__ stats,
+                                             int* __restrict__ cell2leaf);
+
+// one-wave blocks: every lane's stores / atomics are acknowledged, then lane 0 takes the ticket
+__device__ __forceinline__ bool last_ticket_wave(unsigned int* ticket, unsigned int nblocks) {
+  int last = 0;
+  if ((threadIdx.x & 63) == 0) last = last_ticket(ticket, nblocks) ? 1 : 0;  // drains vmcnt first
+  else __builtin_amdgcn_s_waitcnt(0);
+  return __builtin_amdgcn_readfirstlane(last) != 0;
+}
+
 // ref: voxel_grid_covariance_impl.hpp:265-343 -- one thread per leaf: mean, covariance,
 // eigen-decomposition, eigenvalue inflation, inverse, validity checks.  (Fusing this into the
 // 8 lanes that sum a leaf was tried in round 2: 48 us against 20 + 12 -- the Jacobi state on top
@@ -682,9 +701,28 @@ __global__ void __launch_bounds__(64) k_leaf_finalize(const uint32_t* __restrict
                                                       const int* __restrict__ leaf_cnt,
                                                       const double* __restrict__ sums, FinalizeParams fp,
                                                       VoxelRecord* __restrict__ rec, LeafStats* __restrict__ stats,
-                                                      int* __restrict__ cell2leaf) {
+                                                      int* __restrict__ cell2leaf, unsigned int* __restrict__ ticket,
+                                                      int* __restrict__ nleaf_host) {
   const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot >= nleaf_p[0]) return;
+  const int nl = nleaf_p[0];
+  // the grid is sized for the worst case (n / min_points leaves); only the blocks that hold a
+  // leaf -- block 0 always -- take part in the ticket (one contended address serves ~90 adds/us)
+  const int live_blocks = max(1, (nl + (int)blockDim.x - 1) / (int)blockDim.x);
+  if ((int)blockIdx.x >= live_blocks) return;
+  if (slot < nl) finalize_one(slot, keys, nleaf_p, leaf_start, leaf_cnt, sums, fp, rec, stats, cell2leaf);
+  // the block (one wave) that draws the last ticket hands the two leaf counters to the host
+  // through pinned memory: the D2H copy they used to take was a 4.4 us launch of its own
+  if (last_ticket_wave(ticket, (unsigned int)live_blocks)) {
+    if (threadIdx.x < 2) nleaf_host[threadIdx.x] = ld_agent(nleaf_p + threadIdx.x);
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+__device__ __forceinline__ void finalize_one(int slot, const uint32_t* __restrict__ keys, int* __restrict__ nleaf_p,
+                                             const int* __restrict__ leaf_start, const int* __restrict__ leaf_cnt,
+                                             const double* __restrict__ sums, FinalizeParams fp,
+                                             VoxelRecord* __restrict__ rec, LeafStats* __restrict__ stats,
+                                             int* __restrict__ cell2leaf) {
   const int start = leaf_start[slot], cnt = leaf_cnt[slot];
   const double* in = sums + (size_t)slot * 9;
   const double s[3] = {in[0], in[1], in[2]};
@@ -1141,14 +1179,14 @@ void launch_find_runs(const uint32_t* keys_sorted, size_t n, const BuildGeom* gd
 void launch_finalize_leaves(const float* xyz4, const uint32_t* keys_sorted, const uint32_t* vals_sorted,
                             int* d_nleaf, const int* leaf_start, const int* leaf_cnt, int max_leaves,
                             FinalizeParams fp, double* sums, VoxelRecord* rec, LeafStats* stats, int* cell2leaf,
-                            hipStream_t s) {
+                            unsigned int* ticket, int* nleaf_host, hipStream_t s) {
   if (max_leaves <= 0) return;
   size_t blocks = ((size_t)max_leaves * LANES_PER_LEAF + 255) / 256;
   if (blocks > (size_t)SUMS_BLOCKS_MAX) blocks = SUMS_BLOCKS_MAX;
   hipLaunchKernelGGL(k_leaf_sums, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(xyz4),
                      vals_sorted, d_nleaf, leaf_start, leaf_cnt, sums);
   hipLaunchKernelGGL(k_leaf_finalize, dim3((unsigned)((max_leaves + 63) / 64)), dim3(64), 0, s, keys_sorted, d_nleaf,
-                     leaf_start, leaf_cnt, sums, fp, rec, stats, cell2leaf);
+                     leaf_start, leaf_cnt, sums, fp, rec, stats, cell2leaf, ticket, nleaf_host);
 }
 
 }  // namespace ndt
