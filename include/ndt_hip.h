@@ -96,6 +96,16 @@ typedef enum ndt_source_order {
                                 few distinct voxel records; only the f64 summation order changes) */
 } ndt_source_order;
 
+typedef enum ndt_prelaunch {
+  NDT_PRELAUNCH_AUTO = 0, /* inside ndt_align (spin wait, no device-side reducer): the kernel of the next
+                             evaluation is enqueued while the current one runs and waits on the device for its
+                             pose, which the host publishes through BAR-mapped device memory -- takes the launch
+                             + dispatch latency (~4 us of ~7) out of every evaluation but the first.  Used when
+                             the device exposes a large BAR; a kernel that waited 20 ms gives up and the pose is
+                             evaluated through an ordinary launch. */
+  NDT_PRELAUNCH_OFF = 1
+} ndt_prelaunch;
+
 /* Named parameter sets.  ndt_default_params() is the vendored-code hybrid the parity tests pin
  * (svn covariance, full Hessian, no ridge, More-Thuente); the presets restate the two engines. */
 typedef enum ndt_preset {
@@ -126,6 +136,7 @@ typedef struct ndt_params {
   int device_id;                 /* HIP device ordinal; -1 = current device */
   int wait_mode;                 /* ndt_wait_mode */
   int source_order;              /* ndt_source_order */
+  int prelaunch;                 /* ndt_prelaunch */
 } ndt_params;
 
 typedef struct ndt_handle ndt_handle;

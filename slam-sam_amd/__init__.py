@@ -29,6 +29,7 @@ HESSIAN_FULL, HESSIAN_GAUSS_NEWTON = 0, 1
 COV_SVN, COV_PCL_RECALLED = 0, 1
 WAIT_SPIN, WAIT_BLOCK = 0, 1
 SOURCE_ORDER_AUTO, SOURCE_ORDER_KEEP, SOURCE_ORDER_SORT = 0, 1, 2
+PRELAUNCH_AUTO, PRELAUNCH_OFF = 0, 1
 PRESET_DEFAULT, PRESET_PCLOMP_RECALLED, PRESET_SVN = 0, 1, 2
 
 STATUS = {0: "NDT_OK", -1: "NDT_ERR_INVALID_ARG", -2: "NDT_ERR_NO_DEVICE", -3: "NDT_ERR_HIP",
@@ -50,6 +51,7 @@ class Params(C.Structure):
         ("hessian_mode", C.c_int), ("cov_mode", C.c_int), ("add_ridge", C.c_int),
         ("use_line_search", C.c_int), ("regularization_scale_factor", C.c_float),
         ("num_threads", C.c_int), ("device_id", C.c_int), ("wait_mode", C.c_int), ("source_order", C.c_int),
+        ("prelaunch", C.c_int),
     ]
 
 
@@ -194,6 +196,7 @@ def lib():
         L.ndt_params_preset.argtypes = [C.POINTER(Params), C.c_int]
         L.ndt_score_transform.argtypes = [vp, fp, C.POINTER(Score)]
         L.ndt_comm_info.argtypes = [C.c_char_p, C.c_size_t]
+        L.ndt_debug_prelaunch_counters.argtypes = [vp, C.POINTER(C.c_int64)]  # test seam, not in the header
         L.ndt_debug_sort_pairs.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, vp]  # test seam, not in the header
         _lib = L
     return _lib
@@ -519,6 +522,12 @@ class NormalDistributionsTransform:
     # --- instrumentation ---
     def enableKernelTiming(self, on=True):
         self._check(lib().ndt_enable_kernel_timing(self._h, int(on)))
+
+    def prelaunchCounters(self):
+        """(evaluations served by a pre-launched kernel, pre-launched kernels told to leave, time-outs)."""
+        out = (C.c_int64 * 3)()
+        self._check(lib().ndt_debug_prelaunch_counters(self._h, out))
+        return tuple(out)
 
     def getTiming(self):
         t = Timing()

@@ -3,6 +3,8 @@
 // One handle = one engine instance = one HIP stream on one gfx950 device; it
 // owns every device allocation.  There is no CPU path: without a device every
 // compute call fails with NDT_ERR_NO_DEVICE.
+#include <immintrin.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -131,6 +133,14 @@ struct ndt_handle {
   };
   std::unordered_map<int64_t, Keyframe> keyframes;
 
+  // pre-launched evaluation (ndt_prelaunch): mailbox in BAR-mapped fine-grained device memory
+  PoseMailbox* mbox = nullptr;
+  bool mbox_tried = false;
+  bool prelaunch_armed = false;       // inside ndt_align
+  unsigned long long pre_seq = 0;     // sequence number of the kernel that is waiting, 0 = none
+  bool pre_need_h = false;
+  int64_t n_prelaunch_used = 0, n_prelaunch_quit = 0, n_prelaunch_timeouts = 0;
+
   bool have_reg = false;
   float reg_pose[16];
 
@@ -169,6 +179,7 @@ bool params_valid(const ndt_params* p, std::string* why) {
   }
   if (p->wait_mode != NDT_WAIT_SPIN && p->wait_mode != NDT_WAIT_BLOCK) { *why = "unknown wait_mode"; return false; }
   if (p->source_order < NDT_SOURCE_ORDER_AUTO || p->source_order > NDT_SOURCE_ORDER_SORT) { *why = "unknown source_order"; return false; }
+  if (p->prelaunch != NDT_PRELAUNCH_AUTO && p->prelaunch != NDT_PRELAUNCH_OFF) { *why = "unknown prelaunch"; return false; }
   if (!(p->outlier_ratio >= 0.0 && p->outlier_ratio < 1.0)) { *why = "outlier_ratio must be in [0,1)"; return false; }
   if (p->max_iterations < 0) { *why = "max_iterations must be >= 0"; return false; }
   return true;
@@ -458,6 +469,44 @@ int wait_slots(ndt_handle* h, unsigned long long seq) {
   return NDT_OK;
 }
 
+// ---- pre-launched evaluation -------------------------------------------------------------------
+// The mailbox: fine-grained device memory the host can write by pointer (large BAR).  Absent
+// (no large BAR, allocation refused, NDT_PRELAUNCH=0 in the environment) -> plain launches.
+bool ensure_mailbox(ndt_handle* h) {
+  if (h->mbox_tried) return h->mbox != nullptr;
+  h->mbox_tried = true;
+  const char* e = getenv("NDT_PRELAUNCH");
+  if (e && atoi(e) == 0) return false;
+  int largebar = 0;
+  if (hipDeviceGetAttribute(&largebar, hipDeviceAttributeIsLargeBar, h->device) != hipSuccess || largebar != 1) return false;
+  void* p = nullptr;
+  if (hipExtMallocWithFlags(&p, 4096, hipDeviceMallocFinegrained) != hipSuccess || !p) {
+    (void)hipGetLastError();
+    return false;
+  }
+  if (hipMemset(p, 0, 4096) != hipSuccess) { (void)hipFree(p); return false; }
+  h->mbox = static_cast<PoseMailbox*>(p);
+  return true;
+}
+
+// pose first, sequence number last; write-combined BAR memory: fence in between and after
+void publish_pose(ndt_handle* h, unsigned long long seq, const PoseConsts& pc) {
+  static_assert(sizeof(PoseConsts) == 81 * sizeof(float), "PoseConsts is 81 packed floats");
+  std::memcpy(const_cast<unsigned int*>(h->mbox->words), &pc, sizeof(PoseConsts));
+  _mm_sfence();
+  *reinterpret_cast<volatile unsigned long long*>(&h->mbox->seq) = seq;
+  _mm_sfence();
+}
+
+// tells a waiting pre-launched kernel to leave (stream order does the rest)
+void quit_prelaunched(ndt_handle* h) {
+  if (h->pre_seq == 0) return;
+  *reinterpret_cast<volatile unsigned long long*>(&h->mbox->seq) = h->pre_seq | MBOX_QUIT;
+  _mm_sfence();
+  h->pre_seq = 0;
+  h->n_prelaunch_quit++;
+}
+
 // one global evaluation at (p, T): local kernel + cross-rank sum
 int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, Eval* out, bool score_only = false) {
   hipStream_t s = h->stream;
@@ -482,13 +531,45 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
   }
   double* d_out = dev_out ? h->dres.p : h->result.d;
   const bool spin = !dev_out && !h->timing && h->prm.wait_mode == NDT_WAIT_SPIN;
-  const unsigned long long seq = g_launch_seq.fetch_add(1, std::memory_order_relaxed);
-  if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, s));
-  launch_derivatives(h->src_sorted ? h->ox.p : h->sx.p, h->src_sorted ? h->oy.p : h->sy.p,
-                     h->src_sorted ? h->oz.p : h->sz.p, h->n_src, h->geom, h->cell2leaf.p, h->rec.p, pc,
-                     nullptr, 1, ec, h->partials.p, h->counters.p, d_out, s, spin ? h->flag.d : nullptr, seq);
-  HIP_TRY(h, hipGetLastError());
-  if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, s));
+  const float* px = h->src_sorted ? h->ox.p : h->sx.p;
+  const float* py = h->src_sorted ? h->oy.p : h->sy.p;
+  const float* pz = h->src_sorted ? h->oz.p : h->sz.p;
+  const bool prelaunch = spin && !score_only && h->prelaunch_armed && h->prm.prelaunch == NDT_PRELAUNCH_AUTO &&
+                         ensure_mailbox(h);
+  unsigned long long seq = 0;
+  bool via_mailbox = false;
+  if (h->pre_seq != 0) {
+    if (prelaunch && h->pre_need_h == need_h) {  // the kernel for this evaluation is already waiting on the device
+      seq = h->pre_seq;
+      h->pre_seq = 0;
+      {  // test seam: hold the pose back so that the waiting kernel gives up (NDT_DEBUG_PUBLISH_DELAY_MS)
+        static const int delay_ms = [] { const char* e = getenv("NDT_DEBUG_PUBLISH_DELAY_MS"); return e ? atoi(e) : 0; }();
+        if (delay_ms > 0 && h->n_prelaunch_used == 3) std::this_thread::sleep_for(std::chrono::milliseconds(delay_ms));
+      }
+      publish_pose(h, seq, pc);
+      via_mailbox = true;
+      h->n_prelaunch_used++;
+    } else {
+      quit_prelaunched(h);
+    }
+  }
+  if (!via_mailbox) {
+    seq = g_launch_seq.fetch_add(1, std::memory_order_relaxed);
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, s));
+    launch_derivatives(px, py, pz, h->n_src, h->geom, h->cell2leaf.p, h->rec.p, pc, nullptr, 1, ec, h->partials.p,
+                       h->counters.p, d_out, s, spin ? h->flag.d : nullptr, seq);
+    HIP_TRY(h, hipGetLastError());
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, s));
+  }
+  if (prelaunch) {
+    // the next evaluation's kernel goes onto the stream now, behind the one in flight; it will
+    // start when that one has finished and wait for its pose (or for the order to leave)
+    h->pre_seq = g_launch_seq.fetch_add(1, std::memory_order_relaxed);
+    h->pre_need_h = need_h;
+    launch_derivatives(px, py, pz, h->n_src, h->geom, h->cell2leaf.p, h->rec.p, pc, nullptr, 1, ec, h->partials.p,
+                       h->counters.p, d_out, s, h->flag.d, h->pre_seq, h->mbox);
+    HIP_TRY(h, hipGetLastError());
+  }
   if (dev_out) {
     int rc = h->red.allreduce_device(h->dres.p, EV_WORDS, s, &h->err);
     if (rc) return rc;
@@ -521,6 +602,14 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
   // word 31 is zero by construction; the in-kernel final sum raises it when it gave up waiting
   // for a partial row (a lost hand-off must not look like a converged result), and the kernel
   // never produces a non-finite score from finite records
+  if (words[EV_FAIL] == 2.0 && via_mailbox) {
+    // the pre-launched kernel gave up waiting for its pose (this thread was away for > 20 ms):
+    // nothing was evaluated.  Stop pre-launching on this handle and evaluate the ordinary way.
+    h->n_prelaunch_timeouts++;
+    quit_prelaunched(h);
+    h->prm.prelaunch = NDT_PRELAUNCH_OFF;
+    return evaluate(h, p, T, need_h, out, score_only);
+  }
   if (words[EV_FAIL] != 0.0 || !std::isfinite(words[EV_SCORE])) {
     h->counters_zeroed = 0;  // the ticket words may be stale: re-zero them before the next launch
     return fail(h, NDT_ERR_HIP, words[EV_FAIL] != 0.0 ? "derivative kernel: a partial row never arrived (hand-off lost)"
@@ -560,6 +649,7 @@ void ndt_default_params(ndt_params* p) {
   p->device_id = -1;
   p->wait_mode = NDT_WAIT_SPIN;
   p->source_order = NDT_SOURCE_ORDER_AUTO;
+  p->prelaunch = NDT_PRELAUNCH_AUTO;
 }
 
 int ndt_params_preset(ndt_params* p, int preset) {
@@ -643,6 +733,7 @@ int ndt_destroy(ndt_handle* h) {
   h->svals.release(); h->svals2.release(); h->ssort_tmp.release(); h->splan.release();
   h->stage.release(); h->result.release(); h->small.release(); h->partials.release();
   h->dres.release(); h->dposes.release(); h->hposes.release(); h->counters.release(); h->flag.release();
+  if (h->mbox) (void)hipFree(h->mbox);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->ev2) (void)hipEventDestroy(h->ev2);
@@ -846,7 +937,10 @@ int ndt_align(ndt_handle* h, const float guess[16], ndt_result* out) {
   const double dev_ms0 = h->tm.ms_eval_kernel_total;
   EvalFn fn = [h](const double* p, const float* T, bool need_h, Eval* e) { return evaluate(h, p, T, need_h, e); };
   const int64_t n_total = h->n_src_global >= 0 ? h->n_src_global : (int64_t)h->n_src;
+  h->prelaunch_armed = true;
   rc = newton_align(h->prm, n_total, guess, fn, out, /*hessian_in_trials=*/true);
+  h->prelaunch_armed = false;
+  quit_prelaunched(h);  // the kernel enqueued for an evaluation that never came
   out->ms_device = h->tm.ms_eval_kernel_total - dev_ms0;
   return rc;
 }
@@ -1084,6 +1178,14 @@ int ndt_comm_destroy(ndt_handle* h) {
 int ndt_result_covariance(const double hessian36[36], double eps, int gtsam_order, double cov36[36]) {
   if (!hessian36 || !cov36 || !std::isfinite(eps)) return NDT_ERR_INVALID_ARG;
   return result_covariance(hessian36, eps, gtsam_order != 0, cov36) ? NDT_OK : NDT_ERR_INVALID_ARG;
+}
+
+// test seam (not in the public header): evaluations served by a pre-launched kernel, pre-launched
+// kernels told to leave, mailbox time-outs
+int ndt_debug_prelaunch_counters(const ndt_handle* h, int64_t out[3]) {
+  if (!h || !out) return NDT_ERR_INVALID_ARG;
+  out[0] = h->n_prelaunch_used; out[1] = h->n_prelaunch_quit; out[2] = h->n_prelaunch_timeouts;
+  return NDT_OK;
 }
 
 // diagnostic builds only (-DNDT_STAMPS): 8 x 100 MHz stamps per block of the last launch

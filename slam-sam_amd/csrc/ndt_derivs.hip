@@ -598,19 +598,22 @@ struct DerivKernArgs {
   double* out;
   unsigned long long* flag;
   unsigned long long seq;
+  const PoseMailbox* mbox;
 };
 constexpr unsigned int KERNARG_TABLES_OFFSET = offsetof(DerivKernArgs, pose) + offsetof(PoseConsts, jang);
 static_assert(offsetof(PoseConsts, hang) == offsetof(PoseConsts, jang) + 24 * sizeof(float) &&
               offsetof(AngleTables, hang) == 24 * sizeof(float), "jang / hang must be contiguous");
 
 // NB: neighbourhood -- 0 DIRECT1, 1 DIRECT7, 2 KDTREE, 3 DIRECT26
-template <bool BATCH, int MODE, int NB>
+// MBOX (single-pose only): a pre-launched evaluation -- the pose is not in the kernel arguments
+// (it did not exist yet when the launch was enqueued) but arrives in *mbox, see PoseMailbox.
+template <bool BATCH, int MODE, int NB, bool MBOX>
 __global__ void __launch_bounds__(MAX_BLOCK)
 k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, int n,
               GridGeom g, const int* __restrict__ cell2leaf, const VoxelRecord* __restrict__ rec,
               PoseConsts pose_arg, const PoseConsts* __restrict__ poses, EvalConsts ec,
               double* __restrict__ partials, unsigned int* __restrict__ counters, double* __restrict__ out,
-              unsigned long long* flag, unsigned long long seq) {
+              unsigned long long* flag, unsigned long long seq, const PoseMailbox* mbox) {
   // R|t (12 dwords) stay in scalar registers; the 69 angle-table words are only needed
   // after the pair loop, so they are parked in LDS (81 live SGPRs would spill) and the
   // barrier that publishes them sits behind the memory-latency part of the kernel.
@@ -628,7 +631,41 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
   // only behind the pair phase: a wave-0 prologue of 69 scalar-to-vector moves and four
   // serialised s_load waits used to sit in front of every block's first point load.
   float tab_word = 0.0f;
-  if (BATCH) {
+  if (MBOX) {
+    __shared__ float s_rt[12];
+    __shared__ int s_go;
+    if (threadIdx.x == 0) {
+      int go = -1;  // timed out
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      for (;;) {
+        const unsigned long long v = __hip_atomic_load(&mbox->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (v == seq) { go = 1; break; }
+        if (v == (seq | MBOX_QUIT)) { go = 0; break; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > MBOX_TIMEOUT_TICKS) break;  // every wave reaches an exit
+        __builtin_amdgcn_s_sleep(1);
+      }
+      s_go = go;
+    }
+    __syncthreads();
+    const int go = s_go;
+    if (go <= 0) {
+      // quit: nothing to do.  timed out: say so in the result slots (word 31 = 2), the host
+      // evaluates this pose through an ordinary launch instead
+      if (go < 0 && blockIdx.x == 0 && threadIdx.x < EV_WORDS && flag != nullptr)
+        store_slot(slots_rsrc(flag), threadIdx.x * 16u, seq, threadIdx.x == EV_FAIL ? 2.0 : 0.0, true);
+      return;
+    }
+    if (threadIdx.x < 81) {  // the pose was published before seq (PCIe keeps posted writes in order)
+      const unsigned int w = __hip_atomic_load(&mbox->words[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (threadIdx.x < 12) s_rt[threadIdx.x] = __uint_as_float(w);
+      else tab.jang[threadIdx.x - 12] = __uint_as_float(w);  // runs on into hang[]
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 9; ++k) rt.R[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s_rt[k])));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rt.t[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s_rt[9 + k])));
+  } else if (BATCH) {
     const PoseConsts& pg = poses[blockIdx.y];
 #pragma unroll
     for (int k = 0; k < 9; ++k) rt.R[k] = pg.R[k];
@@ -668,8 +705,10 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
 #endif
   }
   NDT_STAMP(2);
-  if (threadIdx.x < 69) tab.jang[threadIdx.x] = tab_word;  // runs on into hang[]: the two arrays are contiguous
-  __syncthreads();  // angle tables visible
+  if (!MBOX) {  // (a pre-launched kernel has had its tables in LDS since it was released)
+    if (threadIdx.x < 69) tab.jang[threadIdx.x] = tab_word;  // runs on into hang[]: the two arrays are contiguous
+    __syncthreads();  // angle tables visible
+  }
   double acc[EV_WORDS];
 #if defined(NDT_ABL) && NDT_ABL >= 3  // ablation: launch + reduction only
 #pragma unroll
@@ -752,7 +791,7 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
                         const PoseConsts& pose, const PoseConsts* d_poses, int K,
                         const EvalConsts& ec, double* d_partials, unsigned int* d_counters,
                         double* d_out, hipStream_t s, unsigned long long* d_flag,
-                        unsigned long long seq) {
+                        unsigned long long seq, const PoseMailbox* d_mbox) {
   const int blocks = derivs_grid_blocks(n_src, d_poses ? K : 1);
   const int threads = derivs_block_threads(n_src, d_poses ? K : 1);
   const int mode = ec.score_only ? 3 : (!ec.need_hessian ? 0 : (ec.gauss_newton ? 2 : 1));
@@ -770,10 +809,15 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
   ecl.fixed_summer = summer;
   const int nb = ec.kdtree ? 2 : (ec.direct26 ? 3 : (ec.direct7 ? 1 : 0));
   const size_t dyn_lds = nb >= 2 ? (size_t)KD_CELLS * threads * sizeof(int) : 0;
-#define NDT_LAUNCH(B, M, NBH, GY, FLAG, SEQ)                                                              \
-  hipLaunchKernelGGL((k_derivatives<B, M, NBH>), dim3(blocks, GY), dim3(threads), dyn_lds, s, sx, sy, sz,  \
-                     (int)n_src, g, cell2leaf, rec, pose, d_poses, ecl, d_partials, d_counters, d_out,     \
-                     FLAG, SEQ)
+#define NDT_LAUNCH2(B, M, NBH, MB, GY, FLAG, SEQ)                                                            \
+  hipLaunchKernelGGL((k_derivatives<B, M, NBH, MB>), dim3(blocks, GY), dim3(threads), dyn_lds, s, sx, sy, sz,  \
+                     (int)n_src, g, cell2leaf, rec, pose, d_poses, ecl, d_partials, d_counters, d_out,         \
+                     FLAG, SEQ, d_mbox)
+#define NDT_LAUNCH(B, M, NBH, GY, FLAG, SEQ)                                  \
+  do {                                                                         \
+    if (!B && d_mbox != nullptr) NDT_LAUNCH2(false, M, NBH, true, GY, FLAG, SEQ);  \
+    else NDT_LAUNCH2(B, M, NBH, false, GY, FLAG, SEQ);                         \
+  } while (0)
 #define NDT_LAUNCH_MODE(B, NBH, GY, FLAG, SEQ)                 \
   do {                                                          \
     if (mode == 0) NDT_LAUNCH(B, 0, NBH, GY, FLAG, SEQ);        \
@@ -794,6 +838,7 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
 #undef NDT_LAUNCH_NB
 #undef NDT_LAUNCH_MODE
 #undef NDT_LAUNCH
+#undef NDT_LAUNCH2
 }
 
 void launch_transform(const float* sx, const float* sy, const float* sz, size_t n,

@@ -68,6 +68,19 @@ struct PoseConsts {
   float hang[45];  // 15x3 (ref: svn_ndt_impl.hpp:299-331)
 };
 
+// Mailbox of a PRE-LAUNCHED evaluation kernel (round 2): the kernel of evaluation N + 1 is put on
+// the stream while evaluation N is still running, starts the moment N has finished and waits,
+// one lane per block, for the host to publish the pose here -- fine-grained device memory the
+// host writes through the PCIe BAR.  words = the 81 floats of a PoseConsts; seq is written last.
+// seq == the kernel's own sequence number: go; seq == that number | MBOX_QUIT: leave at once.
+struct PoseMailbox {
+  unsigned long long seq;
+  unsigned int pad[2];
+  unsigned int words[84];
+};
+constexpr unsigned long long MBOX_QUIT = 1ull << 63;
+constexpr unsigned long long MBOX_TIMEOUT_TICKS = 2000000ull;  // 20 ms of the 100 MHz s_memrealtime clock
+
 struct EvalConsts {
   double d1, d2;   // Gauss constants (ref: svn_ndt_impl.hpp:80-131)
   int direct7;     // 1: centre + 6 face neighbours, 0: centre only (ignored in KDTREE mode)
@@ -89,7 +102,8 @@ enum {
   EV_NVTL = 28,
   EV_NWITH = 29,
   EV_NPAIRS = 30,
-  EV_FAIL = 31,    // 0; non-zero = the in-kernel final sum gave up waiting for a partial row
+  EV_FAIL = 31,    // 0; 1 = the in-kernel final sum gave up waiting for a partial row,
+                   // 2 = a pre-launched kernel gave up waiting for its pose (nothing was evaluated)
   EV_WORDS = 32
 };
 

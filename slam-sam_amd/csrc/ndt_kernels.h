@@ -87,12 +87,14 @@ int derivs_read_stamps(unsigned long long* out, int nblocks);  // diagnostic bui
 // Result: d_host_slots == nullptr -> K * EV_WORDS plain doubles in d_out (device memory);
 // d_host_slots != nullptr (single-pose path only, device-mapped pinned host memory, 2 * EV_WORDS
 // words) -> 32 slots {seq, value} for the host to poll, d_out unused.
+// d_mbox != nullptr (single-pose only): a PRE-LAUNCHED evaluation -- `pose` is ignored, the kernel
+// waits for the pose to appear in *d_mbox under its sequence number (PoseMailbox in ndt_device.h).
 void launch_derivatives(const float* sx, const float* sy, const float* sz, size_t n_src,
                         const GridGeom& g, const int* cell2leaf, const VoxelRecord* rec,
                         const PoseConsts& pose, const PoseConsts* d_poses, int K,
                         const EvalConsts& ec, double* d_partials, unsigned int* d_counters,
                         double* d_out, hipStream_t s, unsigned long long* d_host_slots,
-                        unsigned long long seq);
+                        unsigned long long seq, const PoseMailbox* d_mbox = nullptr);
 
 void launch_transform(const float* sx, const float* sy, const float* sz, size_t n,
                       const PoseConsts& pose, float* out_xyz, hipStream_t s);

@@ -224,3 +224,72 @@ def test_source_ordering_is_a_permutation_with_the_same_result(pkg, O, S):
         ea, Ta, ra, _ = res[pkg.SOURCE_ORDER_AUTO]
         same_as = e1 if auto_sorts else e0                 # bit-identical to the variant AUTO chose
         assert ea["score"] == same_as["score"] and np.array_equal(ea["hessian"], same_as["hessian"])
+
+
+def test_prelaunched_evaluations_change_no_number(pkg, S):
+    """NDT_PRELAUNCH_AUTO: inside align() the kernel of the next evaluation is already on the stream
+    and waits on the device for its pose.  Same numbers as ordinary launches, bit for bit; every
+    evaluation but the first of an align is served that way, one enqueued kernel per align is told
+    to leave; other entry points in between are unaffected."""
+    cfg = S.config_c2()
+    res = {}
+    for mode in (pkg.PRELAUNCH_OFF, pkg.PRELAUNCH_AUTO):
+        ndt = _ndt(pkg, prelaunch=mode)
+        ndt.setInputTarget(cfg["target"])
+        ndt.setInputSource(cfg["source"])
+        out = []
+        for k in range(3):
+            T = ndt.align(cfg["guess"])
+            r = ndt.getResult()
+            out.append((T, r["hessian"], r["iterations"], r["n_evaluations"], r["score"]))
+            if k == 0:   # other launches between two aligns
+                sc = ndt.scoreTransform(T)
+                e = ndt.evalDerivatives(r["pose"])[0]
+                assert sc["score"] == e["score"]
+                ndt.setInputTarget(cfg["target"])
+        res[mode] = (out, ndt.prelaunchCounters())
+        ndt.close()
+    off, (used0, quit0, to0) = res[pkg.PRELAUNCH_OFF]
+    on, (used1, quit1, to1) = res[pkg.PRELAUNCH_AUTO]
+    assert (used0, quit0, to0) == (0, 0, 0)
+    for a, b in zip(off, on):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:] == b[2:]
+    n_ev = sum(a[3] for a in on)
+    assert to1 == 0
+    if used1 == 0:
+        pytest.skip("this device exposes no BAR-mapped memory: pre-launch stays off")
+    assert used1 == n_ev - 3 and quit1 == 3
+
+
+def test_prelaunched_kernel_that_times_out_falls_back(pkg, S):
+    """A pre-launched kernel that waited 20 ms for its pose gives up; the host sees it (word 31 of
+    the result = 2), stops pre-launching on that handle and evaluates the pose through an ordinary
+    launch: same result, no hang.  (Own process: the delay seam is read once from the environment.)"""
+    import subprocess, sys, os
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+import __graft_entry__ as ge
+pkg = ge.load_package(); S = pkg.synth
+cfg = S.config_c2()
+kw = dict(resolution=1.0, step_size=0.1, trans_epsilon=1e-4, max_iterations=35)
+ref = pkg.NormalDistributionsTransform(device_id=0, prelaunch=pkg.PRELAUNCH_OFF, **kw)
+ref.setInputTarget(cfg["target"]); ref.setInputSource(cfg["source"])
+T0 = ref.align(cfg["guess"])
+ndt = pkg.NormalDistributionsTransform(device_id=0, **kw)
+ndt.setInputTarget(cfg["target"]); ndt.setInputSource(cfg["source"])
+T1 = ndt.align(cfg["guess"])
+used, quit, timeouts = ndt.prelaunchCounters()
+print("counters", used, quit, timeouts, "equal", bool(np.array_equal(T0, T1)))
+T2 = ndt.align(cfg["guess"])
+print("again equal", bool(np.array_equal(T0, T2)))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NDT_DEBUG_PUBLISH_DELAY_MS="60")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("counters")][0].split()
+    used, quit, timeouts = int(line[1]), int(line[2]), int(line[3])
+    assert "equal True" in p.stdout and "again equal True" in p.stdout
+    if used == 0:
+        pytest.skip("no BAR-mapped memory on this device")
+    assert timeouts == 1
