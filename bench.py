@@ -229,6 +229,7 @@ def main():
         for _ in range(args.warmup):
             step()
         fence()
+        pre0 = ndt.prelaunchCounters()
         t0 = time.perf_counter()
         iters = evals = reused = 0
         t_build = t_align = 0.0
@@ -245,7 +246,9 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        return dict(elapsed=elapsed, iters=iters, evals=evals, reused=reused, t_build=t_build, t_align=t_align)
+        pre1 = ndt.prelaunchCounters()
+        return dict(elapsed=elapsed, iters=iters, evals=evals, reused=reused, t_build=t_build, t_align=t_align,
+                    prelaunched=pre1[0] - pre0[0], prelaunch_timeouts=pre1[2] - pre0[2])
 
     def init_reducer(mode):
         """Creates the engine's cross-rank reducer on every rank; False if any rank failed."""
@@ -319,9 +322,11 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_source,
                          "hbm_achieved_from_traffic": (traffic / (ms_kernel * 1e-3) / 1e9) if (traffic and ms_kernel > 0) else None,
-                         "note": "achieved = algorithmic bytes / HIP-event launch duration (SURVEY 8d); the table is "
-                                 "cache-resident at this size, so real HBM traffic is far lower and the kernel is "
-                                 "latency-bound, see DESIGN.md 4.1",
+                         "note": "achieved = algorithmic bytes / HIP-event launch duration (SURVEY 8d), measured in an "
+                                 "instrumented repeat that uses ordinary launches (k_derivatives<..., false>): the "
+                                 "pre-launched variant (<..., true>) of the timed steps starts early and its duration "
+                                 "includes waiting for the pose.  The table is cache-resident at this size, so real HBM "
+                                 "traffic is far lower and the kernel is VALU/latency-bound, see DESIGN.md 4.1",
                          "algorithmic_bytes_per_launch": algo_bytes, "ms_per_launch": ms_kernel,
                          "ms_final_reduce": ms_reduce, "launches_timed": int(n_timed)},
             # the build as a group of kernels: SURVEY 8d's B_build over the device time of one build
@@ -346,6 +351,10 @@ def main():
             "iterations_per_align": iters / args.steps, "evaluations_per_align": evals / args.steps,
             # line-search requests at the pose of the evaluation before them, answered without a launch
             "evaluations_reused_per_align": res["reused"] / args.steps,
+            # evaluations whose kernel was already waiting on the device for its pose (pre-launched while the
+            # previous evaluation ran); the rest went through an ordinary launch
+            "evaluations_prelaunched_per_align": res["prelaunched"] / args.steps,
+            "prelaunch_timeouts": res["prelaunch_timeouts"],
             "align_only_iterations_per_sec": iters / res["t_align"], "evaluations_per_sec": evals / res["t_align"],
         })
         out["config"]["reduce"] = reduce_mode

@@ -36,6 +36,7 @@ def test_bench_line_schema():
     hc = d["host_cloud"]
     assert hc["unit"] == "iterations/s" and 0 < hc["value"] < d["value"] and hc["ms_scan"] > d["ms_per_step"]
     assert d["evaluations_reused_per_align"] >= 0 and d["config"]["rccl"]["version"] > 20000
+    assert 0 <= d["evaluations_prelaunched_per_align"] < d["evaluations_per_align"] and d["prelaunch_timeouts"] == 0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "iterations/s" and cb["sample"]
     assert cb["nproc"] >= cb["cores"] and cb["cpus_usable"] >= 1 and "-O" in cb["build_flags"] and cb["threads_8"]["threads"] <= 8
