@@ -12,10 +12,10 @@ ndt = pkg.NormalDistributionsTransform(device_id=0, resolution=0.5, step_size=0.
 ndt.setInputTarget(cfg["target"])
 gt_inv = np.linalg.inv(cfg["gt"])
 big = (cfg["target"].astype(np.float64) @ gt_inv[:3, :3].T + gt_inv[:3, 3]).astype(np.float32)
-shapes = [("200k (196 blocks of 1024)", cfg["source"], reps),
+shapes = [("200k (241 blocks of 832)", cfg["source"], reps),
           ("1k (2 blocks)", cfg["source"][:1000], reps),
           ("130k (254 blocks of 512)", cfg["source"][:130000], reps),
-          ("1M (1954 rows, 7 trips)", big, max(50, reps // 20)),
+          ("1M (1954 rows)", big, max(50, reps // 20)),
           ("1.2M (two-level sum)", np.concatenate([big, big[:200000] + np.float32(0.01)]), max(50, reps // 20))]
 g = pkg.ColMajor4f(cfg["guess"])
 bad = 0
