@@ -125,6 +125,9 @@ struct ndt_handle {
   size_t counters_zeroed = 0;
   DevBuf<PoseConsts> dposes;
   PinBuf<PoseConsts> hposes;
+  PoseConsts* bposes = nullptr;      // pose batch in BAR-mapped fine-grained device memory (host writes it directly)
+  size_t bposes_cap = 0;
+  size_t flag_slots = 0;             // poses the pinned result slots `flag` can hold
 
   // device-resident keyframe archive (pointsArchive of the drivers, ref: run/pipeline.cpp:784)
   struct Keyframe {
@@ -397,6 +400,15 @@ int ready_for_eval(ndt_handle* h) {
   return NDT_OK;
 }
 
+// pinned result slots for K poses (32 tagged 16-byte slots each), zeroed when (re)allocated
+int ensure_flag_slots(ndt_handle* h, size_t K) {
+  if (K <= h->flag_slots && h->flag.h) return NDT_OK;
+  HIP_TRY(h, h->flag.ensure(K * 2 * EV_WORDS));
+  std::memset(h->flag.h, 0, K * 2 * EV_WORDS * sizeof(unsigned long long));
+  h->flag_slots = K;
+  return NDT_OK;
+}
+
 // The source in block order of the target grid under T, when the engine's parameters ask for it
 // (NDT_SOURCE_ORDER_*).  Done once per (source, target): the copy stays a valid permutation of the
 // source whatever the later poses are.
@@ -451,15 +463,20 @@ bool slots_complete(const volatile unsigned long long* slots, unsigned long long
   return true;
 }
 
-int wait_slots(ndt_handle* h, unsigned long long seq) {
+int wait_slots(ndt_handle* h, unsigned long long seq, int K = 1) {
   const volatile unsigned long long* f = h->flag.h;
   const auto t0 = std::chrono::steady_clock::now();
   unsigned int spins = 0;
-  while (!slots_complete(f, seq)) {
+  auto all_complete = [&] {
+    for (int k = K - 1; k >= 0; --k)
+      if (!slots_complete(f + (size_t)k * 2 * EV_WORDS, seq)) return false;
+    return true;
+  };
+  while (!all_complete()) {
     if ((++spins & 0xFFFF) == 0 &&
         std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
       HIP_TRY(h, hipStreamSynchronize(h->stream));
-      if (!slots_complete(f, seq)) {
+      if (!all_complete()) {
         h->counters_zeroed = 0;  // the ticket words may be stale: re-zero them before the next launch
         return fail(h, NDT_ERR_HIP, "derivative kernel finished without publishing its result");
       }
@@ -519,9 +536,9 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
     if (rc) return rc;
   }
   HIP_TRY(h, h->result.ensure(EV_WORDS));
-  if (!h->flag.h) {
-    HIP_TRY(h, h->flag.ensure(2 * EV_WORDS));
-    std::memset(h->flag.h, 0, 2 * EV_WORDS * sizeof(unsigned long long));
+  {
+    int rc = ensure_flag_slots(h, 1);
+    if (rc) return rc;
   }
   const bool dev_out = h->red.wants_device_buffer();
   if (dev_out) HIP_TRY(h, h->dres.ensure(EV_WORDS));
@@ -734,6 +751,7 @@ int ndt_destroy(ndt_handle* h) {
   h->stage.release(); h->result.release(); h->small.release(); h->partials.release();
   h->dres.release(); h->dposes.release(); h->hposes.release(); h->counters.release(); h->flag.release();
   if (h->mbox) (void)hipFree(h->mbox);
+  if (h->bposes) (void)hipFree(h->bposes);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->ev2) (void)hipEventDestroy(h->ev2);
@@ -984,12 +1002,36 @@ int ndt_eval_derivatives(ndt_handle* h, const double* poses6, const float* trans
   hipStream_t s = h->stream;
   HIP_TRY(h, h->hposes.ensure((size_t)K));
   HIP_TRY(h, h->dposes.ensure((size_t)K));
+  // Fast hand-off of a batch (one SVN iteration): the poses are written by the host straight into
+  // BAR-mapped device memory (no H2D copy launch) and every pose's result comes back as 32 tagged
+  // slots in pinned host memory that this thread polls (no D2H copy launch, no stream sync).
+  const bool dev_red = h->red.wants_device_buffer();
+  bool fast = !dev_red && !h->timing && h->prm.wait_mode == NDT_WAIT_SPIN && ensure_mailbox(h);
+  if (fast && (size_t)K > h->bposes_cap) {
+    if (h->bposes) (void)hipFree(h->bposes);
+    h->bposes = nullptr;
+    h->bposes_cap = 0;
+    void* p = nullptr;
+    const size_t want = (size_t)K + 8;
+    if (hipExtMallocWithFlags(&p, want * sizeof(PoseConsts), hipDeviceMallocFinegrained) == hipSuccess && p) {
+      h->bposes = static_cast<PoseConsts*>(p);
+      h->bposes_cap = want;
+    } else {
+      (void)hipGetLastError();
+      fast = false;
+    }
+  }
+  PoseConsts* stage = fast ? h->bposes : h->hposes.h;
   for (int k = 0; k < K; ++k) {
     float T[16];
     const float* Tk = transforms ? transforms + 16 * (size_t)k : T;
     if (!transforms) pose_to_matrix(poses6 + 6 * (size_t)k, T);
-    fill_pose_consts(poses6 + 6 * (size_t)k, Tk, &h->hposes.h[k]);
+    PoseConsts pc;
+    fill_pose_consts(poses6 + 6 * (size_t)k, Tk, &pc);
+    std::memcpy(&stage[k], &pc, sizeof(pc));
+    if (k == 0) h->hposes.h[0] = pc;
   }
+  if (fast) _mm_sfence();  // the write-combined BAR stores are on their way before the doorbell rings
   const EvalConsts ec = make_eval_consts(h, compute_hessian != 0);
   rc = ensure_partials(h, derivs_partials_words(h->n_src, K));
   if (rc) return rc;
@@ -997,20 +1039,34 @@ int ndt_eval_derivatives(ndt_handle* h, const double* poses6, const float* trans
   HIP_TRY(h, h->dres.ensure((size_t)K * EV_WORDS));
   rc = ensure_counters(h, (size_t)K * derivs_counters_per_pose());
   if (rc) return rc;
-  HIP_TRY(h, hipMemcpyAsync(h->dposes.p, h->hposes.h, (size_t)K * sizeof(PoseConsts), hipMemcpyHostToDevice, s));
+  if (fast) {
+    rc = ensure_flag_slots(h, (size_t)K);
+    if (rc) return rc;
+  } else {
+    HIP_TRY(h, hipMemcpyAsync(h->dposes.p, h->hposes.h, (size_t)K * sizeof(PoseConsts), hipMemcpyHostToDevice, s));
+  }
+  const unsigned long long seq = g_launch_seq.fetch_add(1, std::memory_order_relaxed);
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, s));
   launch_derivatives(h->src_sorted ? h->ox.p : h->sx.p, h->src_sorted ? h->oy.p : h->sy.p,
                      h->src_sorted ? h->oz.p : h->sz.p, h->n_src, h->geom, h->cell2leaf.p, h->rec.p,
-                     h->hposes.h[0], h->dposes.p, K, ec, h->partials.p, h->counters.p, h->dres.p, s, nullptr,
-                     g_launch_seq.fetch_add(1, std::memory_order_relaxed));
+                     h->hposes.h[0], fast ? h->bposes : h->dposes.p, K, ec, h->partials.p, h->counters.p, h->dres.p, s,
+                     fast ? h->flag.d : nullptr, seq);
   HIP_TRY(h, hipGetLastError());
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, s));
-  if (h->red.wants_device_buffer()) {
-    rc = h->red.allreduce_device(h->dres.p, K * EV_WORDS, s, &h->err);
+  if (fast) {
+    rc = wait_slots(h, seq, K);
     if (rc) return rc;
+    for (int k = 0; k < K; ++k)
+      for (int v = 0; v < EV_WORDS; ++v)
+        std::memcpy(&h->result.h[(size_t)k * EV_WORDS + v], &h->flag.h[((size_t)k * EV_WORDS + v) * 2 + 1], sizeof(double));
+  } else {
+    if (dev_red) {
+      rc = h->red.allreduce_device(h->dres.p, K * EV_WORDS, s, &h->err);
+      if (rc) return rc;
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->result.h, h->dres.p, (size_t)K * EV_WORDS * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
   }
-  HIP_TRY(h, hipMemcpyAsync(h->result.h, h->dres.p, (size_t)K * EV_WORDS * sizeof(double), hipMemcpyDeviceToHost, s));
-  HIP_TRY(h, hipStreamSynchronize(s));
   h->tm.n_eval_launches++;
   if (h->timing) {
     float ms = 0;
@@ -1019,6 +1075,11 @@ int ndt_eval_derivatives(ndt_handle* h, const double* poses6, const float* trans
     h->tm.ms_eval_kernel_total += ms;
     h->tm.n_timed_evals++;
   }
+  for (int k = 0; k < K; ++k)
+    if (h->result.h[(size_t)k * EV_WORDS + EV_FAIL] != 0.0 || !std::isfinite(h->result.h[(size_t)k * EV_WORDS + EV_SCORE])) {
+      h->counters_zeroed = 0;
+      return fail(h, NDT_ERR_HIP, "derivative kernel (batched): a partial row never arrived or the score is not finite");
+    }
   std::memcpy(out, h->result.h, (size_t)K * EV_WORDS * sizeof(double));
   if (!h->red.wants_device_buffer() && h->red.mode() != NDT_REDUCE_NONE) {
     for (int k = 0; k < K; ++k) {

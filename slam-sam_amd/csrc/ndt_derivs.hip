@@ -721,7 +721,9 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
   NDT_STAMP(3);
   double* base = partials + (size_t)blockIdx.y * (gridDim.x + NGROUPS) * ROW_WORDS;
   block_reduce_finish(acc, base + (size_t)NGROUPS * ROW_WORDS, base, counters + blockIdx.y * COUNTERS_PER_POSE,
-                      out + (size_t)blockIdx.y * EV_WORDS, BATCH ? nullptr : flag, seq, ec.single_level_max,
+                      out + (size_t)blockIdx.y * EV_WORDS,
+                      flag ? flag + (size_t)blockIdx.y * ROW_WORDS : nullptr,  // pose y's 32 host slots
+                      seq, ec.single_level_max,
                       ec.fixed_summer != 0);
 }
 
@@ -832,8 +834,7 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
     else if (nb == 2) NDT_LAUNCH_MODE(B, 2, GY, FLAG, SEQ);     \
     else NDT_LAUNCH_MODE(B, 3, GY, FLAG, SEQ);                  \
   } while (0)
-  unsigned long long* const no_flag = nullptr;
-  if (d_poses) NDT_LAUNCH_NB(true, K, no_flag, seq);
+  if (d_poses) NDT_LAUNCH_NB(true, K, d_flag, seq);
   else NDT_LAUNCH_NB(false, 1, d_flag, seq);
 #undef NDT_LAUNCH_NB
 #undef NDT_LAUNCH_MODE

@@ -85,8 +85,8 @@ int derivs_read_stamps(unsigned long long* out, int nblocks);  // diagnostic bui
 // tags every partial slot).  If d_poses is null the single pose `pose` is passed as a kernel
 // argument.  One launch: the last block to finish adds the per-block rows in fixed order.
 // Result: d_host_slots == nullptr -> K * EV_WORDS plain doubles in d_out (device memory);
-// d_host_slots != nullptr (single-pose path only, device-mapped pinned host memory, 2 * EV_WORDS
-// words) -> 32 slots {seq, value} for the host to poll, d_out unused.
+// d_host_slots != nullptr (device-mapped pinned host memory, K * 2 * EV_WORDS words) -> 32 slots
+// {seq, value} per pose for the host to poll, d_out unused.
 // d_mbox != nullptr (single-pose only): a PRE-LAUNCHED evaluation -- `pose` is ignored, the kernel
 // waits for the pose to appear in *d_mbox under its sequence number (PoseMailbox in ndt_device.h).
 void launch_derivatives(const float* sx, const float* sy, const float* sz, size_t n_src,

@@ -149,7 +149,8 @@ int ndt_svn_align(ndt_handle* h, const ndt_svn_params* sp, const double prior16[
   std::vector<double> poses6(6 * (size_t)K), words((size_t)K * NDT_EVAL_WORDS), upd(6 * (size_t)K);
   std::vector<float> transforms(16 * (size_t)K);
   std::vector<double> grad(6 * (size_t)K), hess(36 * (size_t)K);  // GTSAM order
-  std::vector<char> gfin((size_t)K), hfin((size_t)K);
+  std::vector<char> gfin((size_t)K), hfin((size_t)K), kok;
+  std::vector<double> kval, kgrad;
   Pose mean_cur = prior, mean_prev = prior;
   const double hb = sp->kernel_bandwidth;
 
@@ -181,9 +182,15 @@ int ndt_svn_align(ndt_handle* h, const ndt_svn_params* sp, const double prior16[
     }
     const double t2 = now_ms();
     // ---- Stage 2: kernel-weighted mix + one 6x6 solve per particle (ref :789-839) ----
-    for (int k = 0; k < K; ++k) {
-      double phi[6] = {0, 0, 0, 0, 0, 0}, Ht[36] = {0};
-      for (int l = 0; l < K; ++l) {
+    // k(l, k) = exp(-|Log(l^-1 k)|^2 / h) and its gradient k * (-2/h) * Log(l^-1 k) (ref :213-244).
+    // Log((l^-1 k)^-1) = -Log(l^-1 k), so every pair is evaluated once: k(k, l) = k(l, k),
+    // grad(k, l) = -grad(l, k); the diagonal is k = 1, grad = 0.  (The reference evaluates all
+    // K^2 ordered pairs: identical up to the rounding of the logarithm.)
+    kval.assign((size_t)K * K, 1.0);
+    kgrad.assign((size_t)K * K * 6, 0.0);
+    kok.assign((size_t)K * K, 1);
+    for (int l = 0; l < K; ++l)
+      for (int k = l + 1; k < K; ++k) {
         double d[6];
         se3::logmap(se3::between(part[(size_t)l], part[(size_t)k]), d);
         double sq = 0;
@@ -196,7 +203,19 @@ int ndt_svn_align(ndt_handle* h, const ndt_svn_params* sp, const double prior16[
           kv = std::exp(-sq / hb);
           for (int i = 0; i < 6; ++i) kg[i] = kv * (-2.0 / hb) * d[i];
         }
-        if (!std::isfinite(kv) || !all_finite(kg, 6)) continue;
+        const bool ok = std::isfinite(kv) && all_finite(kg, 6);
+        const size_t a = (size_t)l * K + k, b = (size_t)k * K + l;
+        kval[a] = kval[b] = kv;
+        kok[a] = kok[b] = ok ? 1 : 0;
+        for (int i = 0; i < 6; ++i) { kgrad[6 * a + i] = kg[i]; kgrad[6 * b + i] = -kg[i]; }
+      }
+    for (int k = 0; k < K; ++k) {
+      double phi[6] = {0, 0, 0, 0, 0, 0}, Ht[36] = {0};
+      for (int l = 0; l < K; ++l) {
+        const size_t a = (size_t)l * K + k;
+        if (!kok[a]) continue;
+        const double kv = kval[a];
+        const double* kg = &kgrad[6 * a];
         const double* gl = &grad[6 * (size_t)l];
         const double* Hl = &hess[36 * (size_t)l];
         for (int i = 0; i < 6; ++i) phi[i] += (gfin[(size_t)l] ? kv * gl[i] : 0.0) + kg[i];
