@@ -264,6 +264,26 @@ typedef struct ndt_score {
   int64_t n_points_with_neighbors;
 } ndt_score;
 int ndt_score_transform(ndt_handle* h, const float T_colmajor[16], ndt_score* out);
+/* K transforms (K x 16 floats) scored in ONE launch of the batched score-only kernel */
+int ndt_score_transforms(ndt_handle* h, const float* transforms_colmajor, int K, ndt_score* out);
+
+/* 2-D (x, y) covariance estimators of tier4 ndt_omp's estimate_covariance.cpp.
+ * [RECALLED]: the file is in the un-vendored submodule; the reference names it only in its build
+ * (ref: CMakeLists.txt:40) and no driver calls it.  cov_xy: 2x2 row-major.
+ *  - Laplace approximation: -(H[0:2,0:2])^-1 of a result's Hessian;
+ *  - poses to search: (offset_x, offset_y) pairs rotated onto the principal axes of that
+ *    covariance and added to the result's translation (n x 16 floats out);
+ *  - MULTI_NDT: re-align from every pose, unbiased sample covariance of the (x, y) of the main
+ *    result and the n re-aligned results (the handle's last result is the last re-alignment);
+ *  - MULTI_NDT_SCORE: NVTL of the source at every pose -- one batched launch --, weights
+ *    softmax(NVTL / temperature) over {main result} + poses, weighted mean and covariance. */
+int ndt_xy_covariance_laplace(const double hessian36[36], double cov_xy[4]);
+int ndt_propose_poses_to_search(const ndt_result* r, const double* offsets_x, const double* offsets_y, int n,
+                                float* poses16_out);
+int ndt_xy_covariance_multi_ndt(ndt_handle* h, const ndt_result* main_result, const float* poses16, int n,
+                                double mean_xy[2], double cov_xy[4]);
+int ndt_xy_covariance_multi_ndt_score(ndt_handle* h, const ndt_result* main_result, const float* poses16, int n,
+                                      double temperature, double mean_xy[2], double cov_xy[4]);
 
 /* Covariance of a registration result for the pose graph: cov = -(H + eps I)^-1 of
  * ndt_result.hessian (ref: run/pipeline.cpp:594-596, eps = 1e-6 there), and with

@@ -129,7 +129,9 @@ ABI_SYMBOLS = [
     "ndt_svn_default_params", "ndt_svn_sample_particles", "ndt_svn_align",
     "ndt_keyframe_put", "ndt_keyframe_erase", "ndt_keyframe_count", "ndt_set_target_from_keyframes",
     "ndt_result_covariance", "ndt_set_source_from_keyframe",
-    "ndt_params_preset", "ndt_score_transform", "ndt_comm_info",
+    "ndt_params_preset", "ndt_score_transform", "ndt_comm_info", "ndt_score_transforms",
+    "ndt_xy_covariance_laplace", "ndt_propose_poses_to_search", "ndt_xy_covariance_multi_ndt",
+    "ndt_xy_covariance_multi_ndt_score",
 ]
 
 _lib = None
@@ -196,6 +198,11 @@ def lib():
         L.ndt_params_preset.argtypes = [C.POINTER(Params), C.c_int]
         L.ndt_score_transform.argtypes = [vp, fp, C.POINTER(Score)]
         L.ndt_comm_info.argtypes = [C.c_char_p, C.c_size_t]
+        L.ndt_score_transforms.argtypes = [vp, fp, C.c_int, C.POINTER(Score)]
+        L.ndt_xy_covariance_laplace.argtypes = [dp, dp]
+        L.ndt_propose_poses_to_search.argtypes = [C.POINTER(Result), dp, dp, C.c_int, fp]
+        L.ndt_xy_covariance_multi_ndt.argtypes = [vp, C.POINTER(Result), fp, C.c_int, dp, dp]
+        L.ndt_xy_covariance_multi_ndt_score.argtypes = [vp, C.POINTER(Result), fp, C.c_int, C.c_double, dp, dp]
         L.ndt_debug_prelaunch_counters.argtypes = [vp, C.POINTER(C.c_int64)]  # test seam, not in the header
         L.ndt_debug_sort_pairs.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, vp]  # test seam, not in the header
         _lib = L
@@ -440,6 +447,40 @@ class NormalDistributionsTransform:
                     nvtl=sc.nearest_voxel_transformation_likelihood, n_pairs=sc.n_pairs,
                     n_points_with_neighbors=sc.n_points_with_neighbors)
 
+    def scoreTransforms(self, transforms):
+        """K transforms scored in one launch: list of dicts like scoreTransform()."""
+        t = np.ascontiguousarray(np.stack([_colmajor(T) for T in transforms]), dtype=np.float32)
+        K = len(t)
+        out = (Score * K)()
+        self._check(lib().ndt_score_transforms(self._h, _fp(t), K, out))
+        return [dict(score=o.score, transform_probability=o.transform_probability,
+                     nvtl=o.nearest_voxel_transformation_likelihood, n_pairs=o.n_pairs,
+                     n_points_with_neighbors=o.n_points_with_neighbors) for o in out]
+
+    # --- 2-D covariance estimators of tier4 ndt_omp [RECALLED] (SURVEY 8f-4) ---
+    def proposePosesToSearch(self, offsets_x, offsets_y):
+        """Offsets rotated onto the principal axes of the Laplace covariance of the LAST result."""
+        ox = np.ascontiguousarray(offsets_x, dtype=np.float64)
+        oy = np.ascontiguousarray(offsets_y, dtype=np.float64)
+        out = np.zeros((len(ox), 16), np.float32)
+        self._check(lib().ndt_propose_poses_to_search(C.byref(self._raw), _dp(ox), _dp(oy), len(ox), _fp(out)))
+        return [out[i].reshape(4, 4).T.astype(np.float64) for i in range(len(ox))]
+
+    def estimateXYCovarianceMultiNdt(self, poses):
+        main = Result.from_buffer_copy(self._raw)
+        t = np.ascontiguousarray(np.stack([_colmajor(T) for T in poses]), dtype=np.float32)
+        mean, cov = np.zeros(2), np.zeros(4)
+        self._check(lib().ndt_xy_covariance_multi_ndt(self._h, C.byref(main), _fp(t), len(t), _dp(mean), _dp(cov)))
+        return mean, cov.reshape(2, 2)
+
+    def estimateXYCovarianceMultiNdtScore(self, poses, temperature):
+        main = Result.from_buffer_copy(self._raw)
+        t = np.ascontiguousarray(np.stack([_colmajor(T) for T in poses]), dtype=np.float32)
+        mean, cov = np.zeros(2), np.zeros(4)
+        self._check(lib().ndt_xy_covariance_multi_ndt_score(self._h, C.byref(main), _fp(t), len(t), float(temperature),
+                                                            _dp(mean), _dp(cov)))
+        return mean, cov.reshape(2, 2)
+
     def calculateTransformationProbability(self, cloud, T=None):
         """pclomp's scoring-only call [RECALLED]: score / #points of `cloud` (already transformed,
         or moved by T) against the current target."""
@@ -544,6 +585,16 @@ def comm_unique_id():
     if rc != 0:
         raise NdtError(rc, "ndt_comm_unique_id")
     return buf.raw
+
+
+def xy_covariance_laplace(hessian):
+    """-(H[0:2,0:2])^-1 [RECALLED tier4 estimate_xy_covariance_by_Laplace_approximation]."""
+    H = np.ascontiguousarray(hessian, dtype=np.float64).reshape(36)
+    out = np.zeros(4)
+    rc = lib().ndt_xy_covariance_laplace(_dp(H), _dp(out))
+    if rc != 0:
+        raise NdtError(rc, "xy block of the Hessian is singular or not finite")
+    return out.reshape(2, 2)
 
 
 def result_covariance(hessian, eps=1e-6, gtsam_order=True):

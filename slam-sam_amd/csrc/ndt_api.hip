@@ -986,8 +986,8 @@ int ndt_score_transform(ndt_handle* h, const float T[16], ndt_score* out) {
 
 int ndt_comm_info(char* path_buf, size_t cap) { return Reducer::library_info(path_buf, cap); }
 
-int ndt_eval_derivatives(ndt_handle* h, const double* poses6, const float* transforms, int K,
-                         int compute_hessian, double* out) {
+static int eval_batch(ndt_handle* h, const double* poses6, const float* transforms, int K, int compute_hessian,
+                      bool score_only, double* out) {
   if (!h || !poses6 || !out || K <= 0) return NDT_ERR_INVALID_ARG;
   int rc = bind_device(h);
   if (rc) return rc;
@@ -1032,7 +1032,8 @@ int ndt_eval_derivatives(ndt_handle* h, const double* poses6, const float* trans
     if (k == 0) h->hposes.h[0] = pc;
   }
   if (fast) _mm_sfence();  // the write-combined BAR stores are on their way before the doorbell rings
-  const EvalConsts ec = make_eval_consts(h, compute_hessian != 0);
+  EvalConsts ec = make_eval_consts(h, compute_hessian != 0);
+  ec.score_only = score_only ? 1 : 0;
   rc = ensure_partials(h, derivs_partials_words(h->n_src, K));
   if (rc) return rc;
   HIP_TRY(h, h->result.ensure((size_t)K * EV_WORDS));
@@ -1087,6 +1088,7 @@ int ndt_eval_derivatives(ndt_handle* h, const double* poses6, const float* trans
       if (rc) return rc;
     }
   }
+  if (score_only) return NDT_OK;
   // ridge / regularisation / guards, then repack so callers see finished values
   for (int k = 0; k < K; ++k) {
     double* w = out + (size_t)k * EV_WORDS;
@@ -1098,6 +1100,28 @@ int ndt_eval_derivatives(ndt_handle* h, const double* poses6, const float* trans
     int idx = EV_H;
     for (int i = 0; i < 6; ++i)
       for (int j = i; j < 6; ++j) w[idx++] = e.H[6 * i + j];
+  }
+  return NDT_OK;
+}
+
+int ndt_eval_derivatives(ndt_handle* h, const double* poses6, const float* transforms, int K,
+                         int compute_hessian, double* out) {
+  return eval_batch(h, poses6, transforms, K, compute_hessian, false, out);
+}
+
+int ndt_score_transforms(ndt_handle* h, const float* transforms, int K, ndt_score* out) {
+  if (!h || !transforms || !out || K <= 0) return NDT_ERR_INVALID_ARG;
+  std::vector<double> poses6(6 * (size_t)K, 0.0), words((size_t)K * EV_WORDS);  // the angle tables are not used
+  int rc = eval_batch(h, poses6.data(), transforms, K, 0, true, words.data());
+  if (rc) return rc;
+  const int64_t n_total = h->n_src_global >= 0 ? h->n_src_global : (int64_t)h->n_src;
+  for (int k = 0; k < K; ++k) {
+    const double* w = &words[(size_t)k * EV_WORDS];
+    out[k].score = w[EV_SCORE];
+    out[k].transform_probability = n_total > 0 ? w[EV_SCORE] / (double)n_total : 0.0;
+    out[k].nearest_voxel_transformation_likelihood = w[EV_NWITH] > 0 ? w[EV_NVTL] / w[EV_NWITH] : 0.0;
+    out[k].n_pairs = (int64_t)w[EV_NPAIRS];
+    out[k].n_points_with_neighbors = (int64_t)w[EV_NWITH];
   }
   return NDT_OK;
 }

@@ -196,3 +196,35 @@ def test_presets_and_new_parameter_validation(pkg):
 def test_comm_info_names_the_collective_library(pkg):
     v, path = pkg.comm_info()
     assert v > 20000 and "rccl" in path
+
+
+def test_xy_covariance_laplace_and_search_poses(pkg):
+    """tier4 ndt_omp's estimate_covariance helpers [RECALLED], host-only parts:
+    Laplace covariance = -(H_xy)^-1; search poses = offsets rotated onto the principal axis of
+    the smaller eigenvalue of that covariance, added to the result's translation."""
+    rng = np.random.default_rng(4)
+    A = rng.normal(size=(6, 6))
+    H = -(A @ A.T + 6 * np.eye(6))
+    cov = pkg.xy_covariance_laplace(H)
+    np.testing.assert_allclose(cov, -np.linalg.inv(H[:2, :2]), rtol=1e-12)
+    with pytest.raises(pkg.NdtError):
+        pkg.xy_covariance_laplace(np.zeros((6, 6)))
+    r = pkg.Result()
+    T = np.eye(4); T[:3, 3] = [10.0, -4.0, 1.5]
+    r.final_transformation[:] = list(np.ascontiguousarray(T.T, dtype=np.float32).ravel())
+    r.hessian[:] = list(H.ravel())
+    ox, oy = np.array([0.0, 0.0, 0.3, -0.3, 1.0]), np.array([0.4, -0.4, 0.0, 0.0, 1.0])
+    out = np.zeros((5, 16), np.float32)
+    dp, fp = C.POINTER(C.c_double), C.POINTER(C.c_float)
+    assert pkg.lib().ndt_propose_poses_to_search(C.byref(r), ox.ctypes.data_as(dp), oy.ctypes.data_as(dp), 5,
+                                                 out.ctypes.data_as(fp)) == 0
+    w, V = np.linalg.eigh(cov)
+    th = np.arctan2(V[1, 0], V[0, 0])
+    R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    for i in range(5):
+        P = out[i].reshape(4, 4).T
+        want = T[:2, 3] + R @ np.array([ox[i], oy[i]])
+        # the eigenvector's sign is arbitrary: the offset may come out mirrored through the centre
+        mirrored = T[:2, 3] - R @ np.array([ox[i], oy[i]])
+        assert np.allclose(P[:2, 3], want, atol=1e-5) or np.allclose(P[:2, 3], mirrored, atol=1e-5)
+        assert np.allclose(P[:3, :3], np.eye(3)) and P[2, 3] == np.float32(1.5)

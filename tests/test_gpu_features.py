@@ -293,3 +293,53 @@ print("again equal", bool(np.array_equal(T0, T2)))
     if used == 0:
         pytest.skip("no BAR-mapped memory on this device")
     assert timeouts == 1
+
+
+def test_batched_scoring_and_xy_covariance_estimators(pkg, O, S):
+    """ndt_score_transforms: K poses in one launch == K single scoring launches, bit for bit.
+    The 2-D covariance estimators of tier4 ndt_omp [RECALLED] on top of it: MULTI_NDT (re-align
+    from every search pose) and MULTI_NDT_SCORE (NVTL softmax) against a NumPy restatement that
+    uses the ORACLE for the re-alignments / scores."""
+    cfg = S.config_c2()
+    ndt = _ndt(pkg)
+    ndt.setInputTarget(cfg["target"])
+    ndt.setInputSource(cfg["source"])
+    T = ndt.align(cfg["guess"])
+    main = ndt.getResult()
+    lap = pkg.xy_covariance_laplace(main["hessian"])
+    np.testing.assert_allclose(lap, -np.linalg.inv(main["hessian"][:2, :2]), rtol=1e-10)
+    assert np.all(np.linalg.eigvalsh(lap) > 0)
+    ox = [0.0, 0.0, 0.5, -0.5, 1.0, -1.0]
+    oy = [0.5, -0.5, 0.0, 0.0, 0.0, 0.0]
+    poses = ndt.proposePosesToSearch(ox, oy)
+    n0 = ndt.getTiming()["n_eval_launches"]
+    batch = ndt.scoreTransforms(poses)
+    assert ndt.getTiming()["n_eval_launches"] == n0 + 1
+    for P, b in zip(poses, batch):
+        one = ndt.scoreTransform(P)
+        assert one["score"] == b["score"] and one["nvtl"] == b["nvtl"] and one["n_pairs"] == b["n_pairs"]
+    # MULTI_NDT_SCORE
+    temperature = 0.05
+    mean_s, cov_s = ndt.estimateXYCovarianceMultiNdtScore(poses, temperature)
+    grid = O.Grid(cfg["target"], O.default_params(num_threads=8, **KW))
+    pts = [T[:2, 3]] + [P[:2, 3] for P in poses]
+    sc = [main["nvtl"]]
+    for P in poses:
+        d = grid.derivatives(cfg["source"], O.matrix_to_pose(P), T=P, compute_hessian=False)
+        sc.append(d["nvtl_sum"] / d["n_with_neighbors"])
+    w = np.exp((np.array(sc) - max(sc)) / temperature); w /= w.sum()
+    m = sum(wi * p for wi, p in zip(w, pts))
+    c = sum(wi * np.outer(p - m, p - m) for wi, p in zip(w, pts))
+    np.testing.assert_allclose(mean_s, m, atol=1e-6)
+    np.testing.assert_allclose(cov_s, c, rtol=1e-4, atol=1e-9)
+    # MULTI_NDT
+    mean_m, cov_m = ndt.estimateXYCovarianceMultiNdt(poses)
+    pts = [T[:2, 3]]
+    for P in poses:
+        r = grid.align(cfg["source"], P)
+        pts.append(r["T"][:2, 3])
+    pts = np.array(pts)
+    np.testing.assert_allclose(mean_m, pts.mean(0), atol=1e-3)
+    cm = np.cov(pts.T, ddof=1)
+    assert np.abs(cov_m - cm).max() < 1e-6 + 0.2 * np.abs(cm).max()   # re-alignments end within 1 mm of the oracle's
+    assert np.all(np.linalg.eigvalsh(cov_m) >= -1e-12)
