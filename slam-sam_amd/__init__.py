@@ -204,6 +204,7 @@ def lib():
         L.ndt_xy_covariance_multi_ndt.argtypes = [vp, C.POINTER(Result), fp, C.c_int, dp, dp]
         L.ndt_xy_covariance_multi_ndt_score.argtypes = [vp, C.POINTER(Result), fp, C.c_int, C.c_double, dp, dp]
         L.ndt_debug_prelaunch_counters.argtypes = [vp, C.POINTER(C.c_int64)]  # test seam, not in the header
+        L.ndt_debug_build_counters.argtypes = [vp, C.POINTER(C.c_int64)]  # test seam, not in the header
         L.ndt_debug_sort_pairs.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, vp]  # test seam, not in the header
         _lib = L
     return _lib
@@ -568,6 +569,12 @@ class NormalDistributionsTransform:
         """(evaluations served by a pre-launched kernel, pre-launched kernels told to leave, time-outs)."""
         out = (C.c_int64 * 3)()
         self._check(lib().ndt_debug_prelaunch_counters(self._h, out))
+        return tuple(out)
+
+    def buildCounters(self):
+        """(builds that fell back from the fused sort passes to the classic ones,)."""
+        out = (C.c_int64 * 1)()
+        self._check(lib().ndt_debug_build_counters(self._h, out))
         return tuple(out)
 
     def getTiming(self):

@@ -86,7 +86,13 @@ struct ndt_handle {
   DevBuf<uint32_t> keys, vals, keys2, vals2;
   DevBuf<char> sort_tmp;
   DevBuf<int> nleaf;                 // [0] slots, [1] valid
-  DevBuf<int> leaf_start, leaf_cnt, run_counts, run_offsets;
+  DevBuf<int> leaf_start, leaf_cnt, run_counts, run_offsets, fin_counts;
+  DevBuf<uint32_t> sort_tags;         // tagged tile counts of the fused sort passes
+  uint32_t sort_seq = 0;              // ... and their launch tag counter
+  DevBuf<uint32_t> run_tags;          // tagged block leaf counts of the fused run search
+  uint32_t run_seq = 0;
+  long long n_fused_sort_fallbacks = 0;
+  int n_cus = 0;                      // compute units of the device (a fused sort pass needs one per tile)
   DevBuf<double> leaf_sums;
   DevBuf<int> brows;                 // per-block bounds rows
   DevBuf<unsigned int> tickets;      // [0] bounds, [1] run-count, [2] finalize kernel; zero between launches
@@ -302,11 +308,26 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
   HIP_TRY(h, h->leaf_sums.ensure((size_t)max_leaves * 9));
   HIP_TRY(h, h->run_counts.ensure((size_t)runs_blocks(n)));
   HIP_TRY(h, h->run_offsets.ensure((size_t)runs_blocks(n)));
+  HIP_TRY(h, h->fin_counts.ensure((size_t)finalize_blocks(max_leaves)));
   HIP_TRY(h, h->sort_tmp.ensure(sort_temp_bytes(n)));
+  // fused = launches that wait, inside the kernel, for sibling blocks (k_sort_pass, k_runs<RUNS_FUSED>)
+  bool fused = fused_build_enabled();
+  const bool fused_sort = fused && fused_sort_fits(n, h->n_cus);
+  if (fused_sort && !h->sort_tags.p) {
+    HIP_TRY(h, h->sort_tags.ensure(fused_table_words()));
+    HIP_TRY(h, hipMemsetAsync(h->sort_tags.p, 0, h->sort_tags.cap * sizeof(uint32_t), s));
+    h->sort_seq = 0;
+  }
+  if (fused && run_tag_words(n) > h->run_tags.cap) {
+    HIP_TRY(h, h->run_tags.ensure(run_tag_words(n)));
+    HIP_TRY(h, hipMemsetAsync(h->run_tags.p, 0, h->run_tags.cap * sizeof(uint32_t), s));
+    h->run_seq = 0;
+  }
 
   HIP_TRY(h, hipEventRecord(h->ev0, s));
-  for (int attempt = 0; attempt < 2; ++attempt) {
-    const bool optimistic = attempt == 0 && clean_cap != 0 && clean_cap == h->cell2leaf.cap;
+  bool built = false;
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    const bool optimistic = clean_cap != 0 && clean_cap == h->cell2leaf.cap;
     const long long lim = std::numeric_limits<int32_t>::max();
     const long long cap_cells = optimistic ? (long long)h->cell2leaf.cap : lim;
     int passes = optimistic ? sort_passes_for_cells(cap_cells) : 0;
@@ -325,16 +346,23 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
       HIP_TRY(h, hipMemsetAsync(h->cell2leaf.p, 0xFF, h->cell2leaf.cap * sizeof(int), s));
     }
     HIP_TRY(h, h->stats.ensure((size_t)max_leaves));
-    launch_cell_keys(x, y, z, n, h->gd.p, h->keys.p, h->xyz4.p, h->sort_tmp.p, s);
     bool in_b = false;
-    HIP_TRY(h, sort_pairs(h->sort_tmp.p, h->keys.p, h->keys2.p, h->vals.p, h->vals2.p, n, passes, h->gd.p, s, &in_b));
+    if (fused && fused_sort) {
+      HIP_TRY(h, sort_cloud_fused(x, y, z, n, h->gd.p, h->gdh.d, h->xyz4.p, h->keys.p, h->keys2.p, h->vals.p, h->vals2.p,
+                                  passes, h->sort_tags.p, &h->sort_seq, s, &in_b));
+    } else {
+      launch_cell_keys(x, y, z, n, h->gd.p, h->keys.p, h->xyz4.p, h->sort_tmp.p, s);
+      HIP_TRY(h, sort_pairs(h->sort_tmp.p, h->keys.p, h->keys2.p, h->vals.p, h->vals2.p, n, passes, h->gd.p, s, &in_b));
+    }
     const uint32_t* keys_sorted = in_b ? h->keys2.p : h->keys.p;
     const uint32_t* vals_sorted = in_b ? h->vals2.p : h->vals.p;
-    launch_find_runs(keys_sorted, n, h->gd.p, min_pts, h->nleaf.p, h->run_counts.p, h->run_offsets.p, h->tickets.p + 1,
-                     h->leaf_start.p, h->leaf_cnt.p, s);
+    HIP_TRY(h, launch_find_runs(keys_sorted, n, h->gd.p, h->gdh.d, min_pts, h->nleaf.p, h->run_counts.p, h->run_offsets.p,
+                                h->tickets.p + 1, fused ? h->run_tags.p : nullptr, h->run_tags.cap, &h->run_seq,
+                                h->leaf_start.p, h->leaf_cnt.p, s));
     FinalizeParams fp{h->prm.eig_inflation_ratio, h->prm.cov_mode};
     launch_finalize_leaves(h->xyz4.p, keys_sorted, vals_sorted, h->nleaf.p, h->leaf_start.p, h->leaf_cnt.p, max_leaves,
-                           fp, h->leaf_sums.p, h->rec.p, h->stats.p, h->cell2leaf.p, h->tickets.p + 2, h->small.d + 8, s);
+                           fp, h->leaf_sums.p, h->rec.p, h->stats.p, h->cell2leaf.p, h->fin_counts.p, h->tickets.p + 2,
+                           h->small.d + 8, s);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->ev1, s));
     HIP_TRY(h, hipStreamSynchronize(s));
@@ -346,13 +374,24 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
       dirty_slots = 0;
       continue;
     }
+    if (fused && bg.status == BG_SPIN) {
+      // a fused sort pass gave up waiting for its sibling blocks (the CUs were held by other
+      // work): no leaf was published and the old cells are already reset.  Once more with the
+      // classic three-launch passes, which never wait inside a kernel.
+      fused = false;
+      dirty_slots = 0;
+      ++h->n_fused_sort_fallbacks;
+      continue;
+    }
     if (bg.status == BG_NO_FINITE) return fail(h, NDT_ERR_NO_TARGET, "target has no finite point");
     if (bg.status != BG_OK)
       return fail(h, NDT_ERR_GRID_OVERFLOW, "leaf size too small for the target extent (index overflow)");
     h->geom = bg.g;
     for (int a = 0; a < 3; ++a) h->max_b[a] = bg.max_b[a];
+    built = true;
     break;
   }
+  if (!built) return fail(h, NDT_ERR_HIP, "voxel-grid build did not go through (internal)");
   float ms = 0;
   HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
   h->ms_build = ms;
@@ -722,6 +761,10 @@ int ndt_create(const ndt_params* p, ndt_handle** out) {
   ndt_handle* h = new ndt_handle();
   h->prm = prm;
   h->device = dev;
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) h->n_cus = cus;
+  }
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
       hipEventCreate(&h->ev2) != hipSuccess) {
@@ -741,7 +784,7 @@ int ndt_destroy(ndt_handle* h) {
   h->keys.release(); h->vals.release(); h->keys2.release(); h->vals2.release();
   h->sort_tmp.release(); h->nleaf.release(); h->leaf_start.release(); h->leaf_cnt.release();
   h->cell2leaf.release(); h->rec.release(); h->stats.release();
-  h->run_counts.release(); h->run_offsets.release(); h->xyz4.release(); h->leaf_sums.release();
+  h->run_counts.release(); h->run_offsets.release(); h->fin_counts.release(); h->sort_tags.release(); h->run_tags.release(); h->xyz4.release(); h->leaf_sums.release();
   h->brows.release(); h->tickets.release(); h->gd.release(); h->gdh.release();
   for (auto& kv : h->keyframes) { kv.second.x.release(); kv.second.y.release(); kv.second.z.release(); }
   h->keyframes.clear();
@@ -1273,8 +1316,17 @@ int ndt_debug_prelaunch_counters(const ndt_handle* h, int64_t out[3]) {
   return NDT_OK;
 }
 
+// test seam (not in the public header): builds that fell back from the fused sort passes to the
+// classic ones after a block gave up waiting
+int ndt_debug_build_counters(const ndt_handle* h, int64_t out[1]) {
+  if (!h || !out) return NDT_ERR_INVALID_ARG;
+  out[0] = h->n_fused_sort_fallbacks;
+  return NDT_OK;
+}
+
 // diagnostic builds only (-DNDT_STAMPS): 8 x 100 MHz stamps per block of the last launch
 int ndt_debug_read_stamps(unsigned long long* out, int nblocks) { return derivs_read_stamps(out, nblocks); }
+int ndt_debug_read_build_stamps(unsigned long long* out) { return build_read_stamps(out); }
 
 // test seam (not in the public header): the voxel build's radix sort on caller-supplied keys;
 // vals_out receives the stable sorting permutation.  Host arrays.

@@ -36,23 +36,39 @@ hipError_t sort_pairs(void* temp, uint32_t* keys_a, uint32_t* keys_b, uint32_t* 
 void fill_sort_plan(BuildGeom* b, int end_bit);
 void launch_sort_first_count(const uint32_t* keys, size_t n, const BuildGeom* gd, void* sort_temp, hipStream_t s);
 
+// One launch per digit, straight from the cloud (no launch_cell_keys): see k_sort_pass.  Only for
+// clouds with fused_sort_fits(n, CUs of the device); `table`: fused_table_words() words, zero at allocation; a build
+// that had to give up waiting leaves BG_SPIN in *gd / *gd_host (repeat it with the classic passes).
+bool fused_build_enabled();  // NDT_FUSED_SORT != 0 (default): fused sort passes and the fused run search
+bool fused_sort_fits(size_t n, int compute_units);
+size_t fused_table_words();
+hipError_t sort_cloud_fused(const float* x, const float* y, const float* z, size_t n, BuildGeom* gd, BuildGeom* gd_host,
+                            float* xyz4, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
+                            int passes, uint32_t* table, uint32_t* seq, hipStream_t s, bool* result_in_b);
+
 // runs of equal cell key with >= min_pts points get a leaf slot (ascending cell order);
 // block_counts / block_offsets: runs_blocks(n) ints each; d_nleaf[0] receives the total
 // (count pass; its last block also scans the counts); *ticket as above
 int runs_blocks(size_t n);
-void launch_find_runs(const uint32_t* keys_sorted, size_t n, const BuildGeom* gd, int min_pts, int* d_nleaf,
-                      int* block_counts, int* block_offsets, unsigned int* ticket, int* leaf_start, int* leaf_cnt,
-                      hipStream_t s);
+// run_tags != nullptr (run_tag_words(n) words, zero at allocation; *seq its tag counter): count and
+// emit in ONE launch; a block that had to give up waiting leaves BG_SPIN in *gd / *gd_host
+size_t run_tag_words(size_t n);
+hipError_t launch_find_runs(const uint32_t* keys_sorted, size_t n, BuildGeom* gd, BuildGeom* gd_host, int min_pts,
+                            int* d_nleaf, int* block_counts, int* block_offsets, unsigned int* ticket, uint32_t* run_tags,
+                            size_t run_tags_cap, uint32_t* seq, int* leaf_start, int* leaf_cnt, hipStream_t s);
 
 struct FinalizeParams {
   double eig_ratio;
   int cov_mode;  // 0 svn, 1 pcl (recalled)
 };
+int finalize_blocks(int max_leaves);
+int build_read_stamps(unsigned long long* out /* 4 x 512 x 8 */);  // -DNDT_STAMPS builds only; else 0
 // per-leaf sums, then per-leaf statistics; sums: 9 doubles per leaf slot (scratch)
 void launch_finalize_leaves(const float* xyz4, const uint32_t* keys_sorted, const uint32_t* vals_sorted,
                             int* d_nleaf /* [0]=slots, [1]=valid */, const int* leaf_start, const int* leaf_cnt,
                             int max_leaves, FinalizeParams fp, double* sums, VoxelRecord* rec, LeafStats* stats,
-                            int* cell2leaf, unsigned int* ticket /* zero, left at zero */,
+                            int* cell2leaf, int* block_ok /* finalize_blocks(max_leaves) ints, scratch */,
+                            unsigned int* ticket /* zero, left at zero */,
                             int* nleaf_host /* pinned: receives d_nleaf[0..1] */, hipStream_t s);
 
 // out[i] = (float)(R x + t) in f64 (sliding-window target assembly); out arrays hold n floats

@@ -24,6 +24,7 @@
 #include "ndt_kernels.h"
 
 #include <climits>
+#include <cstdlib>
 #include <cstring>
 
 namespace ndt {
@@ -40,6 +41,19 @@ __device__ __forceinline__ bool finite3(float a, float b, float c) {
 }
 
 constexpr int BOUNDS_BLOCKS = 512;
+
+#ifdef NDT_STAMPS
+// diagnostic build only: 100 MHz wall-clock stamps of thread 0 of every block of the fused build
+// kernels (slot 0-2: sort pass 0-2, 3: run search), written to a side buffer no other code reads
+__device__ unsigned long long g_bstamps[4 * 512 * 8];
+#define NDT_BSTAMP(slot, k)                                                                  \
+  do {                                                                                       \
+    if (threadIdx.x == 0 && blockIdx.x < 512)                                                \
+      g_bstamps[((slot) * 512 + blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memrealtime();   \
+  } while (0)
+#else
+#define NDT_BSTAMP(slot, k) do { } while (0)
+#endif
 
 __device__ __forceinline__ float decode_ordered_dev(int enc) {
   return __int_as_float(enc >= 0 ? enc : enc ^ 0x7fffffff);
@@ -134,6 +148,7 @@ __device__ void derive_geometry(const int mnmx[6], int n_finite, float leaf, flo
 // last ticket folds the <= 512 rows, derives the geometry and zeroes the leaf counters; every
 // block also resets its share of the cells the PREVIOUS build published (the dense grid is
 // filled with -1 once per allocation, not per build).
+template <int U>
 __global__ void __launch_bounds__(256) k_bounds(const float* __restrict__ x, const float* __restrict__ y,
                                                const float* __restrict__ z, size_t n, int* __restrict__ rows,
                                                unsigned int* __restrict__ ticket, float leaf, float inv_leaf,
@@ -151,17 +166,17 @@ __global__ void __launch_bounds__(256) k_bounds(const float* __restrict__ x, con
   int mx[3] = {INT_MIN, INT_MIN, INT_MIN};
   int cnt = 0;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  // four strided points per trip: 12 loads in flight instead of 3 (the pass is latency-bound)
-  for (size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 4 * stride) {
-    float a[4], b[4], c[4];
+  // U strided points per trip: 3 U loads in flight instead of 3 (the pass is latency-bound)
+  for (size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += U * stride) {
+    float a[U], b[U], c[U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const size_t i = i0 + u * stride;
       const size_t j = i < n ? i : i0;
       a[u] = x[j]; b[u] = y[j]; c[u] = z[j];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       if (i0 + u * stride >= n || !finite3(a[u], b[u], c[u])) continue;
       int ea = encode_ordered(a[u]), eb = encode_ordered(b[u]), ec = encode_ordered(c[u]);
       mn[0] = min(mn[0], ea); mx[0] = max(mx[0], ea);
@@ -447,8 +462,235 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_scatter(const uint32_t* _
   }
 }
 
-// Runs of equal cell key in the sorted array.  A thread owns RUN_KEYS consecutive keys (two
-// 16-byte loads), a block one 2048-key tile.  Every run TAIL needs its head: the thread's
+// ---- one launch per digit ("fused pass") -------------------------------------------------
+// count + scan + scatter of a digit in ONE launch (three launches at a 4-5 us floor each before):
+// a block ranks its tile, publishes the tile's 256 digit counts as self-validating words
+// {16-bit launch tag | 16-bit count} with agent-scope stores, and then reads the WHOLE
+// tiles x 256 table back with agent-scope loads, re-reading any word whose tag is not this
+// launch's yet: the column sum over all tiles gives the digit totals, the part of it over the
+// tiles before its own the digit's offset.  No scan kernel, no look-back chain (every block does
+// the same fixed amount of reading), no atomics, and the outcome does not depend on arrival
+// order.  The table read grows with tiles^2, so the tile is 8192 pairs (1024 threads, wave w owns
+// the contiguous 512 pairs [w*512, (w+1)*512) in 8 rounds of 64, so tile order is (wave, round,
+// lane) as in the classic pass): 123 tiles x 1 KB for 1M points.  Every block waits for every
+// other one, so all of them must be resident at once: the host uses this path for at most
+// FUSED_MAX_TILES tiles (one block per CU) and the classic three-launch pass beyond.  A block that
+// has waited FUSED_TIMEOUT_TICKS (other work holding the CUs) gives up: it marks the build
+// BG_SPIN in *gd and *gd_host, every later build kernel returns at once, and the host repeats the
+// build with classic passes.
+constexpr int FUSED_THREADS = 1024;
+constexpr int FUSED_WAVES = FUSED_THREADS / 64;
+constexpr int FUSED_TILE = FUSED_THREADS * SORT_ROUNDS;
+constexpr int FUSED_MAX_TILES = 256;
+constexpr int FUSED_COLS = FUSED_THREADS / 64;  // tile rows read per trip (one per wave)
+constexpr unsigned long long FUSED_TIMEOUT_TICKS = 5000000ull;  // 50 ms of the 100 MHz clock
+
+__device__ __forceinline__ int fused_index(int tile, int wave, int round, int lane) {
+  return tile * FUSED_TILE + wave * (FUSED_TILE / FUSED_WAVES) + round * 64 + lane;
+}
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+// FROM_POINTS: pass 0 straight from the cloud -- the cell key is computed here (k_cell_keys is
+// not launched), the packed float4 copy is written, and the values are the identity permutation.
+template <bool FROM_POINTS>
+__global__ void __launch_bounds__(FUSED_THREADS) k_sort_pass(const float* __restrict__ x, const float* __restrict__ y,
+                                                            const float* __restrict__ z, float4* __restrict__ xyz4,
+                                                            const uint32_t* __restrict__ keys_in,
+                                                            const uint32_t* __restrict__ vals_in, int n, int pass,
+                                                            BuildGeom* __restrict__ gd, BuildGeom* __restrict__ gd_host,
+                                                            int ntiles, uint32_t* __restrict__ table, uint32_t tag,
+                                                            int mute_tile /* test seam: this tile never publishes */,
+                                                            uint32_t* __restrict__ keys_out,
+                                                            uint32_t* __restrict__ vals_out) {
+  __shared__ int cnt[FUSED_WAVES][SORT_BINS];
+  // the column partial sums, and later -- once they have been folded -- the tile in sorted order
+  __shared__ uint32_t scratch[2 * FUSED_TILE];
+  int (*part_total)[SORT_BINS] = reinterpret_cast<int (*)[SORT_BINS]>(scratch);
+  int (*part_before)[SORT_BINS] = reinterpret_cast<int (*)[SORT_BINS]>(scratch + FUSED_COLS * SORT_BINS);
+  uint32_t* stage_k = scratch;
+  uint32_t* stage_v = scratch + FUSED_TILE;
+  __shared__ int gbase[SORT_BINS];
+  __shared__ int lbase[SORT_BINS];
+  __shared__ int wsum[2 * SORT_BINS / 64];
+  __shared__ int s_fail;
+  if (gd->status != BG_OK) return;  // uniform over the grid: no block waits for one that left here
+  const int shift = gd->shift[pass];
+  const uint32_t digit_mask = (1u << gd->width[pass]) - 1u;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = blockIdx.x;
+  NDT_BSTAMP(pass, 0);
+  uint32_t key[SORT_ROUNDS], val[SORT_ROUNDS];
+  int rank[SORT_ROUNDS];
+  if (FROM_POINTS) {
+    const GridGeom g = gd->g;
+    float a[SORT_ROUNDS], b[SORT_ROUNDS], c[SORT_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < SORT_ROUNDS; ++r) {  // all loads of the tile in flight before any use
+      const int i = fused_index(tile, wave, r, lane);
+      const int j = i < n ? i : 0;
+      a[r] = x[j]; b[r] = y[j]; c[r] = z[j];
+    }
+#pragma unroll
+    for (int r = 0; r < SORT_ROUNDS; ++r) {
+      const int i = fused_index(tile, wave, r, lane);
+      key[r] = (uint32_t)g.ncells;  // sentinel sorts behind every real cell
+      val[r] = (uint32_t)i;
+      if (i < n) {
+        xyz4[i] = make_float4(a[r], b[r], c[r], 0.0f);  // one 16-byte line per point for the per-voxel gather
+        if (finite3(a[r], b[r], c[r])) {
+          const int idx = cell_of(a[r], b[r], c[r], g);
+          if (idx >= 0 && idx < g.ncells) key[r] = (uint32_t)idx;
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < SORT_ROUNDS; ++r) {
+      const int i = fused_index(tile, wave, r, lane);
+      key[r] = i < n ? keys_in[i] : 0u;
+      val[r] = i < n ? vals_in[i] : 0u;
+    }
+  }
+  for (int d = threadIdx.x; d < FUSED_WAVES * SORT_BINS; d += FUSED_THREADS) (&cnt[0][0])[d] = 0;
+  if (threadIdx.x == 0) s_fail = 0;
+  __syncthreads();
+  NDT_BSTAMP(pass, 1);  // keys in registers (thread 0's at least: its loads were consumed)
+  // (Publishing the tile counts BEFORE the ranking, from an LDS-atomic histogram, was tried so that
+  // the table would be complete by the time the ranks are: the atomics of a wave whose 64 pairs
+  // share a digit serialise -- +0.9 / +3.8 / +6.2 us on the three passes of C3, whose top digit is
+  // nearly constant -- against 1.2 us saved.  profiles/r02_build_stamps_early_publish.txt)
+  // rank among the equal digits before it in the wave's 512 pairs (8 ballots per round)
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int r = 0; r < SORT_ROUNDS; ++r) {
+    const bool valid = fused_index(tile, wave, r, lane) < n;
+    const uint32_t d = (key[r] >> shift) & digit_mask;
+    unsigned long long same = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const unsigned long long bal = __ballot(bit);
+      same &= bit ? bal : ~bal;
+    }
+    const int before = cnt[wave][d];
+    const int lower = __popcll(same & lt_mask);
+    rank[r] = before + lower;
+    __builtin_amdgcn_wave_barrier();
+    if (valid && lower == 0) cnt[wave][d] = before + __popcll(same);
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  NDT_BSTAMP(pass, 2);  // ranked
+  // per-digit: waves -> exclusive prefix inside the tile, tile count published
+  int my_count = 0;  // digit threadIdx.x in this tile
+  if (threadIdx.x < SORT_BINS) {
+    int run = 0;
+#pragma unroll
+    for (int w = 0; w < FUSED_WAVES; ++w) {
+      const int t = cnt[w][threadIdx.x];
+      cnt[w][threadIdx.x] = run;
+      run += t;
+    }
+    my_count = run;
+    if (tile != mute_tile)
+      __hip_atomic_store(table + (size_t)tile * SORT_BINS + threadIdx.x, (tag << 16) | (uint32_t)run, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // the whole table, 16 bytes (four digits) per lane and one tile row per wave and trip
+  {
+    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(table, 0, 0xFFFFFFFFu, 0x00020000);
+    int tot[4] = {0, 0, 0, 0}, bef[4] = {0, 0, 0, 0};
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    constexpr int BATCH = 8;
+    for (int r0 = wave; r0 < ntiles; r0 += BATCH * FUSED_COLS) {
+      u32x4_t w[BATCH];
+      for (;;) {
+        asm volatile("" ::: "memory");  // the loads below must be re-issued on every trip
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+          const int row = r0 + k * FUSED_COLS;
+          if (row < ntiles)
+            w[k] = __builtin_amdgcn_raw_buffer_load_b128(rt, ((unsigned int)row * SORT_BINS + 4u * lane) * 4u, 0, 16 /* sc1 */);
+          else
+            w[k].x = w[k].y = w[k].z = w[k].w = tag << 16;
+        }
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k)
+          ok = ok && (w[k].x >> 16) == tag && (w[k].y >> 16) == tag && (w[k].z >> 16) == tag && (w[k].w >> 16) == tag;
+        if (ok) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > FUSED_TIMEOUT_TICKS) { s_fail = 1; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+#pragma unroll
+      for (int k = 0; k < BATCH; ++k) {
+        const int row = r0 + k * FUSED_COLS;
+        const int c0 = w[k].x & 0xffff, c1 = w[k].y & 0xffff, c2 = w[k].z & 0xffff, c3 = w[k].w & 0xffff;
+        tot[0] += c0; tot[1] += c1; tot[2] += c2; tot[3] += c3;
+        if (row < tile) { bef[0] += c0; bef[1] += c1; bef[2] += c2; bef[3] += c3; }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { part_total[wave][4 * lane + q] = tot[q]; part_before[wave][4 * lane + q] = bef[q]; }
+  }
+  __syncthreads();
+  NDT_BSTAMP(pass, 3);  // table read
+  if (s_fail) {
+    if (threadIdx.x == 0) { gd->status = BG_SPIN; gd_host->status = BG_SPIN; }
+    return;
+  }
+  int g_excl = 0, l_excl = 0;  // digit threadIdx.x: first output slot over all tiles / inside this tile
+  if (threadIdx.x < SORT_BINS) {
+    int t = 0, b = 0;
+#pragma unroll
+    for (int c = 0; c < FUSED_COLS; ++c) { t += part_total[c][threadIdx.x]; b += part_before[c][threadIdx.x]; }
+    const int incl = wave_inclusive_scan(t, lane);
+    const int lincl = wave_inclusive_scan(my_count, lane);
+    if (lane == 63) { wsum[wave] = incl; wsum[4 + wave] = lincl; }
+    g_excl = incl - t + b;
+    l_excl = lincl - my_count;
+  }
+  __syncthreads();  // part_total / part_before are dead from here on: `scratch` becomes the staging tile
+  if (threadIdx.x < SORT_BINS) {
+    int before = 0, lbefore = 0;
+    for (int w = 0; w < wave; ++w) { before += wsum[w]; lbefore += wsum[4 + w]; }
+    gbase[threadIdx.x] = before + g_excl;
+    lbase[threadIdx.x] = lbefore + l_excl;
+  }
+  __syncthreads();
+  // the tile in sorted order through LDS, so that the global stores of a wave fall into a few
+  // contiguous runs instead of 64 separate places (a scattered wave store occupies the address
+  // path for 64 cycles; 256 of them per CU were 7 us of a 16 us launch)
+#pragma unroll
+  for (int r = 0; r < SORT_ROUNDS; ++r) {
+    if (fused_index(tile, wave, r, lane) >= n) break;
+    const uint32_t d = (key[r] >> shift) & digit_mask;
+    const int p = lbase[d] + cnt[wave][d] + rank[r];
+    stage_k[p] = key[r];
+    stage_v[p] = val[r];
+  }
+  __syncthreads();
+  NDT_BSTAMP(pass, 4);  // staged
+  const int tile_n = min(FUSED_TILE, n - tile * FUSED_TILE);
+#pragma unroll
+  for (int r = 0; r < SORT_ROUNDS; ++r) {
+    const int j = r * FUSED_THREADS + (int)threadIdx.x;
+    if (j >= tile_n) break;
+    const uint32_t k = stage_k[j];
+    const uint32_t d = (k >> shift) & digit_mask;
+    const int pos = gbase[d] + (j - lbase[d]);
+    keys_out[pos] = k;
+    vals_out[pos] = stage_v[j];
+  }
+#ifdef NDT_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);
+  NDT_BSTAMP(pass, 5);  // thread 0's stores acknowledged
+#endif
+}
+
+// Runs of equal cell key in the sorted array.  A thread owns RUN_KEYS consecutive keys (16-byte
+// loads), a block one tile of 256 * RUN_KEYS keys.  Every run TAIL needs its head: the thread's
 // own last head, else the last head of a lower lane (wave max-scan), else of a lower wave
 // (LDS), and only for a run that began before the tile a backward gallop + bisection in
 // global memory.  Runs with at least min_pts points become leaves
@@ -456,31 +698,72 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_scatter(const uint32_t* _
 // count / scan / emit triple instead of a global atomic counter (one contended address
 // served ~90 adds/us and cost 0.1 ms): slots come out in ascending cell order, identically
 // on every run.
-constexpr int RUN_KEYS = 8;
-constexpr int RUN_TILE = 256 * RUN_KEYS;
 
-template <bool EMIT>
+// KEYS consecutive keys per thread (8 or 16): the count launch pays one ticket per block, and a
+// contended ticket is served at ~12 ns, so fewer, fatter blocks are cheaper (489 -> 245 for 1M).
+// MODE 0 / 1: the count launch and the emit launch of the classic pair.  MODE 2: both in ONE
+// launch -- a block publishes its leaf count as a self-validating word {16-bit launch tag | count}
+// and adds up the words of the blocks BEFORE it, re-reading any that is not tagged yet.  A block
+// only ever waits for lower-numbered blocks, which were dispatched before it, so this needs no
+// co-residency; the time-out (BG_SPIN, as in k_sort_pass) is a second line of defence.
+constexpr int RUNS_COUNT = 0, RUNS_EMIT = 1, RUNS_FUSED = 2;
+template <int MODE, int RUN_KEYS>
 __global__ void __launch_bounds__(256) k_runs(const uint32_t* __restrict__ keys, int n,
-                                             const BuildGeom* __restrict__ gd, int min_pts,
+                                             BuildGeom* __restrict__ gd, BuildGeom* __restrict__ gd_host, int min_pts,
                                              int* __restrict__ block_counts, int* __restrict__ block_offsets,
-                                             unsigned int* __restrict__ ticket, int* __restrict__ nleaf_out,
+                                             unsigned int* __restrict__ ticket, uint32_t* __restrict__ run_tags,
+                                             uint32_t tag, int* __restrict__ nleaf_out,
                                              int* __restrict__ leaf_start, int* __restrict__ leaf_cnt) {
+  constexpr bool EMIT = MODE != RUNS_COUNT;
   __shared__ int wave_head[4];
   __shared__ int wave_total[4];
   __shared__ int s_last;
+  __shared__ int s_head0;
+  constexpr int RUN_TILE = 256 * RUN_KEYS;
   if (gd->status != BG_OK) return;
+  NDT_BSTAMP(3, 0);
   const int ncells = gd->g.ncells;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int s0 = blockIdx.x * RUN_TILE + threadIdx.x * RUN_KEYS;
   const uint32_t sentinel = 0xFFFFFFFFu;
   uint32_t k[RUN_KEYS];
   if (s0 + RUN_KEYS <= n) {  // keys is 16-byte aligned and s0 a multiple of 8
-    const uint4 a = *reinterpret_cast<const uint4*>(keys + s0);
-    const uint4 b = *reinterpret_cast<const uint4*>(keys + s0 + 4);
-    k[0] = a.x; k[1] = a.y; k[2] = a.z; k[3] = a.w; k[4] = b.x; k[5] = b.y; k[6] = b.z; k[7] = b.w;
+#pragma unroll
+    for (int q = 0; q < RUN_KEYS / 4; ++q) {
+      const uint4 a = *reinterpret_cast<const uint4*>(keys + s0 + 4 * q);
+      k[4 * q + 0] = a.x; k[4 * q + 1] = a.y; k[4 * q + 2] = a.z; k[4 * q + 3] = a.w;
+    }
   } else {
 #pragma unroll
     for (int j = 0; j < RUN_KEYS; ++j) k[j] = s0 + j < n ? keys[s0 + j] : sentinel;
+  }
+  // At most one run of the tile began before it: the one that holds the tile's first key.  Wave 0
+  // finds its head with two 64-wide probes per 4096 keys of run length (a gallop + bisection by the
+  // one lane that owns the tail was ~20 dependent loads for the map's most crowded voxel, and that
+  // straggler set the launch's duration: 10.6 us against a median block's 4.3).
+  if (wave == 0) {
+    const int b = blockIdx.x * RUN_TILE;
+    int head0 = b;
+    if (b > 0 && b < n) {
+      const uint32_t K0 = keys[b];
+      if (K0 < (uint32_t)ncells && keys[b - 1] == K0) {
+        int hi = b;  // holds K0
+        for (;;) {
+          const long long jc = (long long)hi - (long long)(lane + 1) * 64;
+          const bool differs = jc < 0 || keys[jc] != K0;
+          const unsigned long long m = __ballot(differs);
+          if (m == 0ull) { hi -= 64 * 64; continue; }  // all 64 probes still in the run: further back
+          const int l = __ffsll((long long)m) - 1;      // nearest probe outside the run
+          const int lo_excl = hi - (l + 1) * 64;        // outside (or < 0); lo_excl + 64 is inside
+          const int jf = lo_excl + 1 + lane;
+          const bool inside = jf >= 0 && keys[jf] == K0;
+          const unsigned long long m2 = __ballot(inside);
+          head0 = lo_excl + 1 + (__ffsll((long long)m2) - 1);
+          break;
+        }
+      }
+    }
+    if (lane == 0) s_head0 = head0;
   }
   uint32_t prev = __shfl_up(k[RUN_KEYS - 1], 1), next = __shfl_down(k[0], 1);
   if (lane == 0) prev = s0 > 0 && s0 - 1 < n ? keys[s0 - 1] : sentinel;
@@ -522,23 +805,7 @@ __global__ void __launch_bounds__(256) k_runs(const uint32_t* __restrict__ keys,
     starts[j] = 0;
     if (tail) {
       int start = cur_head;
-      if (start < 0) {
-        // the run began before this tile: keys[tile_base] == key; walk back
-        int hi = blockIdx.x * RUN_TILE;  // known to hold key
-        int step = 1, lo;
-        for (;;) {
-          int nx = hi - step;
-          if (nx < 0) { lo = -1; break; }
-          if (keys[nx] != k[j]) { lo = nx; break; }
-          hi = nx;
-          step <<= 1;
-        }
-        while (hi - lo > 1) {  // keys[lo] != key (or lo == -1), keys[hi] == key
-          int mid = (lo + hi) >> 1;
-          if (keys[mid] == k[j]) hi = mid; else lo = mid;
-        }
-        start = hi;
-      }
+      if (start < 0) start = s_head0;  // the run began before this tile: it is the tile's carry-in run
       const int cnt = s - start + 1;
       if (cnt >= min_pts) {
         starts[j] = start;
@@ -595,8 +862,59 @@ __global__ void __launch_bounds__(256) k_runs(const uint32_t* __restrict__ keys,
     }
     return;
   }
+  int block_off;
+  NDT_BSTAMP(3, 1);  // counted
+  if (MODE == RUNS_FUSED) {
+    __shared__ int red[4];
+    __shared__ int s_fail;
+    const int mine = wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3];
+    if (threadIdx.x == 0) {
+      s_fail = 0;
+      __hip_atomic_store(run_tags + blockIdx.x, (tag << 16) | (uint32_t)mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    int acc = 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    constexpr int POLL_BATCH = 8;  // words of a thread in flight together (one memory round trip for 2048 blocks)
+    for (int i0 = threadIdx.x; i0 < (int)blockIdx.x; i0 += 256 * POLL_BATCH) {
+      uint32_t w[POLL_BATCH];
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int u = 0; u < POLL_BATCH; ++u) {
+          const int i = i0 + 256 * u;
+          w[u] = i < (int)blockIdx.x ? __hip_atomic_load(run_tags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (tag << 16);
+        }
+#pragma unroll
+        for (int u = 0; u < POLL_BATCH; ++u) ok = ok && (w[u] >> 16) == tag;
+        if (ok) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > FUSED_TIMEOUT_TICKS) {
+          s_fail = 1;
+#pragma unroll
+          for (int u = 0; u < POLL_BATCH; ++u) w[u] = 0;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+#pragma unroll
+      for (int u = 0; u < POLL_BATCH; ++u) acc += (int)(w[u] & 0xffffu);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (s_fail) {
+      if (threadIdx.x == 0) { gd->status = BG_SPIN; gd_host->status = BG_SPIN; }
+      return;
+    }
+    block_off = red[0] + red[1] + red[2] + red[3];
+    NDT_BSTAMP(3, 2);  // offset known
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) nleaf_out[0] = block_off + mine;
+  } else {
+    block_off = block_offsets[blockIdx.x];
+  }
   if (nleaf == 0) return;
-  int slot = block_offsets[blockIdx.x] + lincl - nleaf;
+  int slot = block_off + lincl - nleaf;
   for (int w = 0; w < wave; ++w) slot += wave_total[w];
 #pragma unroll
   for (int j = 0; j < RUN_KEYS; ++j) {
@@ -606,6 +924,10 @@ __global__ void __launch_bounds__(256) k_runs(const uint32_t* __restrict__ keys,
       ++slot;
     }
   }
+#ifdef NDT_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);
+  NDT_BSTAMP(3, 3);
+#endif
 }
 
 // one Jacobi rotation of the symmetric 3x3 A (full storage) in the (P,Q) plane
@@ -681,48 +1003,73 @@ __device__ __forceinline__ void moments_xor_tree(Moments& m) {
   }
 }
 
-__device__ __forceinline__ void finalize_one(int slot, const uint32_t* __restrict__ keys, int* __restrict__ nleaf_p,
+__device__ __forceinline__ bool finalize_one(int slot, const uint32_t* __restrict__ keys,
                                              const int* __restrict__ leaf_start, const int* __restrict__ leaf_cnt,
                                              const double* __restrict__ sums, FinalizeParams fp,
                                              VoxelRecord* __restrict__ rec, LeafStats* __restrict__ stats,
                                              int* __restrict__ cell2leaf);
 
-// one-wave blocks: every lane's stores / atomics are acknowledged, then lane 0 takes the ticket
-__device__ __forceinline__ bool last_ticket_wave(unsigned int* ticket, unsigned int nblocks) {
-  int last = 0;
-  if ((threadIdx.x & 63) == 0) last = last_ticket(ticket, nblocks) ? 1 : 0;  // drains vmcnt first
-  else __builtin_amdgcn_s_waitcnt(0);
-  return __builtin_amdgcn_readfirstlane(last) != 0;
-}
-
 // ref: voxel_grid_covariance_impl.hpp:265-343 -- one thread per leaf: mean, covariance,
 // eigen-decomposition, eigenvalue inflation, inverse, validity checks.  (Fusing this into the
 // 8 lanes that sum a leaf was tried in round 2: 48 us against 20 + 12 -- the Jacobi state on top
 // of the moments spills, and 8 of 64 lanes do distinct work.)
-__global__ void __launch_bounds__(64) k_leaf_finalize(const uint32_t* __restrict__ keys,
-                                                      int* __restrict__ nleaf_p,
-                                                      const int* __restrict__ leaf_start,
-                                                      const int* __restrict__ leaf_cnt,
-                                                      const double* __restrict__ sums, FinalizeParams fp,
-                                                      VoxelRecord* __restrict__ rec, LeafStats* __restrict__ stats,
-                                                      int* __restrict__ cell2leaf, unsigned int* __restrict__ ticket,
-                                                      int* __restrict__ nleaf_host) {
-  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+// The number of accepted leaves is summed without atomics: a count per block, and the block that
+// draws the last ticket adds the counts and hands both leaf counters to the host through pinned
+// memory (the D2H copy they used to take was a 4.4 us launch of its own).  Contended adds on one
+// address are served at ~12 ns each, so the grid is as few blocks as the leaves need: with
+// 64-thread blocks and one atomicAdd per wave this kernel spent 327 tickets + 327 adds on 21 k leaves.
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) k_leaf_finalize(const uint32_t* __restrict__ keys,
+                                                           int* __restrict__ nleaf_p,
+                                                           const int* __restrict__ leaf_start,
+                                                           const int* __restrict__ leaf_cnt,
+                                                           const double* __restrict__ sums, FinalizeParams fp,
+                                                           VoxelRecord* __restrict__ rec,
+                                                           LeafStats* __restrict__ stats,
+                                                           int* __restrict__ cell2leaf, int* __restrict__ block_ok,
+                                                           unsigned int* __restrict__ ticket,
+                                                           int* __restrict__ nleaf_host) {
+  constexpr int WAVES = THREADS / 64;
+  __shared__ int s_ok[WAVES];
+  __shared__ int s_last;
+  const int slot = blockIdx.x * THREADS + threadIdx.x;
   const int nl = nleaf_p[0];
   // the grid is sized for the worst case (n / min_points leaves); only the blocks that hold a
-  // leaf -- block 0 always -- take part in the ticket (one contended address serves ~90 adds/us)
-  const int live_blocks = max(1, (nl + (int)blockDim.x - 1) / (int)blockDim.x);
+  // leaf -- block 0 always -- take part in the ticket
+  const int live_blocks = max(1, (nl + THREADS - 1) / THREADS);
   if ((int)blockIdx.x >= live_blocks) return;
-  if (slot < nl) finalize_one(slot, keys, nleaf_p, leaf_start, leaf_cnt, sums, fp, rec, stats, cell2leaf);
-  // the block (one wave) that draws the last ticket hands the two leaf counters to the host
-  // through pinned memory: the D2H copy they used to take was a 4.4 us launch of its own
-  if (last_ticket_wave(ticket, (unsigned int)live_blocks)) {
-    if (threadIdx.x < 2) nleaf_host[threadIdx.x] = ld_agent(nleaf_p + threadIdx.x);
-    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  bool ok = false;
+  if (slot < nl) ok = finalize_one(slot, keys, leaf_start, leaf_cnt, sums, fp, rec, stats, cell2leaf);
+  const int wave_ok = __popcll(__ballot(ok));
+  if ((threadIdx.x & 63) == 0) s_ok[threadIdx.x >> 6] = wave_ok;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) t += s_ok[w];
+    st_agent(block_ok + blockIdx.x, t);
+    s_last = last_ticket(ticket, (unsigned int)live_blocks) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  int sum = 0;
+  for (int i = threadIdx.x; i < live_blocks; i += THREADS) sum += ld_agent(block_ok + i);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+  if ((threadIdx.x & 63) == 0) s_ok[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int total = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) total += s_ok[w];
+    nleaf_p[1] = total;  // leaves that passed every check
+    nleaf_host[0] = nl;
+    nleaf_host[1] = total;
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
-__device__ __forceinline__ void finalize_one(int slot, const uint32_t* __restrict__ keys, int* __restrict__ nleaf_p,
+__device__ __forceinline__ bool finalize_one(int slot, const uint32_t* __restrict__ keys,
                                              const int* __restrict__ leaf_start, const int* __restrict__ leaf_cnt,
                                              const double* __restrict__ sums, FinalizeParams fp,
                                              VoxelRecord* __restrict__ rec, LeafStats* __restrict__ stats,
@@ -832,10 +1179,8 @@ __device__ __forceinline__ void finalize_one(int slot, const uint32_t* __restric
   r.icov[3] = ok ? I[4] : 0.0; r.icov[4] = ok ? I[5] : 0.0; r.icov[5] = ok ? I[8] : 0.0;
   r.pad = (double)cnt;
   rec[slot] = r;
-  if (ok) {
-    cell2leaf[cell] = slot;
-    atomicAdd(nleaf_p + 1, 1);  // leaves that passed every check
-  }
+  if (ok) cell2leaf[cell] = slot;
+  return ok;
 }
 
 __global__ void __launch_bounds__(256) k_leaf_sums(const float4* __restrict__ xyz4, const uint32_t* __restrict__ vals,
@@ -1084,9 +1429,36 @@ void launch_transform_append(const float* x, const float* y, const float* z, siz
                      ox, oy, oz);
 }
 
+// Launch shapes of the build kernels that end in a "last block finishes the job" ticket; the
+// environment overrides are A/B knobs (profiles/r02_build_tickets.txt).
+struct BuildTuning {
+  int bounds_blocks;     // NDT_BOUNDS_BLOCKS   (<= BOUNDS_BLOCKS)
+  int bounds_unroll;     // NDT_BOUNDS_UNROLL   4 | 8
+  int run_keys;          // NDT_RUN_KEYS        8 | 16 keys per thread in k_runs
+  int finalize_threads;  // NDT_FINALIZE_THREADS 64 | 256
+  int fused_sort;        // NDT_FUSED_SORT      0 | 1: one launch per sort digit where the cloud allows it
+};
+const BuildTuning& build_tuning() {
+  static const BuildTuning t = [] {
+    auto env = [](const char* name, int dflt) {
+      const char* e = getenv(name);
+      return e && *e ? atoi(e) : dflt;
+    };
+    BuildTuning b;
+    b.bounds_blocks = env("NDT_BOUNDS_BLOCKS", 256);
+    if (b.bounds_blocks < 1 || b.bounds_blocks > BOUNDS_BLOCKS) b.bounds_blocks = BOUNDS_BLOCKS;
+    b.bounds_unroll = env("NDT_BOUNDS_UNROLL", 8) == 4 ? 4 : 8;
+    b.run_keys = env("NDT_RUN_KEYS", 8) == 16 ? 16 : 8;
+    b.finalize_threads = env("NDT_FINALIZE_THREADS", 256) == 64 ? 64 : 256;
+    b.fused_sort = env("NDT_FUSED_SORT", 1) != 0 ? 1 : 0;
+    return b;
+  }();
+  return t;
+}
+
 int bounds_rows(size_t n) {
   size_t blocks = (n + 255) / 256;
-  if (blocks > (size_t)BOUNDS_BLOCKS) blocks = BOUNDS_BLOCKS;
+  if (blocks > (size_t)build_tuning().bounds_blocks) blocks = build_tuning().bounds_blocks;
   if (blocks < 1) blocks = 1;
   return (int)blocks;
 }
@@ -1101,8 +1473,14 @@ void launch_bounds_geometry(const float* x, const float* y, const float* z, size
                             long long cell_capacity, int planned_passes, int* rows, unsigned int* ticket,
                             BuildGeom* gd, BuildGeom* gd_host, const LeafStats* old_stats, int dirty_slots,
                             int* cell2leaf, size_t c2l_cap, int* d_nleaf, hipStream_t s) {
-  hipLaunchKernelGGL(k_bounds, dim3((unsigned)bounds_rows(n)), dim3(256), 0, s, x, y, z, n, rows, ticket, leaf, inv_leaf,
-                     cell_capacity, planned_passes, gd, gd_host, old_stats, dirty_slots, cell2leaf, c2l_cap, d_nleaf);
+  if (build_tuning().bounds_unroll == 8)
+    hipLaunchKernelGGL(k_bounds<8>, dim3((unsigned)bounds_rows(n)), dim3(256), 0, s, x, y, z, n, rows, ticket, leaf,
+                       inv_leaf, cell_capacity, planned_passes, gd, gd_host, old_stats, dirty_slots, cell2leaf, c2l_cap,
+                       d_nleaf);
+  else
+    hipLaunchKernelGGL(k_bounds<4>, dim3((unsigned)bounds_rows(n)), dim3(256), 0, s, x, y, z, n, rows, ticket, leaf,
+                       inv_leaf, cell_capacity, planned_passes, gd, gd_host, old_stats, dirty_slots, cell2leaf, c2l_cap,
+                       d_nleaf);
 }
 
 int sort_tiles(size_t n) { return (int)((n + SORT_TILE - 1) / SORT_TILE); }
@@ -1168,30 +1546,127 @@ hipError_t sort_pairs(void* temp, uint32_t* keys_a, uint32_t* keys_b, uint32_t* 
   return hipGetLastError();
 }
 
-int runs_blocks(size_t n) { return (int)((n + RUN_TILE - 1) / RUN_TILE); }
-
-void launch_find_runs(const uint32_t* keys_sorted, size_t n, const BuildGeom* gd, int min_pts, int* d_nleaf,
-                      int* block_counts, int* block_offsets, unsigned int* ticket, int* leaf_start, int* leaf_cnt,
-                      hipStream_t s) {
-  if (n == 0) return;
-  const int blocks = runs_blocks(n);
-  hipLaunchKernelGGL(k_runs<false>, dim3(blocks), dim3(256), 0, s, keys_sorted, (int)n, gd, min_pts, block_counts,
-                     block_offsets, ticket, d_nleaf, leaf_start, leaf_cnt);
-  hipLaunchKernelGGL(k_runs<true>, dim3(blocks), dim3(256), 0, s, keys_sorted, (int)n, gd, min_pts, block_counts,
-                     block_offsets, ticket, d_nleaf, leaf_start, leaf_cnt);
+// sized for the smaller tile, whatever the tuning
+// ---- fused passes (one launch per digit) ----
+int fused_tiles(size_t n) { return (int)((n + FUSED_TILE - 1) / FUSED_TILE); }
+bool fused_build_enabled() { return build_tuning().fused_sort != 0; }
+// every block of a fused pass waits for all the others: one tile per compute unit at most (a
+// partitioned device -- CPX mode: 32 CUs -- takes the classic passes for anything above 256 k points)
+bool fused_sort_fits(size_t n, int compute_units) {
+  return n > 0 && fused_tiles(n) <= FUSED_MAX_TILES && fused_tiles(n) <= compute_units;
 }
+size_t fused_table_words() { return (size_t)FUSED_MAX_TILES * SORT_BINS; }
+
+// Cell keys + stable sort by cell in `passes` launches, straight from the cloud.  `table`
+// (fused_table_words() words, zeroed at allocation and whenever *seq wraps) carries the tagged tile
+// counts; *seq is the engine's launch tag counter.  The result lands in (keys_b, vals_b) for an
+// odd number of passes, (keys_a, vals_a) otherwise.
+hipError_t sort_cloud_fused(const float* x, const float* y, const float* z, size_t n, BuildGeom* gd, BuildGeom* gd_host,
+                            float* xyz4, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
+                            int passes, uint32_t* table, uint32_t* seq, hipStream_t s, bool* result_in_b) {
+  *result_in_b = false;
+  if (n == 0) return hipSuccess;
+  const int ntiles = fused_tiles(n);
+  // test seam: NDT_DEBUG_FUSED_MUTE_TILE=<t> makes tile t withhold its counts, so every block times out
+  static const int mute_tile = [] { const char* e = getenv("NDT_DEBUG_FUSED_MUTE_TILE"); return e && *e ? atoi(e) : -1; }();
+  uint32_t *kin = keys_a, *kout = keys_b, *vin = vals_a, *vout = vals_b;
+  for (int p = 0; p < passes; ++p) {
+    uint32_t tag = (*seq + 1u) & 0xffffu;
+    if (tag == 0u) {  // wrapped: forget every old tag before tag 1 is handed out again
+      hipError_t e = hipMemsetAsync(table, 0, fused_table_words() * sizeof(uint32_t), s);
+      if (e != hipSuccess) return e;
+      tag = 1u;
+    }
+    *seq = tag;
+    if (p == 0) {
+      // pass 0 writes into the "a" buffers' partners so that the ping-pong below stays uniform
+      hipLaunchKernelGGL(k_sort_pass<true>, dim3((unsigned)ntiles), dim3(FUSED_THREADS), 0, s, x, y, z,
+                         reinterpret_cast<float4*>(xyz4), (const uint32_t*)nullptr, (const uint32_t*)nullptr, (int)n, p,
+                         gd, gd_host, ntiles, table, tag, mute_tile, kout, vout);
+    } else {
+      hipLaunchKernelGGL(k_sort_pass<false>, dim3((unsigned)ntiles), dim3(FUSED_THREADS), 0, s, (const float*)nullptr,
+                         (const float*)nullptr, (const float*)nullptr, (float4*)nullptr, kin, vin, (int)n, p, gd, gd_host,
+                         ntiles, table, tag, mute_tile, kout, vout);
+    }
+    uint32_t* t = kin; kin = kout; kout = t;
+    t = vin; vin = vout; vout = t;
+  }
+  *result_in_b = (passes & 1) != 0;
+  return hipGetLastError();
+}
+
+int runs_blocks(size_t n) { return (int)((n + 256 * 8 - 1) / (256 * 8)); }
+
+size_t run_tag_words(size_t n) { return (size_t)runs_blocks(n); }
+
+// run_tags != nullptr: count and emit in one launch (k_runs<RUNS_FUSED>); *seq is the tag counter of
+// that buffer (run_tag_words(n) words, zero at allocation)
+hipError_t launch_find_runs(const uint32_t* keys_sorted, size_t n, BuildGeom* gd, BuildGeom* gd_host, int min_pts,
+                            int* d_nleaf, int* block_counts, int* block_offsets, unsigned int* ticket, uint32_t* run_tags,
+                            size_t run_tags_cap, uint32_t* seq, int* leaf_start, int* leaf_cnt, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  uint32_t tag = 0;
+  if (run_tags) {
+    tag = (*seq + 1u) & 0xffffu;
+    if (tag == 0u) {
+      hipError_t e = hipMemsetAsync(run_tags, 0, run_tags_cap * sizeof(uint32_t), s);
+      if (e != hipSuccess) return e;
+      tag = 1u;
+    }
+    *seq = tag;
+  }
+  if (build_tuning().run_keys == 16) {
+    const int blocks = (int)((n + 256 * 16 - 1) / (256 * 16));
+    if (run_tags) {
+      hipLaunchKernelGGL((k_runs<RUNS_FUSED, 16>), dim3(blocks), dim3(256), 0, s, keys_sorted, (int)n, gd, gd_host, min_pts,
+                         block_counts, block_offsets, ticket, run_tags, tag, d_nleaf, leaf_start, leaf_cnt);
+    } else {
+      hipLaunchKernelGGL((k_runs<RUNS_COUNT, 16>), dim3(blocks), dim3(256), 0, s, keys_sorted, (int)n, gd, gd_host, min_pts,
+                         block_counts, block_offsets, ticket, run_tags, tag, d_nleaf, leaf_start, leaf_cnt);
+      hipLaunchKernelGGL((k_runs<RUNS_EMIT, 16>), dim3(blocks), dim3(256), 0, s, keys_sorted, (int)n, gd, gd_host, min_pts,
+                         block_counts, block_offsets, ticket, run_tags, tag, d_nleaf, leaf_start, leaf_cnt);
+    }
+  } else {
+    const int blocks = runs_blocks(n);
+    if (run_tags) {
+      hipLaunchKernelGGL((k_runs<RUNS_FUSED, 8>), dim3(blocks), dim3(256), 0, s, keys_sorted, (int)n, gd, gd_host, min_pts,
+                         block_counts, block_offsets, ticket, run_tags, tag, d_nleaf, leaf_start, leaf_cnt);
+    } else {
+      hipLaunchKernelGGL((k_runs<RUNS_COUNT, 8>), dim3(blocks), dim3(256), 0, s, keys_sorted, (int)n, gd, gd_host, min_pts,
+                         block_counts, block_offsets, ticket, run_tags, tag, d_nleaf, leaf_start, leaf_cnt);
+      hipLaunchKernelGGL((k_runs<RUNS_EMIT, 8>), dim3(blocks), dim3(256), 0, s, keys_sorted, (int)n, gd, gd_host, min_pts,
+                         block_counts, block_offsets, ticket, run_tags, tag, d_nleaf, leaf_start, leaf_cnt);
+    }
+  }
+  return hipGetLastError();
+}
+
+int build_read_stamps(unsigned long long* out) {
+#ifdef NDT_STAMPS
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bstamps), sizeof(unsigned long long) * 4 * 512 * 8) == hipSuccess ? 4 * 512 : -1;
+#else
+  (void)out;
+  return 0;
+#endif
+}
+
+int finalize_blocks(int max_leaves) { return (max_leaves + 63) / 64; }
 
 void launch_finalize_leaves(const float* xyz4, const uint32_t* keys_sorted, const uint32_t* vals_sorted,
                             int* d_nleaf, const int* leaf_start, const int* leaf_cnt, int max_leaves,
                             FinalizeParams fp, double* sums, VoxelRecord* rec, LeafStats* stats, int* cell2leaf,
-                            unsigned int* ticket, int* nleaf_host, hipStream_t s) {
+                            int* block_ok, unsigned int* ticket, int* nleaf_host, hipStream_t s) {
   if (max_leaves <= 0) return;
   size_t blocks = ((size_t)max_leaves * LANES_PER_LEAF + 255) / 256;
   if (blocks > (size_t)SUMS_BLOCKS_MAX) blocks = SUMS_BLOCKS_MAX;
   hipLaunchKernelGGL(k_leaf_sums, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(xyz4),
                      vals_sorted, d_nleaf, leaf_start, leaf_cnt, sums);
-  hipLaunchKernelGGL(k_leaf_finalize, dim3((unsigned)((max_leaves + 63) / 64)), dim3(64), 0, s, keys_sorted, d_nleaf,
-                     leaf_start, leaf_cnt, sums, fp, rec, stats, cell2leaf, ticket, nleaf_host);
+  if (build_tuning().finalize_threads == 256)
+    hipLaunchKernelGGL(k_leaf_finalize<256>, dim3((unsigned)((max_leaves + 255) / 256)), dim3(256), 0, s, keys_sorted,
+                       d_nleaf, leaf_start, leaf_cnt, sums, fp, rec, stats, cell2leaf, block_ok, ticket, nleaf_host);
+  else
+    hipLaunchKernelGGL(k_leaf_finalize<64>, dim3((unsigned)((max_leaves + 63) / 64)), dim3(64), 0, s, keys_sorted,
+                       d_nleaf, leaf_start, leaf_cnt, sums, fp, rec, stats, cell2leaf, block_ok, ticket, nleaf_host);
 }
 
 }  // namespace ndt

@@ -1,0 +1,25 @@
+"""Reads the in-kernel phase stamps of the fused build kernels from a -DNDT_STAMPS diagnostic build
+(not collected by pytest)."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import __graft_entry__ as ge
+pkg = ge.load_package(); S = pkg.synth
+cfg = S.config_c3()
+ndt = pkg.NormalDistributionsTransform(device_id=0, resolution=0.5, step_size=0.1, trans_epsilon=1e-4, max_iterations=0)
+for _ in range(5): ndt.setInputTarget(cfg["target"])
+L = pkg.lib()
+L.ndt_debug_read_build_stamps.argtypes = [C.c_void_p]
+raw = np.zeros(4 * 512 * 8, np.uint64)
+assert L.ndt_debug_read_build_stamps(raw.ctypes.data) == 4 * 512
+t = raw.reshape(4, 512, 8).astype(np.int64)
+n = len(cfg["target"])
+names = {0: ["entry", "keys loaded", "ranked", "table read", "staged", "stores done"], 3: ["entry", "counted", "offset known", "emitted"]}
+for slot, nb, label in ((0, (n + 8191) // 8192, "sort pass 0 (from points)"), (1, (n + 8191) // 8192, "sort pass 1"),
+                        (2, (n + 8191) // 8192, "sort pass 2"), (3, (n + 2047) // 2048, "run search (fused)")):
+    nm = names[3] if slot == 3 else names[0]
+    b = t[slot, :min(nb, 512), :len(nm)]
+    rel = (b - b[:, 0].min()) * 0.01
+    print("%s: %d blocks (us since the first block's entry)" % (label, nb))
+    for k, name in enumerate(nm):
+        print("  %-13s min %6.2f  median %6.2f  max %6.2f" % (name, rel[:, k].min(), np.median(rel[:, k]), rel[:, k].max()))

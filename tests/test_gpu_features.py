@@ -343,3 +343,45 @@ def test_batched_scoring_and_xy_covariance_estimators(pkg, O, S):
     cm = np.cov(pts.T, ddof=1)
     assert np.abs(cov_m - cm).max() < 1e-6 + 0.2 * np.abs(cm).max()   # re-alignments end within 1 mm of the oracle's
     assert np.all(np.linalg.eigvalsh(cov_m) >= -1e-12)
+
+
+def _leaf_dump(env_extra, cfg_name="config_c2", res=1.0):
+    import subprocess, sys, os
+    code = r"""
+import sys, numpy as np, hashlib
+sys.path.insert(0, %r)
+import __graft_entry__ as ge
+pkg = ge.load_package(); S = pkg.synth
+cfg = getattr(S, %r)()
+ndt = pkg.NormalDistributionsTransform(device_id=0, resolution=%r, step_size=0.1, trans_epsilon=1e-4, max_iterations=35)
+h = hashlib.sha256()
+for rep in range(3):       # first build waits for the geometry, the later ones are optimistic
+    ndt.setInputTarget(cfg["target"])
+    L = ndt.getLeaves()
+    for k in ("cell", "count", "mean", "cov", "icov", "evecs", "evals"):
+        h.update(np.ascontiguousarray(L[k]).tobytes())
+ndt.setInputSource(cfg["source"]); T = ndt.align(cfg["guess"])
+h.update(np.ascontiguousarray(T).tobytes())
+print("dump", h.hexdigest(), len(L["cell"]), ndt.buildCounters()[0])
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), cfg_name, res)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, **env_extra))
+    assert p.returncode == 0, p.stderr[-2000:]
+    w = [ln for ln in p.stdout.splitlines() if ln.startswith("dump")][0].split()
+    return w[1], int(w[2]), int(w[3])
+
+
+def test_fused_sort_passes_equal_classic_passes_and_fall_back():
+    """The build's one-launch-per-digit sort passes (k_sort_pass) against the classic
+    count / scan / scatter passes: every exported leaf field and the aligned transform, bit for bit
+    (own processes: the switch is read once from the environment).  With one tile made to withhold
+    its counts every block of the fused pass gives up after its time-out, the build is marked
+    BG_SPIN, and the engine repeats it with the classic passes: same leaves, and the fallback is
+    counted."""
+    fused = _leaf_dump({"NDT_FUSED_SORT": "1"})
+    classic = _leaf_dump({"NDT_FUSED_SORT": "0"})
+    assert fused[1] > 1000 and fused[2] == 0 and classic[2] == 0
+    assert fused[:2] == classic[:2]
+    muted = _leaf_dump({"NDT_FUSED_SORT": "1", "NDT_DEBUG_FUSED_MUTE_TILE": "0"})
+    assert muted[:2] == classic[:2]
+    assert muted[2] == 3          # every one of the three builds fell back

@@ -572,3 +572,27 @@ def test_c3_wide_parity(pkg, O, S):
     L2 = ndt.getLeaves()
     for k in ("cell", "count", "mean", "cov", "icov"):
         assert np.array_equal(L1[k], L2[k]), k
+
+
+def test_crowded_voxels_across_sort_and_run_tiles(pkg, O):
+    """Voxels that hold thousands of points: their runs of equal cell key straddle several tiles of
+    the run search (2048 keys; the carry-in run's head is found by wave 0 with 64-wide probes, more
+    than one probe round beyond 4096 keys) and of the sort (8192 pairs).  Membership and counts bit
+    for bit, moments to the usual tolerances, against the oracle."""
+    rng = np.random.default_rng(77)
+    parts = []
+    # crowded voxels of awkward sizes, interleaved in input order with ordinary points
+    for i, m in enumerate([10000, 4097, 4096, 2049, 8193, 6000, 2047, 12289]):
+        c = np.array([3.0 * i - 10.0, 20.0, 0.0]) + 0.5
+        parts.append(c + rng.uniform(-0.45, 0.45, (m, 3)))
+    parts.append(rng.uniform(-6, 6, (30000, 3)))
+    tgt = np.concatenate(parts)
+    tgt = tgt[rng.permutation(len(tgt))].astype(np.float32)
+    kw = dict(resolution=1.0, step_size=0.1, trans_epsilon=1e-4, max_iterations=5, min_points_per_voxel=6)
+    grid = O.Grid(tgt, O.default_params(num_threads=4, **kw))
+    ndt = pkg.NormalDistributionsTransform(device_id=0, **kw)
+    for rep in range(2):   # the first build waits for the geometry, the second is the optimistic one
+        ndt.setInputTarget(tgt)
+        L, OL = ndt.getLeaves(), grid.export()
+        assert L["count"].max() >= 12289
+        assert_leaves_match(L, OL)
