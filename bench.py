@@ -214,7 +214,7 @@ def main():
         t0 = time.perf_counter()
         ndt.setInputTargetDevice(tptr[0], tptr[1], tptr[2], n_tgt)
         t1 = time.perf_counter()
-        ndt.setInputSourceDevice(sptr[0], sptr[1], sptr[2], c)
+        ndt.setInputSourceDeviceView(sptr[0], sptr[1], sptr[2], c)
         ndt.align(guess_cm, return_transform=False)
         t2 = time.perf_counter()
         return ndt, t1 - t0, t2 - t1
@@ -313,6 +313,8 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C3 scan-to-map: 200k-pt source into 1M-pt voxelised submap, 0.5 m voxel, DIRECT7, "
                                    "outlier 0.55, eps 1e-4, step 0.1, max 35 it; step = voxel-grid build + align",
+                       "handoff": "clouds resident in HBM as SoA: target consumed by the build (ndt_set_target_device), "
+                                  "source viewed in place (ndt_set_source_device_view: setInputSource's shared_ptr contract)",
                        "n_source": n_src_total, "n_target": len(cfg["target"]), "voxels": int(gi["n_leaves"]),
                        "grid_cells": int(gi["n_cells"]), "mean_neighbors": nbar, "sharding": "source/%d" % world,
                        "reduce": reduce_mode, "reduce_variants": variants},
@@ -390,7 +392,7 @@ def main():
         el = time.perf_counter() - t0
         # leave the engine as the timed steps use it
         ndt.setInputTargetDevice(tptr[0], tptr[1], tptr[2], n_tgt)
-        ndt.setInputSourceDevice(sptr[0], sptr[1], sptr[2], c)
+        ndt.setInputSourceDeviceView(sptr[0], sptr[1], sptr[2], c)
         return {"what": "PCIe-inclusive: host PointXYZI (32 B/pt) clouds through ndt_set_target / ndt_set_source, then align",
                 "value": iters / el, "unit": "iterations/s", "ms_scan": 1e3 * el / k, "ms_set_target": 1e3 * tt / k,
                 "ms_set_source": 1e3 * ts / k, "ms_align": 1e3 * ta / k, "steps": k}
@@ -439,7 +441,7 @@ def main():
             el = float(t.item())
             ndt.setGlobalSourceSize(n_src_total)
         err_t, err_r = S.pose_error(r["T"], cfg["gt"])
-        ndt.setInputSourceDevice(src[0].data_ptr(), src[1].data_ptr(), src[2].data_ptr(), c)
+        ndt.setInputSourceDeviceView(src[0].data_ptr(), src[1].data_ptr(), src[2].data_ptr(), c)
         return {"workload": "same map, %d-point source (the map seen from the scan pose, 2 cm noise), sharded /%d" % (nb, world),
                 "n_source": nb, "value": iters / el, "unit": "iterations/s", "ms_per_step": 1e3 * el / k,
                 "iterations_per_align": iters / k, "evaluations_per_align": evals / k,

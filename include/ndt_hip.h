@@ -215,6 +215,10 @@ int ndt_set_target_device(ndt_handle* h, const float* dx, const float* dy, const
 int ndt_set_source(ndt_handle* h, const float* xyz, size_t n, size_t stride_bytes);
 int ndt_set_source_soa(ndt_handle* h, const float* x, const float* y, const float* z, size_t n);
 int ndt_set_source_device(ndt_handle* h, const float* dx, const float* dy, const float* dz, size_t n);
+/* The same without the copy: the engine reads the caller's device arrays at every later evaluation,
+ * so they must stay valid and unchanged until the source is replaced -- pcl::Registration::
+ * setInputSource's contract (it keeps the caller's shared_ptr; ref: run/pipeline.cpp:558). */
+int ndt_set_source_device_view(ndt_handle* h, const float* dx, const float* dy, const float* dz, size_t n);
 
 /* Device-resident keyframe archive + sliding-window target assembly.  The drivers keep every
  * keyframe's body-frame scan (pointsArchive, ref: run/pipeline.cpp:784) and rebuild the NDT

@@ -120,7 +120,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
 ABI_SYMBOLS = [
     "ndt_abi_version", "ndt_default_params", "ndt_create", "ndt_destroy", "ndt_set_params",
     "ndt_get_params", "ndt_last_error", "ndt_backend_info", "ndt_set_target", "ndt_set_target_soa",
-    "ndt_set_target_device", "ndt_set_source", "ndt_set_source_soa", "ndt_set_source_device",
+    "ndt_set_target_device", "ndt_set_source", "ndt_set_source_soa", "ndt_set_source_device", "ndt_set_source_device_view",
     "ndt_set_regularization_pose", "ndt_clear_regularization_pose", "ndt_align",
     "ndt_eval_derivatives", "ndt_unpack_eval", "ndt_transform_source", "ndt_get_grid_info",
     "ndt_export_leaves", "ndt_newton_align", "ndt_shard_range", "ndt_comm_unique_id",
@@ -161,6 +161,7 @@ def lib():
         L.ndt_set_source.argtypes = [vp, vp, C.c_size_t, C.c_size_t]
         L.ndt_set_source_soa.argtypes = [vp, vp, vp, vp, C.c_size_t]
         L.ndt_set_source_device.argtypes = [vp, vp, vp, vp, C.c_size_t]
+        L.ndt_set_source_device_view.argtypes = [vp, vp, vp, vp, C.c_size_t]
         L.ndt_set_regularization_pose.argtypes = [vp, fp]
         L.ndt_clear_regularization_pose.argtypes = [vp]
         L.ndt_align.argtypes = [vp, fp, C.POINTER(Result)]
@@ -383,6 +384,11 @@ class NormalDistributionsTransform:
 
     def setInputSourceDevice(self, dx, dy, dz, n):
         self._check(lib().ndt_set_source_device(self._h, dx, dy, dz, n))
+
+    def setInputSourceDeviceView(self, dx, dy, dz, n):
+        """No copy: the device arrays must stay valid and unchanged until the source is replaced
+        (pcl::Registration::setInputSource keeps the caller's shared_ptr the same way)."""
+        self._check(lib().ndt_set_source_device_view(self._h, dx, dy, dz, n))
         self._n_src = int(n)
 
     # --- device-resident keyframe archive (ref: run/pipeline.cpp:784, run/pipeline_ligo_tc.cpp:519-529) ---

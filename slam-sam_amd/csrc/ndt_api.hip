@@ -92,6 +92,9 @@ struct ndt_handle {
   DevBuf<uint32_t> run_tags;          // tagged block leaf counts of the fused run search
   uint32_t run_seq = 0;
   long long n_fused_sort_fallbacks = 0;
+  const float* vx = nullptr;          // the source as evaluated: the engine's own copy (sx/sy/sz) or,
+  const float* vy = nullptr;          // after ndt_set_source_device_view, the caller's arrays
+  const float* vz = nullptr;
   int n_cus = 0;                      // compute units of the device (a fused sort pass needs one per tile)
   DevBuf<double> leaf_sums;
   DevBuf<int> brows;                 // per-block bounds rows
@@ -473,7 +476,7 @@ int maybe_sort_source(ndt_handle* h, const float T[16]) {
     for (int j = 0; j < 3; ++j) pc.R[3 * i + j] = T[4 * j + i];
     pc.t[i] = T[12 + i];
   }
-  HIP_TRY(h, sort_source_by_blocks(h->sx.p, h->sy.p, h->sz.p, n, h->geom, pc, h->splan.p, h->ssort_tmp.p, h->skeys.p,
+  HIP_TRY(h, sort_source_by_blocks(h->vx, h->vy, h->vz, n, h->geom, pc, h->splan.p, h->ssort_tmp.p, h->skeys.p,
                                    h->skeys2.p, h->svals.p, h->svals2.p, h->ox.p, h->oy.p, h->oz.p, h->stream));
   h->src_sorted = true;
   return NDT_OK;
@@ -587,9 +590,9 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
   }
   double* d_out = dev_out ? h->dres.p : h->result.d;
   const bool spin = !dev_out && !h->timing && h->prm.wait_mode == NDT_WAIT_SPIN;
-  const float* px = h->src_sorted ? h->ox.p : h->sx.p;
-  const float* py = h->src_sorted ? h->oy.p : h->sy.p;
-  const float* pz = h->src_sorted ? h->oz.p : h->sz.p;
+  const float* px = h->src_sorted ? h->ox.p : h->vx;
+  const float* py = h->src_sorted ? h->oy.p : h->vy;
+  const float* pz = h->src_sorted ? h->oz.p : h->vz;
   const bool prelaunch = spin && !score_only && h->prelaunch_armed && h->prm.prelaunch == NDT_PRELAUNCH_AUTO &&
                          ensure_mailbox(h);
   unsigned long long seq = 0;
@@ -873,8 +876,11 @@ int ndt_set_source(ndt_handle* h, const float* xyz, size_t n, size_t stride_byte
   if (!h || (!xyz && n) || stride_bytes < 12 || stride_bytes % 4) return NDT_ERR_INVALID_ARG;
   int rc = bind_device(h);
   if (rc) return rc;
+  h->vx = h->vy = h->vz = nullptr;
+  h->n_src = 0;
   rc = upload_soa(h, xyz, nullptr, nullptr, nullptr, n, stride_bytes, h->sx, h->sy, h->sz);
   if (rc) return rc;
+  h->vx = h->sx.p; h->vy = h->sy.p; h->vz = h->sz.p;
   h->n_src = n;
   h->src_sorted = false;
   return NDT_OK;
@@ -884,8 +890,11 @@ int ndt_set_source_soa(ndt_handle* h, const float* x, const float* y, const floa
   if (!h || ((!x || !y || !z) && n)) return NDT_ERR_INVALID_ARG;
   int rc = bind_device(h);
   if (rc) return rc;
+  h->vx = h->vy = h->vz = nullptr;
+  h->n_src = 0;
   rc = upload_soa(h, nullptr, x, y, z, n, 0, h->sx, h->sy, h->sz);
   if (rc) return rc;
+  h->vx = h->sx.p; h->vy = h->sy.p; h->vz = h->sz.p;
   h->n_src = n;
   h->src_sorted = false;
   return NDT_OK;
@@ -903,6 +912,19 @@ int ndt_set_source_device(ndt_handle* h, const float* dx, const float* dy, const
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(h->stream));  // the caller's arrays are consumed during the call
   }
+  h->vx = h->sx.p; h->vy = h->sy.p; h->vz = h->sz.p;
+  h->n_src = n;
+  h->src_sorted = false;
+  return NDT_OK;
+}
+
+// pclomp's setInputSource keeps the caller's shared_ptr, not a copy (ref: pcl::Registration::
+// setInputSource, called at run/pipeline.cpp:558): the same contract for device-resident arrays.
+int ndt_set_source_device_view(ndt_handle* h, const float* dx, const float* dy, const float* dz, size_t n) {
+  if (!h || ((!dx || !dy || !dz) && n)) return NDT_ERR_INVALID_ARG;
+  int rc = bind_device(h);
+  if (rc) return rc;
+  h->vx = dx; h->vy = dy; h->vz = dz;
   h->n_src = n;
   h->src_sorted = false;
   return NDT_OK;
@@ -1091,8 +1113,8 @@ static int eval_batch(ndt_handle* h, const double* poses6, const float* transfor
   }
   const unsigned long long seq = g_launch_seq.fetch_add(1, std::memory_order_relaxed);
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, s));
-  launch_derivatives(h->src_sorted ? h->ox.p : h->sx.p, h->src_sorted ? h->oy.p : h->sy.p,
-                     h->src_sorted ? h->oz.p : h->sz.p, h->n_src, h->geom, h->cell2leaf.p, h->rec.p,
+  launch_derivatives(h->src_sorted ? h->ox.p : h->vx, h->src_sorted ? h->oy.p : h->vy,
+                     h->src_sorted ? h->oz.p : h->vz, h->n_src, h->geom, h->cell2leaf.p, h->rec.p,
                      h->hposes.h[0], fast ? h->bposes : h->dposes.p, K, ec, h->partials.p, h->counters.p, h->dres.p, s,
                      fast ? h->flag.d : nullptr, seq);
   HIP_TRY(h, hipGetLastError());
@@ -1190,7 +1212,7 @@ int ndt_transform_source(ndt_handle* h, const float T[16], float* out_xyz, size_
   }
   DevBuf<float> tmp;
   HIP_TRY(h, tmp.ensure(3 * h->n_src));
-  launch_transform(h->sx.p, h->sy.p, h->sz.p, h->n_src, pc, tmp.p, h->stream);
+  launch_transform(h->vx, h->vy, h->vz, h->n_src, pc, tmp.p, h->stream);
   hipError_t e = hipMemcpyAsync(out_xyz, tmp.p, 3 * h->n_src * sizeof(float), hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   tmp.release();

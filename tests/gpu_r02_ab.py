@@ -21,7 +21,7 @@ g = pkg.ColMajor4f(cfg["guess"])
 nt, ns = len(cfg["target"]), len(cfg["source"])
 def step():
     t0 = time.perf_counter(); ndt.setInputTargetDevice(tp[0], tp[1], tp[2], nt)
-    t1 = time.perf_counter(); ndt.setInputSourceDevice(sp[0], sp[1], sp[2], ns)
+    t1 = time.perf_counter(); ndt.setInputSourceDeviceView(sp[0], sp[1], sp[2], ns)
     t2 = time.perf_counter(); ndt.align(g, return_transform=False)
     t3 = time.perf_counter(); return t1 - t0, t2 - t1, t3 - t2
 for _ in range(10): step()

@@ -151,6 +151,13 @@ def test_grid_parameter_change_on_a_consumed_device_target(pkg, S, hipmem):
     T_host = ndt.align(cfg["guess"])
     ndt.setInputSourceDevice(s[0], s[1], s[2], len(cfg["source"]))
     assert np.array_equal(ndt.align(cfg["guess"]), T_host)
+    # ... and so does a view of them (no copy: setInputSource's shared_ptr contract)
+    ndt.setInputSource(cfg["source"][:100])
+    ndt.setInputSourceDeviceView(s[0], s[1], s[2], len(cfg["source"]))
+    assert np.array_equal(ndt.align(cfg["guess"]), T_host)
+    assert np.array_equal(ndt.align(cfg["guess"]), T_host)
+    ndt.setInputSource(cfg["source"])          # replacing a view by an owned copy
+    assert np.array_equal(ndt.align(cfg["guess"]), T_host)
     # a host target is kept and re-voxelised
     ndt2 = _ndt(pkg)
     ndt2.setInputTarget(cfg["target"])
@@ -385,3 +392,23 @@ def test_fused_sort_passes_equal_classic_passes_and_fall_back():
     muted = _leaf_dump({"NDT_FUSED_SORT": "1", "NDT_DEBUG_FUSED_MUTE_TILE": "0"})
     assert muted[:2] == classic[:2]
     assert muted[2] == 3          # every one of the three builds fell back
+
+
+def test_fused_build_launch_tags_wrap_around(pkg, hipmem):
+    """The fused build kernels recognise this launch's words by a 16-bit tag; the tag counters wrap
+    after 65535 launches (21845 builds for the three sort passes, 65535 for the run search) and the
+    tag tables are cleared at that point.  70 000 builds of one small cloud: the leaves never change."""
+    rng = np.random.default_rng(5)
+    tgt = rng.uniform(-12, 12, (20000, 3)).astype(np.float32)
+    t = [hipmem.upload(tgt[:, a]) for a in range(3)]
+    ndt = pkg.NormalDistributionsTransform(device_id=0, resolution=1.5, step_size=0.1, trans_epsilon=1e-4, max_iterations=5)
+    ndt.setInputTargetDevice(t[0], t[1], t[2], len(tgt))
+    ref = ndt.getLeaves()
+    assert len(ref["cell"]) > 1000
+    for i in range(70000):
+        ndt.setInputTargetDevice(t[0], t[1], t[2], len(tgt))
+        if i % 7000 == 6999 or i in (21843, 21844, 21845, 21846, 65533, 65534, 65535, 65536):
+            L = ndt.getLeaves()
+            for k in ("cell", "count", "mean", "icov"):
+                assert np.array_equal(L[k], ref[k]), (i, k)
+    assert ndt.buildCounters()[0] == 0
