@@ -220,6 +220,20 @@ int ndt_set_source_device(ndt_handle* h, const float* dx, const float* dy, const
  * setInputSource's contract (it keeps the caller's shared_ptr; ref: run/pipeline.cpp:558). */
 int ndt_set_source_device_view(ndt_handle* h, const float* dx, const float* dy, const float* dz, size_t n);
 
+/* Multi-grid target [RECALLED: tier4 ndt_omp's MultiGridNormalDistributionsTransform -- addTarget /
+ * removeTarget / createVoxelKdtree -- named by the reference's build (CMakeLists.txt:41-42); its
+ * sources are in the absent extern/ndt_omp submodule and no driver instantiates it].  Every cloud is
+ * voxelised on its own (the leaves of setInputTarget on that cloud alone) and kept under an id;
+ * ndt_multigrid_create_kdtree makes the union of all stored grids the target: the neighbourhood is
+ * the radius search (radius = leaf size) over the centroids of ALL grids' valid leaves, whatever
+ * search_method says; a voxel that two grids share contributes once per grid.  Afterwards
+ * ndt_align / ndt_score_transform / ndt_eval_derivatives work as after ndt_set_target; a plain
+ * ndt_set_target* call replaces the union (the stored grids stay until removed). */
+int ndt_multigrid_add_target(ndt_handle* h, int64_t id, const float* xyz, size_t n, size_t stride_bytes);
+int ndt_multigrid_remove_target(ndt_handle* h, int64_t id);
+int64_t ndt_multigrid_count(const ndt_handle* h);
+int ndt_multigrid_create_kdtree(ndt_handle* h);
+
 /* Device-resident keyframe archive + sliding-window target assembly.  The drivers keep every
  * keyframe's body-frame scan (pointsArchive, ref: run/pipeline.cpp:784) and rebuild the NDT
  * target per keyframe as the sum of <= 5 archived scans, each moved by its current pose

@@ -34,6 +34,7 @@
 #include <array>
 #include <cstddef>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <string>
 #include <utility>
@@ -395,6 +396,38 @@ class NormalDistributionsTransform
     if (status_ == NDT_OK) n_src_ = 0;  // align()'s output cloud is not filled on this path
   }
 
+  // ---- multi-grid target [RECALLED: tier4 ndt_omp multigrid_ndt_omp.h -- addTarget / removeTarget /
+  // createVoxelKdtree with string ids; the reference names the class only in its build,
+  // CMakeLists.txt:41-42, and no driver instantiates it] ----
+  template <class CloudPtrT>
+  void addTarget(const CloudPtrT& cloud, const std::string& target_id) {
+    if (!h_) { status_ = NDT_ERR_NO_DEVICE; return; }
+    if (!cloud || cloud->points.empty()) { status_ = NDT_ERR_INVALID_ARG; return; }
+    auto it = target_ids_.find(target_id);
+    const int64_t id = it != target_ids_.end() ? it->second : next_target_id_++;
+    status_ = ndt_multigrid_add_target(h_, id, &cloud->points[0].x, cloud->points.size(), sizeof(cloud->points[0]));
+    if (status_ == NDT_OK) target_ids_[target_id] = id;
+    grid_ = TargetGrid();
+  }
+  template <class CloudPtrT>
+  void setInputTarget(const CloudPtrT& cloud, const std::string& target_id) { addTarget(cloud, target_id); }
+  void removeTarget(const std::string& target_id) {
+    auto it = target_ids_.find(target_id);
+    if (!h_ || it == target_ids_.end()) { status_ = h_ ? NDT_ERR_INVALID_ARG : NDT_ERR_NO_DEVICE; return; }
+    status_ = ndt_multigrid_remove_target(h_, it->second);
+    target_ids_.erase(it);
+    grid_ = TargetGrid();
+  }
+  void createVoxelKdtree() {
+    status_ = h_ ? ndt_multigrid_create_kdtree(h_) : NDT_ERR_NO_DEVICE;
+    grid_ = TargetGrid();
+  }
+  std::vector<std::string> getCurrentMapIDs() const {
+    std::vector<std::string> v;
+    for (const auto& kv : target_ids_) v.push_back(kv.first);
+    return v;
+  }
+
   int lastStatus() const { return status_; }
   std::string lastError() const { return h_ ? ndt_last_error(h_) : "no engine (ndt_create failed: GPU required)"; }
   const ndt_result& rawResult() const { return res_; }
@@ -458,7 +491,13 @@ class NormalDistributionsTransform
   size_t n_src_ = 0;
   bool fill_output_ = false;
   TargetGrid grid_;
+  std::map<std::string, int64_t> target_ids_;  // multi-grid: tier4's string ids -> the C-ABI's integers
+  int64_t next_target_id_ = 1;
 };
+
+// tier4's class name for the multi-grid face [RECALLED]; here the same engine object carries both faces
+template <typename PointSource, typename PointTarget>
+using MultiGridNormalDistributionsTransform = NormalDistributionsTransform<PointSource, PointTarget>;
 
 // ---------------------------------------------------------------------------------------------
 // svn_ndt::SvnNormalDistributionsTransform-shaped adapter (ref: extern/svn_ndt/include/svn_ndt.h:

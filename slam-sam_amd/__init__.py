@@ -127,6 +127,7 @@ ABI_SYMBOLS = [
     "ndt_comm_init_rccl", "ndt_comm_init_shm", "ndt_comm_init_hook", "ndt_comm_destroy",
     "ndt_set_global_source_size", "ndt_enable_kernel_timing", "ndt_get_timing",
     "ndt_svn_default_params", "ndt_svn_sample_particles", "ndt_svn_align",
+    "ndt_multigrid_add_target", "ndt_multigrid_remove_target", "ndt_multigrid_count", "ndt_multigrid_create_kdtree",
     "ndt_keyframe_put", "ndt_keyframe_erase", "ndt_keyframe_count", "ndt_set_target_from_keyframes",
     "ndt_result_covariance", "ndt_set_source_from_keyframe",
     "ndt_params_preset", "ndt_score_transform", "ndt_comm_info", "ndt_score_transforms",
@@ -185,6 +186,11 @@ def lib():
         L.ndt_set_global_source_size.argtypes = [vp, C.c_int64]
         L.ndt_enable_kernel_timing.argtypes = [vp, C.c_int]
         L.ndt_get_timing.argtypes = [vp, C.POINTER(Timing)]
+        L.ndt_multigrid_add_target.argtypes = [vp, C.c_int64, vp, C.c_size_t, C.c_size_t]
+        L.ndt_multigrid_remove_target.argtypes = [vp, C.c_int64]
+        L.ndt_multigrid_count.restype = C.c_int64
+        L.ndt_multigrid_count.argtypes = [vp]
+        L.ndt_multigrid_create_kdtree.argtypes = [vp]
         L.ndt_keyframe_put.argtypes = [vp, C.c_int64, vp, C.c_size_t, C.c_size_t]
         L.ndt_keyframe_erase.argtypes = [vp, C.c_int64]
         L.ndt_keyframe_count.restype = C.c_int64
@@ -390,6 +396,22 @@ class NormalDistributionsTransform:
         (pcl::Registration::setInputSource keeps the caller's shared_ptr the same way)."""
         self._check(lib().ndt_set_source_device_view(self._h, dx, dy, dz, n))
         self._n_src = int(n)
+
+    # --- multi-grid target [RECALLED: tier4 MultiGridNormalDistributionsTransform] ---
+    def addTarget(self, cloud, target_id):
+        """Voxelises `cloud` on its own and keeps its leaves under `target_id`."""
+        a = self._xyz(cloud)
+        self._check(lib().ndt_multigrid_add_target(self._h, int(target_id), a.ctypes.data, len(a), a.strides[0]))
+
+    def removeTarget(self, target_id):
+        self._check(lib().ndt_multigrid_remove_target(self._h, int(target_id)))
+
+    def targetCount(self):
+        return int(lib().ndt_multigrid_count(self._h))
+
+    def createVoxelKdtree(self):
+        """The union of all stored grids becomes the target (radius search over every grid's leaves)."""
+        self._check(lib().ndt_multigrid_create_kdtree(self._h))
 
     # --- device-resident keyframe archive (ref: run/pipeline.cpp:784, run/pipeline_ligo_tc.cpp:519-529) ---
     def putKeyframe(self, kf_id, cloud):

@@ -14,6 +14,7 @@
 #include <limits>
 #include <string>
 #include <thread>
+#include <map>
 #include <unordered_map>
 #include <vector>
 
@@ -145,6 +146,22 @@ struct ndt_handle {
   };
   std::unordered_map<int64_t, Keyframe> keyframes;
 
+  // multi-grid target [RECALLED] (tier4 MultiGridNormalDistributionsTransform): the valid leaves of
+  // every separately voxelised cloud, on the host (adding a map tile is not a per-scan operation);
+  // ndt_multigrid_create_kdtree assembles their union into the device table
+  struct MultiGridEntry {
+    std::vector<VoxelRecord> rec;
+    std::vector<LeafStats> stats;
+    std::vector<int> ijk;  // absolute lattice index of every leaf, 3 ints
+    size_t n_points = 0;
+    float resolution = 0.0f;
+    int min_points = 0, cov_mode = 0;
+    double eig_ratio = 0.0;
+  };
+  std::map<int64_t, MultiGridEntry> mgrids;
+  bool multi_active = false;          // the device table is the union (neighbourhood: radius search, chained cells)
+  std::vector<LeafStats> multi_stats; // ... and its leaves in table order, for export
+
   // pre-launched evaluation (ndt_prelaunch): mailbox in BAR-mapped fine-grained device memory
   PoseMailbox* mbox = nullptr;
   bool mbox_tried = false;
@@ -274,6 +291,7 @@ int upload_soa(ndt_handle* h, const float* xyz, const float* x, const float* y, 
 // before).  A refused optimistic build (BG_CAPACITY / BG_PASSES) is repeated that way.
 int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, size_t n) {
   h->have_grid = false;
+  h->multi_active = false;
   h->src_sorted = false;
   h->n_tgt = n;
   h->n_slots = h->n_valid = 0;
@@ -425,6 +443,7 @@ EvalConsts make_eval_consts(const ndt_handle* h, bool need_h) {
   ec.kd_radius2 = (float)((double)h->prm.resolution * (double)h->prm.resolution);
   ec.need_hessian = need_h ? 1 : 0;
   ec.gauss_newton = h->prm.hessian_mode == NDT_HESSIAN_GAUSS_NEWTON ? 1 : 0;
+  ec.multigrid = h->multi_active ? 1 : 0;
   return ec;
 }
 
@@ -930,6 +949,154 @@ int ndt_set_source_device_view(ndt_handle* h, const float* dx, const float* dy, 
   return NDT_OK;
 }
 
+// ---- multi-grid target [RECALLED: tier4 ndt_omp multigrid_ndt_omp.h / multi_voxel_grid_covariance_omp.h,
+// named by the reference's build (CMakeLists.txt:41-42), sources in the absent submodule] ----------
+// addTarget(cloud, id): the cloud is voxelised ON ITS OWN by the ordinary build (same kernels, same
+// leaf statistics as setInputTarget) and its valid leaves are kept under `id`.
+int ndt_multigrid_add_target(ndt_handle* h, int64_t id, const float* xyz, size_t n, size_t stride_bytes) {
+  if (!h || !xyz || n == 0 || stride_bytes < 12 || stride_bytes % 4) return NDT_ERR_INVALID_ARG;
+  int rc = bind_device(h);
+  if (rc) return rc;
+  rc = upload_soa(h, xyz, nullptr, nullptr, nullptr, n, stride_bytes, h->tx, h->ty, h->tz);
+  if (rc) return rc;
+  rc = build_grid(h, h->tx.p, h->ty.p, h->tz.p, n);
+  // the handle's single-grid table is scratch here: whatever happens, it is not a target to align to,
+  // and the cloud is not kept (a later resolution change cannot silently re-voxelise one tile)
+  h->have_grid = false;
+  h->tx.release(); h->ty.release(); h->tz.release();
+  if (rc) return rc;
+  std::vector<LeafStats> st((size_t)h->n_slots);
+  std::vector<VoxelRecord> rec((size_t)h->n_slots);
+  if (h->n_slots) {
+    HIP_TRY(h, hipMemcpy(st.data(), h->stats.p, st.size() * sizeof(LeafStats), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(rec.data(), h->rec.p, rec.size() * sizeof(VoxelRecord), hipMemcpyDeviceToHost));
+  }
+  ndt_handle::MultiGridEntry e;
+  const GridGeom& g = h->geom;
+  for (size_t s = 0; s < st.size(); ++s) {
+    if (st[s].count <= 0) continue;
+    const int c = st[s].cell;
+    e.ijk.push_back(g.min_b[0] + c % g.div_b[0]);
+    e.ijk.push_back(g.min_b[1] + (c / g.div_b[0]) % g.div_b[1]);
+    e.ijk.push_back(g.min_b[2] + c / g.mul2);
+    e.rec.push_back(rec[s]);
+    e.stats.push_back(st[s]);
+  }
+  e.n_points = n;
+  e.resolution = h->prm.resolution;
+  e.min_points = h->prm.min_points_per_voxel;
+  e.cov_mode = h->prm.cov_mode;
+  e.eig_ratio = h->prm.eig_inflation_ratio;
+  h->mgrids[id] = std::move(e);
+  h->multi_active = false;  // the union has to be re-assembled (createVoxelKdtree)
+  return NDT_OK;
+}
+
+int ndt_multigrid_remove_target(ndt_handle* h, int64_t id) {
+  if (!h) return NDT_ERR_INVALID_ARG;
+  auto it = h->mgrids.find(id);
+  if (it == h->mgrids.end()) return fail(h, NDT_ERR_INVALID_ARG, "unknown multi-grid target id");
+  h->mgrids.erase(it);
+  if (h->multi_active) { h->multi_active = false; h->have_grid = false; }
+  return NDT_OK;
+}
+
+int64_t ndt_multigrid_count(const ndt_handle* h) { return h ? (int64_t)h->mgrids.size() : NDT_ERR_INVALID_ARG; }
+
+// createVoxelKdtree(): the union of all stored grids becomes the device table.  All grids sit on the
+// same absolute lattice (voxel = floor(p / leaf), ref: voxel_grid_covariance_impl.hpp:222-225), so the
+// kd-tree over every grid's centroids is again a 27-cell scan + distance test; a cell holds one leaf
+// per grid that has points there (head in the dense index, the others chained through the records).
+int ndt_multigrid_create_kdtree(ndt_handle* h) {
+  if (!h) return NDT_ERR_INVALID_ARG;
+  int rc = bind_device(h);
+  if (rc) return rc;
+  h->have_grid = false;
+  h->multi_active = false;
+  h->src_sorted = false;
+  if (h->mgrids.empty()) return fail(h, NDT_ERR_NO_TARGET, "no multi-grid target (addTarget first)");
+  const auto t_begin = std::chrono::steady_clock::now();
+  long long mn[3] = {LLONG_MAX, LLONG_MAX, LLONG_MAX}, mx[3] = {LLONG_MIN, LLONG_MIN, LLONG_MIN};
+  size_t total = 0, total_points = 0;
+  for (const auto& kv : h->mgrids) {
+    const auto& e = kv.second;
+    if (e.resolution != h->prm.resolution || e.min_points != h->prm.min_points_per_voxel || e.cov_mode != h->prm.cov_mode ||
+        e.eig_ratio != h->prm.eig_inflation_ratio)
+      return fail(h, NDT_ERR_INVALID_ARG, "a multi-grid target was voxelised with other grid parameters: add it again");
+    for (size_t i = 0; i < e.rec.size(); ++i)
+      for (int a = 0; a < 3; ++a) {
+        mn[a] = std::min<long long>(mn[a], e.ijk[3 * i + a]);
+        mx[a] = std::max<long long>(mx[a], e.ijk[3 * i + a]);
+      }
+    total += e.rec.size();
+    total_points += e.n_points;
+  }
+  if (total == 0) return fail(h, NDT_ERR_NO_TARGET, "the multi-grid targets hold no valid voxel");
+  long long d[3], ncells = 1;
+  for (int a = 0; a < 3; ++a) { d[a] = mx[a] - mn[a] + 1; ncells *= d[a]; if (ncells >= 2147483647ll) break; }
+  if (ncells >= 2147483647ll || total >= (size_t)2147483647)
+    return fail(h, NDT_ERR_GRID_OVERFLOW, "the multi-grid targets span too many cells (index overflow)");
+  GridGeom g{};
+  g.leaf = h->prm.resolution;
+  g.inv_leaf = 1.0f / h->prm.resolution;
+  for (int a = 0; a < 3; ++a) {
+    g.min_b[a] = (int)mn[a];
+    g.div_b[a] = (int)d[a];
+    g.lo[a] = (float)g.min_b[a] * g.leaf;
+    g.hi[a] = (float)(mx[a] + 1) * g.leaf;
+  }
+  g.mul1 = g.div_b[0];
+  g.mul2 = g.div_b[0] * g.div_b[1];
+  g.ncells = (int)ncells;
+  // (cell, grid, leaf) order: grids in ascending id, leaves in their own ascending cell order
+  struct Ref { int cell; const ndt_handle::MultiGridEntry* e; size_t i; };
+  std::vector<Ref> refs;
+  refs.reserve(total);
+  for (const auto& kv : h->mgrids) {
+    const auto& e = kv.second;
+    for (size_t i = 0; i < e.rec.size(); ++i) {
+      const int c = (e.ijk[3 * i] - g.min_b[0]) + (e.ijk[3 * i + 1] - g.min_b[1]) * g.mul1 + (e.ijk[3 * i + 2] - g.min_b[2]) * g.mul2;
+      refs.push_back(Ref{c, &e, i});
+    }
+  }
+  std::stable_sort(refs.begin(), refs.end(), [](const Ref& a, const Ref& b) { return a.cell < b.cell; });
+  std::vector<VoxelRecord> rec(total);
+  std::vector<int> head_cells, head_slots;
+  h->multi_stats.resize(total);
+  for (size_t s = 0; s < total; ++s) {
+    rec[s] = refs[s].e->rec[refs[s].i];
+    rec[s].pad = (s + 1 < total && refs[s + 1].cell == refs[s].cell) ? (double)(s + 1) : -1.0;
+    h->multi_stats[s] = refs[s].e->stats[refs[s].i];
+    h->multi_stats[s].cell = refs[s].cell;
+    if (s == 0 || refs[s - 1].cell != refs[s].cell) { head_cells.push_back(refs[s].cell); head_slots.push_back((int)s); }
+  }
+  hipStream_t s = h->stream;
+  HIP_TRY(h, h->cell2leaf.ensure((size_t)g.ncells));
+  HIP_TRY(h, hipMemsetAsync(h->cell2leaf.p, 0xFF, h->cell2leaf.cap * sizeof(int), s));
+  h->grid_clean_cap = 0;   // the next ordinary build starts from a cleared index
+  h->grid_dirty_slots = 0;
+  HIP_TRY(h, h->rec.ensure(total));
+  HIP_TRY(h, hipMemcpyAsync(h->rec.p, rec.data(), total * sizeof(VoxelRecord), hipMemcpyHostToDevice, s));
+  DevBuf<int> dc, ds;
+  HIP_TRY(h, dc.ensure(head_cells.size()));
+  HIP_TRY(h, ds.ensure(head_cells.size()));
+  hipError_t e1 = hipMemcpyAsync(dc.p, head_cells.data(), head_cells.size() * sizeof(int), hipMemcpyHostToDevice, s);
+  if (e1 == hipSuccess) e1 = hipMemcpyAsync(ds.p, head_slots.data(), head_slots.size() * sizeof(int), hipMemcpyHostToDevice, s);
+  if (e1 == hipSuccess) { launch_scatter_heads(dc.p, ds.p, head_cells.size(), h->cell2leaf.p, s); e1 = hipGetLastError(); }
+  if (e1 == hipSuccess) e1 = hipStreamSynchronize(s);
+  dc.release(); ds.release();
+  HIP_TRY(h, e1);
+  h->geom = g;
+  for (int a = 0; a < 3; ++a) h->max_b[a] = (int)mx[a];
+  h->n_slots = h->n_valid = (int)total;
+  h->n_tgt = total_points;
+  h->ms_build = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  h->tm.ms_last_build = h->ms_build;
+  h->have_grid = true;
+  h->multi_active = true;
+  return NDT_OK;
+}
+
 int ndt_keyframe_put(ndt_handle* h, int64_t id, const float* xyz, size_t n, size_t stride_bytes) {
   if (!h || (!xyz && n) || stride_bytes < 12 || stride_bytes % 4) return NDT_ERR_INVALID_ARG;
   int rc = bind_device(h);
@@ -1243,7 +1410,9 @@ int64_t ndt_export_leaves(ndt_handle* h, ndt_leaf* out, size_t cap) {
   if (!h->have_grid) return NDT_ERR_NO_TARGET;
   if (bind_device(h)) return NDT_ERR_HIP;
   std::vector<LeafStats> st((size_t)h->n_slots);
-  if (h->n_slots) {
+  if (h->multi_active) {
+    st = h->multi_stats;  // table order; `cell` is the union grid's index
+  } else if (h->n_slots) {
     hipError_t e = hipMemcpy(st.data(), h->stats.p, st.size() * sizeof(LeafStats), hipMemcpyDeviceToHost);
     if (e != hipSuccess) return fail(h, NDT_ERR_HIP, hipGetErrorString(e));
   }
@@ -1251,7 +1420,7 @@ int64_t ndt_export_leaves(ndt_handle* h, ndt_leaf* out, size_t cap) {
   ok.reserve(st.size());
   for (const auto& L : st)
     if (L.count > 0) ok.push_back(&L);
-  std::sort(ok.begin(), ok.end(), [](const LeafStats* a, const LeafStats* b) { return a->cell < b->cell; });
+  std::stable_sort(ok.begin(), ok.end(), [](const LeafStats* a, const LeafStats* b) { return a->cell < b->cell; });
   const size_t n = std::min(cap, ok.size());
   const GridGeom& g = h->geom;
   for (size_t i = 0; i < n; ++i) {

@@ -299,7 +299,12 @@ constexpr int KD_CELLS = 27;
 
 // RADIUS = false is DIRECT26 [RECALLED] (pclomp getNeighborhoodAtPoint): the same 27-cell
 // enumeration in integer index space, every valid leaf found is a neighbour.
-template <int MODE, bool RADIUS>
+// CHAIN (multi-grid target, [RECALLED] tier4 MultiGridNormalDistributionsTransform): the table is the
+// union of several separately voxelised grids on the same absolute lattice, a cell may hold one leaf
+// per grid; cell2leaf gives the first, VoxelRecord::pad of a leaf the slot of the next one in the
+// same cell (-1: none).  The chain is walked inside the trip loop (wave-uniform exit), so a point's
+// pairs are added in (cell, grid) order.
+template <int MODE, bool RADIUS, bool CHAIN>
 __device__ __forceinline__ void point_pairs_kd(PairAcc& a, float x, float y, float z, const GridGeom& g,
                                                const int* __restrict__ cell2leaf,
                                                const VoxelRecord* __restrict__ rec, const RigidRT& P,
@@ -340,10 +345,21 @@ __device__ __forceinline__ void point_pairs_kd(PairAcc& a, float x, float y, flo
   for (int off = 32; off > 0; off >>= 1) trips = max(trips, __shfl_xor(trips, off));
   for (int j = 0; j < trips; ++j) {
     const bool have = j < count;
-    const int sl = have ? lds_list[j * stride + (int)threadIdx.x] : 0;
-    const VoxelRecord r = rec[sl];
-    const bool present = have && (!RADIUS || kd_within(r, xt, yt, zt, ec.kd_radius2));
-    pair_update<MODE>(a, r, xt, yt, zt, ec, present);
+    if (!CHAIN) {
+      const int sl = have ? lds_list[j * stride + (int)threadIdx.x] : 0;
+      const VoxelRecord r = rec[sl];
+      const bool present = have && (!RADIUS || kd_within(r, xt, yt, zt, ec.kd_radius2));
+      pair_update<MODE>(a, r, xt, yt, zt, ec, present);
+    } else {
+      int sl = have ? lds_list[j * stride + (int)threadIdx.x] : -1;
+      while (__ballot(sl >= 0) != 0ull) {  // every lane of the wave leaves together
+        const bool live = sl >= 0;
+        const VoxelRecord r = rec[live ? sl : 0];
+        const bool present = live && (!RADIUS || kd_within(r, xt, yt, zt, ec.kd_radius2));
+        pair_update<MODE>(a, r, xt, yt, zt, ec, present);
+        sl = live ? (int)r.pad : -1;
+      }
+    }
   }
 }
 
@@ -696,7 +712,7 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
     extern __shared__ int lds_kd_list[];  // KD_CELLS x blockDim.x leaf indices
     if (i < n) { x = sx[i]; y = sy[i]; z = sz[i]; }
     NDT_STAMP(1);
-    point_pairs_kd<MODE, NB == 2>(a, x, y, z, g, cell2leaf, rec, rt, ec, lds_kd_list, i < n);
+    point_pairs_kd<MODE, NB == 2 || NB == 4, NB == 4>(a, x, y, z, g, cell2leaf, rec, rt, ec, lds_kd_list, i < n);
   } else if (i < n) {
     x = sx[i]; y = sy[i]; z = sz[i];
     NDT_STAMP(1);
@@ -809,7 +825,7 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
     return e ? atoi(e) : NDT_DERIV_SUMMER_DEFAULT;
   }();
   ecl.fixed_summer = summer;
-  const int nb = ec.kdtree ? 2 : (ec.direct26 ? 3 : (ec.direct7 ? 1 : 0));
+  const int nb = ec.multigrid ? 4 : (ec.kdtree ? 2 : (ec.direct26 ? 3 : (ec.direct7 ? 1 : 0)));
   const size_t dyn_lds = nb >= 2 ? (size_t)KD_CELLS * threads * sizeof(int) : 0;
 #define NDT_LAUNCH2(B, M, NBH, MB, GY, FLAG, SEQ)                                                            \
   hipLaunchKernelGGL((k_derivatives<B, M, NBH, MB>), dim3(blocks, GY), dim3(threads), dyn_lds, s, sx, sy, sz,  \
@@ -832,7 +848,8 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
     if (nb == 0) NDT_LAUNCH_MODE(B, 0, GY, FLAG, SEQ);          \
     else if (nb == 1) NDT_LAUNCH_MODE(B, 1, GY, FLAG, SEQ);     \
     else if (nb == 2) NDT_LAUNCH_MODE(B, 2, GY, FLAG, SEQ);     \
-    else NDT_LAUNCH_MODE(B, 3, GY, FLAG, SEQ);                  \
+    else if (nb == 3) NDT_LAUNCH_MODE(B, 3, GY, FLAG, SEQ);     \
+    else NDT_LAUNCH_MODE(B, 4, GY, FLAG, SEQ);                  \
   } while (0)
   if (d_poses) NDT_LAUNCH_NB(true, K, d_flag, seq);
   else NDT_LAUNCH_NB(false, 1, d_flag, seq);

@@ -92,6 +92,7 @@ struct EvalConsts {
   int direct26;    // 1: every valid voxel of the 3x3x3 block around the point's cell (pclomp DIRECT26)
   int score_only;  // 1: score / NVTL / counts only, no gradient or Hessian (ndt_score_transform)
   int fixed_summer;  // 1: block 0 adds the partial rows (polls their tags), no tickets (single-level grids)
+  int multigrid;   // 1: the table is a union of grids (radius search, leaves of a cell chained through VoxelRecord::pad)
 };
 
 // layout of one evaluation (matches NDT_EVAL_WORDS in include/ndt_hip.h)

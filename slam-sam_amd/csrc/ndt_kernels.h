@@ -61,6 +61,8 @@ struct FinalizeParams {
   double eig_ratio;
   int cov_mode;  // 0 svn, 1 pcl (recalled)
 };
+// multi-grid union table: cell2leaf[cells[i]] = slots[i], i < n (device arrays)
+void launch_scatter_heads(const int* cells, const int* slots, size_t n, int* cell2leaf, hipStream_t s);
 int finalize_blocks(int max_leaves);
 int build_read_stamps(unsigned long long* out /* 4 x 512 x 8 */);  // -DNDT_STAMPS builds only; else 0
 // per-leaf sums, then per-leaf statistics; sums: 9 doubles per leaf slot (scratch)

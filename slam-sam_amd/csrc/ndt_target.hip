@@ -1396,6 +1396,13 @@ hipError_t sort_source_by_blocks(const float* x, const float* y, const float* z,
 }
 
 // three SoA arrays in one launch (three hipMemcpyAsync cost three dispatches)
+// multi-grid union table: cell2leaf[cells[i]] = slots[i] for the first leaf of every occupied cell
+__global__ void __launch_bounds__(256) k_scatter_heads(const int* __restrict__ cells, const int* __restrict__ slots,
+                                                      int n, int* __restrict__ cell2leaf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) cell2leaf[cells[i]] = slots[i];
+}
+
 __global__ void __launch_bounds__(256) k_copy_soa(const float* __restrict__ x, const float* __restrict__ y,
                                                  const float* __restrict__ z, size_t n, float* __restrict__ ox,
                                                  float* __restrict__ oy, float* __restrict__ oz) {
@@ -1648,6 +1655,11 @@ int build_read_stamps(unsigned long long* out) {
   (void)out;
   return 0;
 #endif
+}
+
+void launch_scatter_heads(const int* cells, const int* slots, size_t n, int* cell2leaf, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_scatter_heads, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, cells, slots, (int)n, cell2leaf);
 }
 
 int finalize_blocks(int max_leaves) { return (max_leaves + 63) / 64; }

@@ -120,6 +120,38 @@ int main() {
          std::fabs(nv - ndt.getNearestVoxelTransformationLikelihood()) < 1e-9 && off <= 0.5 + 1e-6 &&
          cells.getLeaf(mid.first) == &mid.second && cells.getLeaf((size_t)-1) == nullptr;
   }
+  // multi-grid face [RECALLED tier4 names]: the target split into two tiles with string ids
+  {
+    ndt_hip::MultiGridNormalDistributionsTransform<PointT, PointT> mg;
+    mg.setResolution(1.0f);
+    mg.setMaximumIterations(50);
+    mg.setTransformationEpsilon(1e-4);
+    mg.setStepSize(0.1);
+    auto left = std::make_shared<Cloud>(), right = std::make_shared<Cloud>();
+    for (const auto& p : tgt->points) {
+      if (p.x < 1.0f) left->points.push_back(p);
+      if (p.x > -1.0f) right->points.push_back(p);
+    }
+    mg.addTarget(left, "tile_left");
+    mg.addTarget(right, "tile_right");
+    mg.createVoxelKdtree();
+    const int st0 = mg.lastStatus();
+    mg.setInputSource(src);
+    Cloud o4;
+    mg.computeTransformation(o4, guess);
+    ndt_hip::Matrix4f T4 = mg.getFinalTransformation();
+    double e4 = 0;
+    for (int r = 0; r < 3; ++r) e4 += (T4[12 + r] - gt[12 + r]) * (T4[12 + r] - gt[12 + r]);
+    const size_t union_leaves = mg.getTargetCells().getLeaves().size();
+    mg.removeTarget("tile_left");
+    Cloud o5;
+    mg.computeTransformation(o5, guess);   // the union is gone until it is re-created
+    const int st1 = mg.lastStatus();
+    std::printf("multigrid: create=%d converged_err=%.5f union_leaves=%zu ids=%zu after_remove_status=%d\n", st0, std::sqrt(e4),
+                union_leaves, mg.getCurrentMapIDs().size(), st1);
+    ok = ok && st0 == NDT_OK && std::sqrt(e4) < 0.05 && union_leaves > cells.getLeaves().size() &&
+         mg.getCurrentMapIDs().size() == 1 && st1 == NDT_ERR_NO_TARGET;
+  }
   // svn_ndt-shaped adapter: K = 8 particles, Gauss-Newton Hessian, one launch per iteration
   ndt_hip::SvnNormalDistributionsTransform<PointT, PointT> svn;
   svn.setResolution(1.0f);

@@ -63,6 +63,12 @@ def test_invalid_arguments_are_rejected(pkg):
     assert L.ndt_align(None, None, None) == -1
     assert L.ndt_get_grid_info(None, None) == -1
     assert L.ndt_destroy(None) == 0
+    # multi-grid and view entry points: null handle / null cloud
+    assert L.ndt_multigrid_add_target(None, 1, None, 0, 12) == -1
+    assert L.ndt_multigrid_remove_target(None, 1) == -1
+    assert L.ndt_multigrid_create_kdtree(None) == -1
+    assert L.ndt_multigrid_count(None) == -1
+    assert L.ndt_set_source_device_view(None, None, None, None, 0) == -1
 
 
 def test_shard_range_partitions(pkg):
