@@ -5,11 +5,21 @@ import numpy as np
 import __graft_entry__ as ge
 pkg = ge.load_package(); S = pkg.synth
 for cname, cfg in (("C2", S.config_c2()), ("C3", S.config_c3())):
-    for mode in ("DIRECT7", "DIRECT1", "KDTREE"):
+    for mode in ("DIRECT7", "DIRECT1", "KDTREE", "DIRECT26", "MULTIGRID"):
         ndt = pkg.NormalDistributionsTransform(device_id=0, resolution=float(cfg["resolution"]), step_size=0.1,
                                                trans_epsilon=1e-4, max_iterations=35)
-        ndt.setNeighborhoodSearchMethod(getattr(pkg, mode))
-        ndt.setInputTarget(cfg["target"]); ndt.setInputSource(cfg["source"])
+        if mode == "MULTIGRID":   # the map as 2 x 2 tiles that overlap by 2 m, united by createVoxelKdtree
+            t = cfg["target"]; mx, my = np.median(t[:, 0]), np.median(t[:, 1])
+            t0 = time.perf_counter()
+            for k, (sx, sy) in enumerate(((-1, -1), (-1, 1), (1, -1), (1, 1))):
+                ndt.addTarget(t[(sx * (t[:, 0] - mx) > -2.0) & (sy * (t[:, 1] - my) > -2.0)], k)
+            t1 = time.perf_counter(); ndt.createVoxelKdtree(); t2 = time.perf_counter()
+            print("%s MULTIGRID 4 tiles: addTarget x4 %.1f ms, createVoxelKdtree %.1f ms, %d leaves" %
+                  (cname, 1e3 * (t1 - t0), 1e3 * (t2 - t1), ndt.getGridInfo()["n_leaves"]), flush=True)
+            ndt.setInputSource(cfg["source"])
+        else:
+            ndt.setNeighborhoodSearchMethod(getattr(pkg, mode))
+            ndt.setInputTarget(cfg["target"]); ndt.setInputSource(cfg["source"])
         for _ in range(3): ndt.align(cfg["guess"])
         ts = []
         for _ in range(10):
