@@ -96,6 +96,7 @@ struct ndt_handle {
   const float* vx = nullptr;          // the source as evaluated: the engine's own copy (sx/sy/sz) or,
   const float* vy = nullptr;          // after ndt_set_source_device_view, the caller's arrays
   const float* vz = nullptr;
+  unsigned int build_seq = 0;         // tag of the build whose completion the host polls for
   int n_cus = 0;                      // compute units of the device (a fused sort pass needs one per tile)
   DevBuf<double> leaf_sums;
   DevBuf<int> brows;                 // per-block bounds rows
@@ -347,12 +348,16 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
 
   HIP_TRY(h, hipEventRecord(h->ev0, s));
   bool built = false;
+  static const bool poll_env = [] { const char* e = getenv("NDT_BUILD_WAIT"); return !(e && std::strcmp(e, "sync") == 0); }();
+  const bool poll_done = poll_env && h->prm.wait_mode == NDT_WAIT_SPIN;
   for (int attempt = 0; attempt < 3; ++attempt) {
     const bool optimistic = clean_cap != 0 && clean_cap == h->cell2leaf.cap;
     const long long lim = std::numeric_limits<int32_t>::max();
     const long long cap_cells = optimistic ? (long long)h->cell2leaf.cap : lim;
     int passes = optimistic ? sort_passes_for_cells(cap_cells) : 0;
     h->gdh.h->status = -1;
+    const int done_tag = (int)((++h->build_seq << 1) & 0x7fffffffu) | 1;  // odd: never 0, never the previous one
+    h->small.h[10] = 0;
     launch_bounds_geometry(x, y, z, n, leaf, inv_leaf, cap_cells, passes, h->brows.p, h->tickets.p, h->gd.p, h->gdh.d,
                            optimistic ? h->stats.p : nullptr, optimistic ? dirty_slots : 0, h->cell2leaf.p,
                            h->cell2leaf.cap, h->nleaf.p, s);
@@ -383,10 +388,32 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
     FinalizeParams fp{h->prm.eig_inflation_ratio, h->prm.cov_mode};
     launch_finalize_leaves(h->xyz4.p, keys_sorted, vals_sorted, h->nleaf.p, h->leaf_start.p, h->leaf_cnt.p, max_leaves,
                            fp, h->leaf_sums.p, h->rec.p, h->stats.p, h->cell2leaf.p, h->fin_counts.p, h->tickets.p + 2,
-                           h->small.d + 8, s);
+                           h->small.d + 8, done_tag, s);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->ev1, s));
-    HIP_TRY(h, hipStreamSynchronize(s));
+    if (poll_done) {
+      // the last block of the last kernel writes {slots, accepted, tag} to pinned memory in one
+      // store: watching that word costs less than a stream synchronisation (which wakes this
+      // thread through the runtime's signal); every later launch is ordered behind the build by
+      // the stream anyway.  A build that does not report within 2 s is left to the runtime.
+      volatile int* done = h->small.h + 10;
+      const auto t_wait = std::chrono::steady_clock::now();
+      unsigned spins = 0;
+      while (*done != done_tag) {
+        _mm_pause();
+        if ((++spins & 0xfffu) == 0 &&
+            std::chrono::steady_clock::now() - t_wait > std::chrono::seconds(2)) break;
+      }
+      if (*done == done_tag) {
+        hipError_t q;
+        while ((q = hipEventQuery(h->ev1)) == hipErrorNotReady) _mm_pause();
+        HIP_TRY(h, q);
+      } else {
+        HIP_TRY(h, hipStreamSynchronize(s));
+      }
+    } else {
+      HIP_TRY(h, hipStreamSynchronize(s));
+    }
     const BuildGeom& bg = *h->gdh.h;
     if (optimistic && (bg.status == BG_CAPACITY || bg.status == BG_PASSES)) {
       // the cloud outgrew the dense grid (or the enqueued sort passes): nothing after the bounds

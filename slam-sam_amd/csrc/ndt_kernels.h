@@ -71,7 +71,8 @@ void launch_finalize_leaves(const float* xyz4, const uint32_t* keys_sorted, cons
                             int max_leaves, FinalizeParams fp, double* sums, VoxelRecord* rec, LeafStats* stats,
                             int* cell2leaf, int* block_ok /* finalize_blocks(max_leaves) ints, scratch */,
                             unsigned int* ticket /* zero, left at zero */,
-                            int* nleaf_host /* pinned: receives d_nleaf[0..1] */, hipStream_t s);
+                            int* nleaf_host /* pinned, 16-byte aligned: receives {d_nleaf[0], d_nleaf[1], done_tag, 0} in one store */,
+                            int done_tag, hipStream_t s);
 
 // out[i] = (float)(R x + t) in f64 (sliding-window target assembly); out arrays hold n floats
 // device-to-device copy of three SoA arrays in one launch

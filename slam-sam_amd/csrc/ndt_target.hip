@@ -1028,7 +1028,7 @@ __global__ void __launch_bounds__(THREADS) k_leaf_finalize(const uint32_t* __res
                                                            LeafStats* __restrict__ stats,
                                                            int* __restrict__ cell2leaf, int* __restrict__ block_ok,
                                                            unsigned int* __restrict__ ticket,
-                                                           int* __restrict__ nleaf_host) {
+                                                           int* __restrict__ nleaf_host, int done_tag) {
   constexpr int WAVES = THREADS / 64;
   __shared__ int s_ok[WAVES];
   __shared__ int s_last;
@@ -1063,8 +1063,9 @@ __global__ void __launch_bounds__(THREADS) k_leaf_finalize(const uint32_t* __res
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) total += s_ok[w];
     nleaf_p[1] = total;  // leaves that passed every check
-    nleaf_host[0] = nl;
-    nleaf_host[1] = total;
+    // one 16-byte store {slots, accepted, build tag, 0}: the host may poll the tag instead of waiting
+    // for the stream (nleaf_host is 16-byte aligned)
+    *reinterpret_cast<int4*>(nleaf_host) = make_int4(nl, total, done_tag, 0);
     __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
@@ -1667,7 +1668,7 @@ int finalize_blocks(int max_leaves) { return (max_leaves + 63) / 64; }
 void launch_finalize_leaves(const float* xyz4, const uint32_t* keys_sorted, const uint32_t* vals_sorted,
                             int* d_nleaf, const int* leaf_start, const int* leaf_cnt, int max_leaves,
                             FinalizeParams fp, double* sums, VoxelRecord* rec, LeafStats* stats, int* cell2leaf,
-                            int* block_ok, unsigned int* ticket, int* nleaf_host, hipStream_t s) {
+                            int* block_ok, unsigned int* ticket, int* nleaf_host, int done_tag, hipStream_t s) {
   if (max_leaves <= 0) return;
   size_t blocks = ((size_t)max_leaves * LANES_PER_LEAF + 255) / 256;
   if (blocks > (size_t)SUMS_BLOCKS_MAX) blocks = SUMS_BLOCKS_MAX;
@@ -1675,10 +1676,10 @@ void launch_finalize_leaves(const float* xyz4, const uint32_t* keys_sorted, cons
                      vals_sorted, d_nleaf, leaf_start, leaf_cnt, sums);
   if (build_tuning().finalize_threads == 256)
     hipLaunchKernelGGL(k_leaf_finalize<256>, dim3((unsigned)((max_leaves + 255) / 256)), dim3(256), 0, s, keys_sorted,
-                       d_nleaf, leaf_start, leaf_cnt, sums, fp, rec, stats, cell2leaf, block_ok, ticket, nleaf_host);
+                       d_nleaf, leaf_start, leaf_cnt, sums, fp, rec, stats, cell2leaf, block_ok, ticket, nleaf_host, done_tag);
   else
     hipLaunchKernelGGL(k_leaf_finalize<64>, dim3((unsigned)((max_leaves + 63) / 64)), dim3(64), 0, s, keys_sorted,
-                       d_nleaf, leaf_start, leaf_cnt, sums, fp, rec, stats, cell2leaf, block_ok, ticket, nleaf_host);
+                       d_nleaf, leaf_start, leaf_cnt, sums, fp, rec, stats, cell2leaf, block_ok, ticket, nleaf_host, done_tag);
 }
 
 }  // namespace ndt

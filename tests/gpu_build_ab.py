@@ -22,9 +22,9 @@ gi = ndt.getGridInfo()
 print("%%-44s build wall %%.1f us  device %%.1f us  (leaves %%d)" %% (sys.argv[1], 1e6 * float(np.median(W)), 1e3 * float(np.median(D)), gi["n_leaves"]), flush=True)
 ''' % ROOT
 SETS = [
-    ("classic passes (NDT_FUSED_SORT=0)", {"NDT_FUSED_SORT": "0"}),
-    ("fused passes", {"NDT_FUSED_SORT": "1"}),
-    ("classic, old shapes (512/U4/F64)", {"NDT_FUSED_SORT": "0", "NDT_BOUNDS_BLOCKS": "512", "NDT_BOUNDS_UNROLL": "4", "NDT_FINALIZE_THREADS": "64"}),
+    ("fused, host polls the done word", {}),
+    ("fused, hipStreamSynchronize", {"NDT_BUILD_WAIT": "sync"}),
+    ("classic passes, hipStreamSynchronize", {"NDT_FUSED_SORT": "0", "NDT_BUILD_WAIT": "sync"}),
 ]
 for rep in range(2):
     for name, env in SETS:

@@ -596,3 +596,23 @@ def test_crowded_voxels_across_sort_and_run_tiles(pkg, O):
         L, OL = ndt.getLeaves(), grid.export()
         assert L["count"].max() >= 12289
         assert_leaves_match(L, OL)
+
+
+@pytest.mark.parametrize("n", [8191, 8192, 8193, 16384, 24577, 65536, 100003, 262144, 300000])
+def test_build_at_tile_boundaries_of_the_fused_passes(pkg, O, n):
+    """Cloud sizes at and around multiples of the fused sort pass's 8192-pair tile (and of the run
+    search's 2048-key tile): voxel membership and counts bit for bit against the oracle, twice
+    (waiting build, optimistic build), with a few non-finite points thrown in."""
+    rng = np.random.default_rng(n)
+    tgt = (rng.normal(0, 1, (n, 3)) * np.array([14.0, 9.0, 1.5])).astype(np.float32)
+    tgt[rng.integers(0, n, 5)] = np.nan
+    kw = dict(resolution=0.7, step_size=0.1, trans_epsilon=1e-4, max_iterations=5, min_points_per_voxel=6)
+    grid = O.Grid(tgt, O.default_params(num_threads=4, **kw))
+    OL = grid.export()
+    ndt = pkg.NormalDistributionsTransform(device_id=0, **kw)
+    for rep in range(2):
+        ndt.setInputTarget(tgt)
+        L = ndt.getLeaves()
+        assert np.array_equal(L["cell"], OL["cell"]) and np.array_equal(L["count"], OL["count"])
+        np.testing.assert_allclose(L["mean"], OL["mean"], rtol=1e-12, atol=0)
+    assert ndt.buildCounters()[0] == 0
