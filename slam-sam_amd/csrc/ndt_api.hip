@@ -166,6 +166,8 @@ struct ndt_handle {
   // pre-launched evaluation (ndt_prelaunch): mailbox in BAR-mapped fine-grained device memory
   PoseMailbox* mbox = nullptr;
   bool mbox_tried = false;
+  bool mbox_tagged = true;            // the pose is published as tagged 16-byte slots
+  bool mbox_preload = false;          // the waiting kernel fetches its points before the pose arrives (measured: no gain)
   bool prelaunch_armed = false;       // inside ndt_align
   unsigned long long pre_seq = 0;     // sequence number of the kernel that is waiting, 0 = none
   bool pre_need_h = false;
@@ -471,6 +473,8 @@ EvalConsts make_eval_consts(const ndt_handle* h, bool need_h) {
   ec.need_hessian = need_h ? 1 : 0;
   ec.gauss_newton = h->prm.hessian_mode == NDT_HESSIAN_GAUSS_NEWTON ? 1 : 0;
   ec.multigrid = h->multi_active ? 1 : 0;
+  ec.mbox_tagged = h->mbox_tagged ? 1 : 0;
+  ec.mbox_preload = h->mbox_preload ? 1 : 0;
   return ec;
 }
 
@@ -594,9 +598,21 @@ bool ensure_mailbox(ndt_handle* h) {
   return true;
 }
 
-// pose first, sequence number last; write-combined BAR memory: fence in between and after
+// The pose goes through write-combined BAR memory.  Tagged form (default): 41 slots of 16 bytes
+// {seq, two pose words}, one store each, one fence -- the kernel needs no second look after the tag.
+// Plain form (NDT_MBOX_TAGGED=0): pose first, fence, sequence number last, fence.
 void publish_pose(ndt_handle* h, unsigned long long seq, const PoseConsts& pc) {
   static_assert(sizeof(PoseConsts) == 81 * sizeof(float), "PoseConsts is 81 packed floats");
+  if (h->mbox_tagged) {
+    unsigned int w[2 * MBOX_SLOTS] = {0};
+    std::memcpy(w, &pc, sizeof(PoseConsts));
+    for (int k = 0; k < MBOX_SLOTS; ++k) {
+      const __m128i v = _mm_set_epi32((int)w[2 * k + 1], (int)w[2 * k], (int)(unsigned int)(seq >> 32), (int)(unsigned int)seq);
+      _mm_store_si128(reinterpret_cast<__m128i*>(const_cast<unsigned int*>(h->mbox->slot[k])), v);
+    }
+    _mm_sfence();
+    return;
+  }
   std::memcpy(const_cast<unsigned int*>(h->mbox->words), &pc, sizeof(PoseConsts));
   _mm_sfence();
   *reinterpret_cast<volatile unsigned long long*>(&h->mbox->seq) = seq;
@@ -606,7 +622,13 @@ void publish_pose(ndt_handle* h, unsigned long long seq, const PoseConsts& pc) {
 // tells a waiting pre-launched kernel to leave (stream order does the rest)
 void quit_prelaunched(ndt_handle* h) {
   if (h->pre_seq == 0) return;
-  *reinterpret_cast<volatile unsigned long long*>(&h->mbox->seq) = h->pre_seq | MBOX_QUIT;
+  const unsigned long long q = h->pre_seq | MBOX_QUIT;
+  if (h->mbox_tagged) {
+    const __m128i v = _mm_set_epi32(0, 0, (int)(unsigned int)(q >> 32), (int)(unsigned int)q);
+    _mm_store_si128(reinterpret_cast<__m128i*>(const_cast<unsigned int*>(h->mbox->slot[0])), v);
+  } else {
+    *reinterpret_cast<volatile unsigned long long*>(&h->mbox->seq) = q;
+  }
   _mm_sfence();
   h->pre_seq = 0;
   h->n_prelaunch_quit++;
@@ -813,6 +835,12 @@ int ndt_create(const ndt_params* p, ndt_handle** out) {
   {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) h->n_cus = cus;
+  }
+  {  // A/B knobs of the pose hand-over to pre-launched kernels (profiles/r02_mailbox_ab.txt)
+    const char* t = getenv("NDT_MBOX_TAGGED");
+    const char* q = getenv("NDT_MBOX_PRELOAD");
+    h->mbox_tagged = !(t && atoi(t) == 0);
+    h->mbox_preload = q && atoi(q) != 0;
   }
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||

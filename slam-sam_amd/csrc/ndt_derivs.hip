@@ -647,22 +647,62 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
   // only behind the pair phase: a wave-0 prologue of 69 scalar-to-vector moves and four
   // serialised s_load waits used to sit in front of every block's first point load.
   float tab_word = 0.0f;
+  // exactly one source point per thread: the 32 accumulator words are only live from the
+  // per-point expansion to the block reduction, not across the pair loop
+  const int i = blockIdx.x * (int)blockDim.x + threadIdx.x;
+  float x = 0.0f, y = 0.0f, z = 0.0f;
   if (MBOX) {
+    // a pre-launched kernel has nothing to do until its pose arrives: its point does not depend
+    // on the pose, so it can be fetched now (one memory round trip off the critical path)
+    if (ec.mbox_preload && i < n) { x = sx[i]; y = sy[i]; z = sz[i]; }
     __shared__ float s_rt[12];
     __shared__ int s_go;
-    if (threadIdx.x == 0) {
-      int go = -1;  // timed out
-      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-      for (;;) {
-        const unsigned long long v = __hip_atomic_load(&mbox->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (v == seq) { go = 1; break; }
-        if (v == (seq | MBOX_QUIT)) { go = 0; break; }
-        if (__builtin_amdgcn_s_memrealtime() - t0 > MBOX_TIMEOUT_TICKS) break;  // every wave reaches an exit
-        __builtin_amdgcn_s_sleep(1);
+    if (ec.mbox_tagged) {
+      // the pose as 41 self-validating 16-byte slots: lane k of wave 0 watches slot k; when every
+      // tag is this launch's the words are already in registers
+      if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        const bool mine = lane < MBOX_SLOTS;
+        const __amdgpu_buffer_rsrc_t rm = slots_rsrc(mbox);
+        const unsigned int tag_lo = (unsigned int)seq, tag_hi = (unsigned int)(seq >> 32);
+        const unsigned int quit_hi = (unsigned int)((seq | MBOX_QUIT) >> 32);
+        u32x4 v;
+        v.x = v.y = v.z = v.w = 0u;
+        int go = -1;  // timed out
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+          asm volatile("" ::: "memory");  // re-issued on every trip
+          if (mine) v = __builtin_amdgcn_raw_buffer_load_b128(rm, (unsigned int)offsetof(PoseMailbox, slot) + lane * 16u, 0, AUX_SYSTEM);
+          const bool ok = !mine || (v.x == tag_lo && v.y == tag_hi);
+          const bool quit = lane == 0 && v.x == tag_lo && v.y == quit_hi;
+          if (__ballot(quit) != 0ull) { go = 0; break; }
+          if (__ballot(ok) == ~0ull) { go = 1; break; }
+          if (__builtin_amdgcn_s_memrealtime() - t0 > MBOX_TIMEOUT_TICKS) break;  // every wave reaches an exit
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (go == 1 && mine) {
+          const int w0 = 2 * lane, w1 = 2 * lane + 1;
+          if (w0 < 12) s_rt[w0] = __uint_as_float(v.z); else tab.jang[w0 - 12] = __uint_as_float(v.z);  // runs on into hang[]
+          if (w1 < 12) s_rt[w1] = __uint_as_float(v.w); else if (w1 < 81) tab.jang[w1 - 12] = __uint_as_float(v.w);
+        }
+        if (lane == 0) s_go = go;
       }
-      s_go = go;
+      __syncthreads();
+    } else {
+      if (threadIdx.x == 0) {
+        int go = -1;  // timed out
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+          const unsigned long long v = __hip_atomic_load(&mbox->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (v == seq) { go = 1; break; }
+          if (v == (seq | MBOX_QUIT)) { go = 0; break; }
+          if (__builtin_amdgcn_s_memrealtime() - t0 > MBOX_TIMEOUT_TICKS) break;  // every wave reaches an exit
+          __builtin_amdgcn_s_sleep(1);
+        }
+        s_go = go;
+      }
+      __syncthreads();
     }
-    __syncthreads();
     const int go = s_go;
     if (go <= 0) {
       // quit: nothing to do.  timed out: say so in the result slots (word 31 = 2), the host
@@ -671,12 +711,14 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
         store_slot(slots_rsrc(flag), threadIdx.x * 16u, seq, threadIdx.x == EV_FAIL ? 2.0 : 0.0, true);
       return;
     }
-    if (threadIdx.x < 81) {  // the pose was published before seq (PCIe keeps posted writes in order)
-      const unsigned int w = __hip_atomic_load(&mbox->words[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      if (threadIdx.x < 12) s_rt[threadIdx.x] = __uint_as_float(w);
-      else tab.jang[threadIdx.x - 12] = __uint_as_float(w);  // runs on into hang[]
+    if (!ec.mbox_tagged) {
+      if (threadIdx.x < 81) {  // the pose was published before seq (PCIe keeps posted writes in order)
+        const unsigned int w = __hip_atomic_load(&mbox->words[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x < 12) s_rt[threadIdx.x] = __uint_as_float(w);
+        else tab.jang[threadIdx.x - 12] = __uint_as_float(w);  // runs on into hang[]
+      }
+      __syncthreads();
     }
-    __syncthreads();
 #pragma unroll
     for (int k = 0; k < 9; ++k) rt.R[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s_rt[k])));
 #pragma unroll
@@ -698,10 +740,6 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
       tab_word = reinterpret_cast<const float*>(ka + KERNARG_TABLES_OFFSET)[threadIdx.x];
     }
   }
-  // exactly one source point per thread: the 32 accumulator words are only live from the
-  // per-point expansion to the block reduction, not across the pair loop
-  const int i = blockIdx.x * (int)blockDim.x + threadIdx.x;
-  float x = 0.0f, y = 0.0f, z = 0.0f;
   PairAcc a;
   a.w[0] = a.w[1] = a.w[2] = 0.0;
 #pragma unroll
@@ -710,11 +748,11 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
   if (NB >= 2) {
     // every lane takes part (wave-wide trip count): lanes beyond n run with nothing to add
     extern __shared__ int lds_kd_list[];  // KD_CELLS x blockDim.x leaf indices
-    if (i < n) { x = sx[i]; y = sy[i]; z = sz[i]; }
+    if (!(MBOX && ec.mbox_preload) && i < n) { x = sx[i]; y = sy[i]; z = sz[i]; }
     NDT_STAMP(1);
     point_pairs_kd<MODE, NB == 2 || NB == 4, NB == 4>(a, x, y, z, g, cell2leaf, rec, rt, ec, lds_kd_list, i < n);
   } else if (i < n) {
-    x = sx[i]; y = sy[i]; z = sz[i];
+    if (!(MBOX && ec.mbox_preload)) { x = sx[i]; y = sy[i]; z = sz[i]; }
     NDT_STAMP(1);
 #if !(defined(NDT_ABL) && NDT_ABL >= 3)
     point_pairs<MODE, NB == 1>(a, x, y, z, g, cell2leaf, rec, rt, ec);

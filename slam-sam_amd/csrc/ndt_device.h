@@ -1,6 +1,7 @@
 // ndt_device.h -- structures shared by the host code and the HIP kernels of the
 // NDT engine (gfx950 only).  Not part of the public ABI (that is include/ndt_hip.h).
 #pragma once
+#include <cstddef>
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -73,11 +74,17 @@ struct PoseConsts {
 // one lane per block, for the host to publish the pose here -- fine-grained device memory the
 // host writes through the PCIe BAR.  words = the 81 floats of a PoseConsts; seq is written last.
 // seq == the kernel's own sequence number: go; seq == that number | MBOX_QUIT: leave at once.
+constexpr int MBOX_SLOTS = 41;  // 81 pose words, two per slot
 struct PoseMailbox {
   unsigned long long seq;
   unsigned int pad[2];
   unsigned int words[84];
+  unsigned int pad2[40];
+  // the same pose as self-validating 16-byte slots {seq lo, seq hi, word 2k, word 2k + 1}: one
+  // store of the host per slot, one load of one lane per slot, no second round trip after the tag
+  unsigned int slot[MBOX_SLOTS][4];
 };
+static_assert(offsetof(PoseMailbox, slot) == 512, "slots are 16-byte aligned");
 constexpr unsigned long long MBOX_QUIT = 1ull << 63;
 constexpr unsigned long long MBOX_TIMEOUT_TICKS = 2000000ull;  // 20 ms of the 100 MHz s_memrealtime clock
 
@@ -92,6 +99,8 @@ struct EvalConsts {
   int direct26;    // 1: every valid voxel of the 3x3x3 block around the point's cell (pclomp DIRECT26)
   int score_only;  // 1: score / NVTL / counts only, no gradient or Hessian (ndt_score_transform)
   int fixed_summer;  // 1: block 0 adds the partial rows (polls their tags), no tickets (single-level grids)
+  int mbox_tagged;  // pre-launched kernels: 1 = the pose arrives as tagged 16-byte slots, 0 = words then sequence number
+  int mbox_preload; // pre-launched kernels: 1 = the point is fetched before the wait for the pose
   int multigrid;   // 1: the table is a union of grids (radius search, leaves of a cell chained through VoxelRecord::pad)
 };
 
