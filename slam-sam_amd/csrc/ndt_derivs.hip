@@ -655,6 +655,9 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
     // a pre-launched kernel has nothing to do until its pose arrives: its point does not depend
     // on the pose, so it can be fetched now (one memory round trip off the critical path)
     if (ec.mbox_preload && i < n) { x = sx[i]; y = sy[i]; z = sz[i]; }
+    // (Pulling the whole record table into every XCD's L2 while waiting -- the L2s are cold at every
+    // launch -- was measured too: 16.2-16.6 us per evaluation against 16.2-16.45,
+    // profiles/r02_mailbox_prefetch_ab.txt.  Not kept.)
     __shared__ float s_rt[12];
     __shared__ int s_go;
     if (ec.mbox_tagged) {
