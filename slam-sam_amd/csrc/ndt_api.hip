@@ -1273,8 +1273,9 @@ int ndt_score_transform(ndt_handle* h, const float T[16], ndt_score* out) {
 
 int ndt_comm_info(char* path_buf, size_t cap) { return Reducer::library_info(path_buf, cap); }
 
+// overlap: host work that does not need this evaluation's results, run between the launch and the wait
 static int eval_batch(ndt_handle* h, const double* poses6, const float* transforms, int K, int compute_hessian,
-                      bool score_only, double* out) {
+                      bool score_only, double* out, void (*overlap)(void*) = nullptr, void* overlap_ctx = nullptr) {
   if (!h || !poses6 || !out || K <= 0) return NDT_ERR_INVALID_ARG;
   int rc = bind_device(h);
   if (rc) return rc;
@@ -1341,6 +1342,7 @@ static int eval_batch(ndt_handle* h, const double* poses6, const float* transfor
                      fast ? h->flag.d : nullptr, seq);
   HIP_TRY(h, hipGetLastError());
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, s));
+  if (overlap) overlap(overlap_ctx);
   if (fast) {
     rc = wait_slots(h, seq, K);
     if (rc) return rc;
@@ -1394,6 +1396,13 @@ static int eval_batch(ndt_handle* h, const double* poses6, const float* transfor
 int ndt_eval_derivatives(ndt_handle* h, const double* poses6, const float* transforms, int K,
                          int compute_hessian, double* out) {
   return eval_batch(h, poses6, transforms, K, compute_hessian, false, out);
+}
+
+// internal (ndt_svn.cpp; not in the public header): ndt_eval_derivatives with host work run while the
+// batched kernel is in flight
+int ndt_eval_derivatives_overlapped(ndt_handle* h, const double* poses6, const float* transforms, int K,
+                                    int compute_hessian, double* out, void (*overlap)(void*), void* ctx) {
+  return eval_batch(h, poses6, transforms, K, compute_hessian, false, out, overlap, ctx);
 }
 
 int ndt_score_transforms(ndt_handle* h, const float* transforms, int K, ndt_score* out) {

@@ -21,6 +21,12 @@
 #include "ndt_se3.h"
 
 using ndt::se3::Pose;
+
+// internal entry point of ndt_api.hip (not in the public header): ndt_eval_derivatives with host
+// work run between the launch and the wait
+extern "C" int ndt_eval_derivatives_overlapped(ndt_handle* h, const double* poses6, const float* transforms, int K,
+                                               int compute_hessian, double* out, void (*overlap)(void*), void* ctx);
+
 namespace se3 = ndt::se3;
 
 namespace {
@@ -167,7 +173,47 @@ int ndt_svn_align(ndt_handle* h, const ndt_svn_params* sp, const double prior16[
       p[0] = part[(size_t)k].t[0]; p[1] = part[(size_t)k].t[1]; p[2] = part[(size_t)k].t[2];
       p[3] = a[0]; p[4] = a[1]; p[5] = a[2];
     }
-    int rc = ndt_eval_derivatives(h, poses6.data(), transforms.data(), K, 1, words.data());
+    // The RBF kernel of every particle pair needs the particles only, not their derivatives: it is
+    // computed on the host while the batched Stage-1 launch is in flight (Stage 2's first half).
+    struct PairTablesCtx { const std::vector<Pose>* part; int K; double hb; std::vector<double>* kval; std::vector<double>* kgrad; std::vector<char>* kok; };
+    PairTablesCtx ptc{&part, K, hb, &kval, &kgrad, &kok};
+    auto pair_tables_thunk = [](void* vp) {
+      PairTablesCtx& c = *static_cast<PairTablesCtx*>(vp);
+      const int K = c.K;
+      const double hb = c.hb;
+      const std::vector<Pose>& part = *c.part;
+      std::vector<double>& kval = *c.kval;
+      std::vector<double>& kgrad = *c.kgrad;
+      std::vector<char>& kok = *c.kok;
+      // k(l, k) = exp(-|Log(l^-1 k)|^2 / h) and its gradient k * (-2/h) * Log(l^-1 k) (ref :213-244).
+      // Log((l^-1 k)^-1) = -Log(l^-1 k), so every pair is evaluated once: k(k, l) = k(l, k),
+      // grad(k, l) = -grad(l, k); the diagonal is k = 1, grad = 0.  (The reference evaluates all
+      // K^2 ordered pairs: identical up to the rounding of the logarithm.)
+      kval.assign((size_t)K * K, 1.0);
+      kgrad.assign((size_t)K * K * 6, 0.0);
+      kok.assign((size_t)K * K, 1);
+      for (int l = 0; l < K; ++l)
+        for (int k = l + 1; k < K; ++k) {
+          double d[6];
+          se3::logmap(se3::between(part[(size_t)l], part[(size_t)k]), d);
+          double sq = 0;
+          for (int i = 0; i < 6; ++i) sq += d[i] * d[i];
+          double kv, kg[6];
+          if (hb <= 1e-12) {
+            kv = sq < 1e-18 ? 1.0 : 0.0;
+            std::memset(kg, 0, sizeof(kg));
+          } else {
+            kv = std::exp(-sq / hb);
+            for (int i = 0; i < 6; ++i) kg[i] = kv * (-2.0 / hb) * d[i];
+          }
+          const bool ok = std::isfinite(kv) && all_finite(kg, 6);
+          const size_t a = (size_t)l * K + k, b = (size_t)k * K + l;
+          kval[a] = kval[b] = kv;
+          kok[a] = kok[b] = ok ? 1 : 0;
+          for (int i = 0; i < 6; ++i) { kgrad[6 * a + i] = kg[i]; kgrad[6 * b + i] = -kg[i]; }
+        }
+    };
+    int rc = ndt_eval_derivatives_overlapped(h, poses6.data(), transforms.data(), K, 1, words.data(), pair_tables_thunk, &ptc);
     if (rc != NDT_OK) return rc;
     for (int k = 0; k < K; ++k) {
       double s, g[6], H[36];
@@ -181,34 +227,8 @@ int ndt_svn_align(ndt_handle* h, const ndt_svn_params* sp, const double prior16[
       hfin[(size_t)k] = all_finite(HH, 36);
     }
     const double t2 = now_ms();
-    // ---- Stage 2: kernel-weighted mix + one 6x6 solve per particle (ref :789-839) ----
-    // k(l, k) = exp(-|Log(l^-1 k)|^2 / h) and its gradient k * (-2/h) * Log(l^-1 k) (ref :213-244).
-    // Log((l^-1 k)^-1) = -Log(l^-1 k), so every pair is evaluated once: k(k, l) = k(l, k),
-    // grad(k, l) = -grad(l, k); the diagonal is k = 1, grad = 0.  (The reference evaluates all
-    // K^2 ordered pairs: identical up to the rounding of the logarithm.)
-    kval.assign((size_t)K * K, 1.0);
-    kgrad.assign((size_t)K * K * 6, 0.0);
-    kok.assign((size_t)K * K, 1);
-    for (int l = 0; l < K; ++l)
-      for (int k = l + 1; k < K; ++k) {
-        double d[6];
-        se3::logmap(se3::between(part[(size_t)l], part[(size_t)k]), d);
-        double sq = 0;
-        for (int i = 0; i < 6; ++i) sq += d[i] * d[i];
-        double kv, kg[6];
-        if (hb <= 1e-12) {
-          kv = sq < 1e-18 ? 1.0 : 0.0;
-          std::memset(kg, 0, sizeof(kg));
-        } else {
-          kv = std::exp(-sq / hb);
-          for (int i = 0; i < 6; ++i) kg[i] = kv * (-2.0 / hb) * d[i];
-        }
-        const bool ok = std::isfinite(kv) && all_finite(kg, 6);
-        const size_t a = (size_t)l * K + k, b = (size_t)k * K + l;
-        kval[a] = kval[b] = kv;
-        kok[a] = kok[b] = ok ? 1 : 0;
-        for (int i = 0; i < 6; ++i) { kgrad[6 * a + i] = kg[i]; kgrad[6 * b + i] = -kg[i]; }
-      }
+    // ---- Stage 2: kernel-weighted mix + one 6x6 solve per particle (ref :789-839); the pair
+    // tables were filled while Stage 1 ran ----
     for (int k = 0; k < K; ++k) {
       double phi[6] = {0, 0, 0, 0, 0, 0}, Ht[36] = {0};
       for (int l = 0; l < K; ++l) {
