@@ -170,6 +170,9 @@ struct ndt_handle {
   bool mbox_preload = false;          // the waiting kernel fetches its points before the pose arrives (measured: no gain)
   bool prelaunch_armed = false;       // inside ndt_align
   unsigned long long pre_seq = 0;     // sequence number of the kernel that is waiting, 0 = none
+  int pre_buf = 0;                    // ... and the result buffer (0 / 1) it will write
+  int prelaunch_strikes = 0;          // consecutive aligns in which a waiting kernel gave up
+  int flag_toggle = 0;                // result buffer of the latest single-pose launch
   bool pre_need_h = false;
   int64_t n_prelaunch_used = 0, n_prelaunch_quit = 0, n_prelaunch_timeouts = 0;
 
@@ -555,8 +558,8 @@ bool slots_complete(const volatile unsigned long long* slots, unsigned long long
   return true;
 }
 
-int wait_slots(ndt_handle* h, unsigned long long seq, int K = 1) {
-  const volatile unsigned long long* f = h->flag.h;
+int wait_slots(ndt_handle* h, unsigned long long seq, int K = 1, int first = 0) {
+  const volatile unsigned long long* f = h->flag.h + (size_t)first * 2 * EV_WORDS;
   const auto t0 = std::chrono::steady_clock::now();
   unsigned int spins = 0;
   auto all_complete = [&] {
@@ -598,18 +601,22 @@ bool ensure_mailbox(ndt_handle* h) {
   return true;
 }
 
-// The pose goes through write-combined BAR memory.  Tagged form (default): 41 slots of 16 bytes
-// {seq, two pose words}, one store each, one fence -- the kernel needs no second look after the tag.
-// Plain form (NDT_MBOX_TAGGED=0): pose first, fence, sequence number last, fence.
+// The pose goes through write-combined BAR memory.  Tagged form (default): 82 granules of 8 bytes
+// {launch tag, word}, ONE aligned 64-bit volatile store each (never split by the compiler, the CPU or
+// a partially flushed write-combining buffer), one fence -- the kernel needs no second look after the
+// tag.  Plain form (NDT_MBOX_TAGGED=0): pose first, fence, sequence number last, fence.
+static inline void mbox_store_granule(PoseMailbox* m, int k, unsigned int tag, unsigned int word) {
+  *reinterpret_cast<volatile unsigned long long*>(&m->gran[k][0]) = (unsigned long long)tag | ((unsigned long long)word << 32);
+}
+
 void publish_pose(ndt_handle* h, unsigned long long seq, const PoseConsts& pc) {
   static_assert(sizeof(PoseConsts) == 81 * sizeof(float), "PoseConsts is 81 packed floats");
   if (h->mbox_tagged) {
-    unsigned int w[2 * MBOX_SLOTS] = {0};
+    unsigned int w[81];
     std::memcpy(w, &pc, sizeof(PoseConsts));
-    for (int k = 0; k < MBOX_SLOTS; ++k) {
-      const __m128i v = _mm_set_epi32((int)w[2 * k + 1], (int)w[2 * k], (int)(unsigned int)(seq >> 32), (int)(unsigned int)seq);
-      _mm_store_si128(reinterpret_cast<__m128i*>(const_cast<unsigned int*>(h->mbox->slot[k])), v);
-    }
+    const unsigned int tag = mbox_tag32(seq);
+    for (int k = 0; k < 81; ++k) mbox_store_granule(h->mbox, k, tag, w[k]);
+    mbox_store_granule(h->mbox, MBOX_GRANULES - 1, tag, 0u);
     _mm_sfence();
     return;
   }
@@ -622,13 +629,8 @@ void publish_pose(ndt_handle* h, unsigned long long seq, const PoseConsts& pc) {
 // tells a waiting pre-launched kernel to leave (stream order does the rest)
 void quit_prelaunched(ndt_handle* h) {
   if (h->pre_seq == 0) return;
-  const unsigned long long q = h->pre_seq | MBOX_QUIT;
-  if (h->mbox_tagged) {
-    const __m128i v = _mm_set_epi32(0, 0, (int)(unsigned int)(q >> 32), (int)(unsigned int)q);
-    _mm_store_si128(reinterpret_cast<__m128i*>(const_cast<unsigned int*>(h->mbox->slot[0])), v);
-  } else {
-    *reinterpret_cast<volatile unsigned long long*>(&h->mbox->seq) = q;
-  }
+  if (h->mbox_tagged) mbox_store_granule(h->mbox, MBOX_GRANULES - 1, mbox_tag32(h->pre_seq), MBOX_CTRL_QUIT);
+  else *reinterpret_cast<volatile unsigned long long*>(&h->mbox->seq) = h->pre_seq | MBOX_QUIT;
   _mm_sfence();
   h->pre_seq = 0;
   h->n_prelaunch_quit++;
@@ -647,7 +649,7 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
   }
   HIP_TRY(h, h->result.ensure(EV_WORDS));
   {
-    int rc = ensure_flag_slots(h, 1);
+    int rc = ensure_flag_slots(h, 2);  // two result buffers, used in turn (below)
     if (rc) return rc;
   }
   const bool dev_out = h->red.wants_device_buffer();
@@ -665,9 +667,17 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
                          ensure_mailbox(h);
   unsigned long long seq = 0;
   bool via_mailbox = false;
+  // Consecutive single-pose launches write their results to ALTERNATING host buffers: a pre-launched
+  // kernel runs ahead of the host, and one that gives up waiting for its pose (this thread frozen for
+  // 20 ms -- a cgroup-throttled or oversubscribed host does that) writes its notice while the result
+  // of its predecessor may still be unread.  With one shared buffer that notice replaced the unread
+  // result and the host waited for tags that were gone ("finished without publishing", found by the
+  // soak under host contention, tests/gpu_mbox_stress.py).
+  int buf = 0;
   if (h->pre_seq != 0) {
     if (prelaunch && h->pre_need_h == need_h) {  // the kernel for this evaluation is already waiting on the device
       seq = h->pre_seq;
+      buf = h->pre_buf;
       h->pre_seq = 0;
       {  // test seam: hold the pose back so that the waiting kernel gives up (NDT_DEBUG_PUBLISH_DELAY_MS)
         static const int delay_ms = [] { const char* e = getenv("NDT_DEBUG_PUBLISH_DELAY_MS"); return e ? atoi(e) : 0; }();
@@ -682,9 +692,10 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
   }
   if (!via_mailbox) {
     seq = g_launch_seq.fetch_add(1, std::memory_order_relaxed);
+    buf = (h->flag_toggle ^= 1);
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, s));
     launch_derivatives(px, py, pz, h->n_src, h->geom, h->cell2leaf.p, h->rec.p, pc, nullptr, 1, ec, h->partials.p,
-                       h->counters.p, d_out, s, spin ? h->flag.d : nullptr, seq);
+                       h->counters.p, d_out, s, spin ? h->flag.d + (size_t)buf * 2 * EV_WORDS : nullptr, seq);
     HIP_TRY(h, hipGetLastError());
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, s));
   }
@@ -693,8 +704,9 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
     // start when that one has finished and wait for its pose (or for the order to leave)
     h->pre_seq = g_launch_seq.fetch_add(1, std::memory_order_relaxed);
     h->pre_need_h = need_h;
+    h->pre_buf = (h->flag_toggle ^= 1);
     launch_derivatives(px, py, pz, h->n_src, h->geom, h->cell2leaf.p, h->rec.p, pc, nullptr, 1, ec, h->partials.p,
-                       h->counters.p, d_out, s, h->flag.d, h->pre_seq, h->mbox);
+                       h->counters.p, d_out, s, h->flag.d + (size_t)h->pre_buf * 2 * EV_WORDS, h->pre_seq, h->mbox);
     HIP_TRY(h, hipGetLastError());
   }
   if (dev_out) {
@@ -703,7 +715,7 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
     HIP_TRY(h, hipMemcpyAsync(h->result.h, h->dres.p, EV_WORDS * sizeof(double), hipMemcpyDeviceToHost, s));
   }
   if (spin) {
-    int rc = wait_slots(h, seq);
+    int rc = wait_slots(h, seq, 1, buf);
     if (rc) return rc;
   } else {
     HIP_TRY(h, hipStreamSynchronize(s));
@@ -718,7 +730,7 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
   }
   double words[EV_WORDS];
   if (spin) {
-    for (int v = 0; v < EV_WORDS; ++v) std::memcpy(&words[v], &h->flag.h[2 * v + 1], sizeof(double));
+    for (int v = 0; v < EV_WORDS; ++v) std::memcpy(&words[v], &h->flag.h[((size_t)buf * EV_WORDS + v) * 2 + 1], sizeof(double));
   } else {
     std::memcpy(words, h->result.h, sizeof(words));
   }
@@ -731,10 +743,11 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
   // never produces a non-finite score from finite records
   if (words[EV_FAIL] == 2.0 && via_mailbox) {
     // the pre-launched kernel gave up waiting for its pose (this thread was away for > 20 ms):
-    // nothing was evaluated.  Stop pre-launching on this handle and evaluate the ordinary way.
+    // nothing was evaluated.  Evaluate the ordinary way, and stop pre-launching for this align.
     h->n_prelaunch_timeouts++;
     quit_prelaunched(h);
-    h->prm.prelaunch = NDT_PRELAUNCH_OFF;
+    h->prelaunch_armed = false;  // ordinary launches for the rest of this align; the next align tries again
+    if (++h->prelaunch_strikes >= 3) h->prm.prelaunch = NDT_PRELAUNCH_OFF;  // three aligns in a row: a chronically starved host
     return evaluate(h, p, T, need_h, out, score_only);
   }
   if (words[EV_FAIL] != 0.0 || !std::isfinite(words[EV_SCORE])) {
@@ -1243,8 +1256,10 @@ int ndt_align(ndt_handle* h, const float guess[16], ndt_result* out) {
   EvalFn fn = [h](const double* p, const float* T, bool need_h, Eval* e) { return evaluate(h, p, T, need_h, e); };
   const int64_t n_total = h->n_src_global >= 0 ? h->n_src_global : (int64_t)h->n_src;
   h->prelaunch_armed = true;
+  const int64_t timeouts0 = h->n_prelaunch_timeouts;
   rc = newton_align(h->prm, n_total, guess, fn, out, /*hessian_in_trials=*/true);
   h->prelaunch_armed = false;
+  if (h->n_prelaunch_timeouts == timeouts0) h->prelaunch_strikes = 0;
   quit_prelaunched(h);  // the kernel enqueued for an evaluation that never came
   out->ms_device = h->tm.ms_eval_kernel_total - dev_ms0;
   return rc;

@@ -343,14 +343,24 @@ __device__ __forceinline__ void point_pairs_kd(PairAcc& a, float x, float y, flo
   int trips = count;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) trips = max(trips, __shfl_xor(trips, off));
-  for (int j = 0; j < trips; ++j) {
-    const bool have = j < count;
-    if (!CHAIN) {
-      const int sl = have ? lds_list[j * stride + (int)threadIdx.x] : 0;
-      const VoxelRecord r = rec[sl];
+  if (!CHAIN) {
+    // software-pipelined: the record of trip j + 1 is requested before trip j is worked on, so the
+    // trips do not pay one L2 / MALL round trip each (8-9 trips per wave on C3)
+    VoxelRecord rn = rec[count > 0 ? lds_list[(int)threadIdx.x] : 0];
+    for (int j = 0; j < trips; ++j) {
+      const bool have = j < count;
+      const VoxelRecord r = rn;
+      const int nx = j + 1 < count ? lds_list[(j + 1) * stride + (int)threadIdx.x] : 0;
+      if (j + 1 < trips) rn = rec[nx];
+      __builtin_amdgcn_sched_barrier(0);  // keeps the load above the pair arithmetic
       const bool present = have && (!RADIUS || kd_within(r, xt, yt, zt, ec.kd_radius2));
       pair_update<MODE>(a, r, xt, yt, zt, ec, present);
-    } else {
+    }
+    return;
+  }
+  for (int j = 0; j < trips; ++j) {
+    const bool have = j < count;
+    {
       int sl = have ? lds_list[j * stride + (int)threadIdx.x] : -1;
       while (__ballot(sl >= 0) != 0ull) {  // every lane of the wave leaves together
         const bool live = sl >= 0;
@@ -661,23 +671,23 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
     __shared__ float s_rt[12];
     __shared__ int s_go;
     if (ec.mbox_tagged) {
-      // the pose as 41 self-validating 16-byte slots: lane k of wave 0 watches slot k; when every
-      // tag is this launch's the words are already in registers
+      // the pose as 82 self-validating 8-byte granules {tag, word} (PoseMailbox): lane k < 41 of wave 0
+      // watches granules 2k and 2k + 1 with one 16-byte load; when every tag is this launch's the
+      // words are already in registers.  Granule 81 is the control word (lane 40's second).
       if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
-        const bool mine = lane < MBOX_SLOTS;
+        const bool mine = lane < MBOX_GRANULES / 2;
         const __amdgpu_buffer_rsrc_t rm = slots_rsrc(mbox);
-        const unsigned int tag_lo = (unsigned int)seq, tag_hi = (unsigned int)(seq >> 32);
-        const unsigned int quit_hi = (unsigned int)((seq | MBOX_QUIT) >> 32);
+        const unsigned int tag = mbox_tag32(seq);
         u32x4 v;
         v.x = v.y = v.z = v.w = 0u;
         int go = -1;  // timed out
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         for (;;) {
           asm volatile("" ::: "memory");  // re-issued on every trip
-          if (mine) v = __builtin_amdgcn_raw_buffer_load_b128(rm, (unsigned int)offsetof(PoseMailbox, slot) + lane * 16u, 0, AUX_SYSTEM);
-          const bool ok = !mine || (v.x == tag_lo && v.y == tag_hi);
-          const bool quit = lane == 0 && v.x == tag_lo && v.y == quit_hi;
+          if (mine) v = __builtin_amdgcn_raw_buffer_load_b128(rm, (unsigned int)offsetof(PoseMailbox, gran) + lane * 16u, 0, AUX_SYSTEM);
+          const bool ok = !mine || (v.x == tag && v.z == tag);
+          const bool quit = lane == MBOX_GRANULES / 2 - 1 && v.z == tag && v.w == MBOX_CTRL_QUIT;
           if (__ballot(quit) != 0ull) { go = 0; break; }
           if (__ballot(ok) == ~0ull) { go = 1; break; }
           if (__builtin_amdgcn_s_memrealtime() - t0 > MBOX_TIMEOUT_TICKS) break;  // every wave reaches an exit
@@ -685,7 +695,7 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
         }
         if (go == 1 && mine) {
           const int w0 = 2 * lane, w1 = 2 * lane + 1;
-          if (w0 < 12) s_rt[w0] = __uint_as_float(v.z); else tab.jang[w0 - 12] = __uint_as_float(v.z);  // runs on into hang[]
+          if (w0 < 12) s_rt[w0] = __uint_as_float(v.y); else tab.jang[w0 - 12] = __uint_as_float(v.y);  // runs on into hang[]
           if (w1 < 12) s_rt[w1] = __uint_as_float(v.w); else if (w1 < 81) tab.jang[w1 - 12] = __uint_as_float(v.w);
         }
         if (lane == 0) s_go = go;

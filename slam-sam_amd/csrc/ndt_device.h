@@ -74,17 +74,27 @@ struct PoseConsts {
 // one lane per block, for the host to publish the pose here -- fine-grained device memory the
 // host writes through the PCIe BAR.  words = the 81 floats of a PoseConsts; seq is written last.
 // seq == the kernel's own sequence number: go; seq == that number | MBOX_QUIT: leave at once.
-constexpr int MBOX_SLOTS = 41;  // 81 pose words, two per slot
+constexpr int MBOX_GRANULES = 82;  // 81 pose words + one control word
+constexpr unsigned int MBOX_CTRL_QUIT = 0x51554954u;  // "QUIT"
 struct PoseMailbox {
+  // plain form (NDT_MBOX_TAGGED=0): pose words first, sequence number last
   unsigned long long seq;
   unsigned int pad[2];
   unsigned int words[84];
   unsigned int pad2[40];
-  // the same pose as self-validating 16-byte slots {seq lo, seq hi, word 2k, word 2k + 1}: one
-  // store of the host per slot, one load of one lane per slot, no second round trip after the tag
-  unsigned int slot[MBOX_SLOTS][4];
+  // tagged form: 82 self-validating 8-byte granules {32-bit launch tag, 32-bit word} -- granule k < 81
+  // carries pose word k, granule 81 the control word (0, or MBOX_CTRL_QUIT).  The host writes every
+  // granule with ONE aligned 64-bit store: the largest store x86 and a partially flushed
+  // write-combining buffer are certain to keep whole.  (A first version used 16-byte slots written
+  // through _mm_store_si128, which the compiler may -- and did -- emit as narrower stores: a
+  // write-combining buffer flushed between them showed the kernel a new tag beside old bytes, once in
+  // some 10^5 evaluations on a loaded host.)  Lane k < 41 of wave 0 reads granules 2k and 2k + 1 with one
+  // 16-byte load and checks both tags.
+  unsigned int gran[MBOX_GRANULES][2];
 };
-static_assert(offsetof(PoseMailbox, slot) == 512, "slots are 16-byte aligned");
+static_assert(offsetof(PoseMailbox, gran) == 512, "granules are 16-byte aligned in pairs");
+// the 32-bit tag of a launch: odd (never the 0 of a fresh mailbox), unique for 2^31 launches
+__host__ __device__ inline unsigned int mbox_tag32(unsigned long long seq) { return ((unsigned int)seq << 1) | 1u; }
 constexpr unsigned long long MBOX_QUIT = 1ull << 63;
 constexpr unsigned long long MBOX_TIMEOUT_TICKS = 2000000ull;  // 20 ms of the 100 MHz s_memrealtime clock
 
@@ -99,7 +109,7 @@ struct EvalConsts {
   int direct26;    // 1: every valid voxel of the 3x3x3 block around the point's cell (pclomp DIRECT26)
   int score_only;  // 1: score / NVTL / counts only, no gradient or Hessian (ndt_score_transform)
   int fixed_summer;  // 1: block 0 adds the partial rows (polls their tags), no tickets (single-level grids)
-  int mbox_tagged;  // pre-launched kernels: 1 = the pose arrives as tagged 16-byte slots, 0 = words then sequence number
+  int mbox_tagged;  // pre-launched kernels: 1 = the pose arrives as tagged 8-byte granules, 0 = words then sequence number
   int mbox_preload; // pre-launched kernels: 1 = the point is fetched before the wait for the pose
   int multigrid;   // 1: the table is a union of grids (radius search, leaves of a cell chained through VoxelRecord::pad)
 };

@@ -24,7 +24,13 @@ for name, src, n in shapes:
     ndt.align(g); ref = ndt.getResult()
     t0 = time.perf_counter(); evals = 0
     for i in range(n):
-        ndt.align(g, return_transform=False)
+        try:
+            ndt.align(g, return_transform=False)
+        except pkg.NdtError as e:
+            bad += 1
+            print("FAILED", name, "align", i, e, "counters (used, quit, timeouts)", ndt.prelaunchCounters(), flush=True)
+            if bad > 5: sys.exit(1)
+            continue
         evals += ndt.getNumEvaluations()
         if i % 97 == 0 or i == n - 1:
             r = ndt.getResult()
