@@ -427,3 +427,39 @@ def test_prelaunched_evaluations_survive_a_starved_host():
     assert p.returncode == 0, p.stderr[-2000:]
     line = [ln for ln in p.stdout.splitlines() if "aligns under host contention" in ln][0]
     assert " 0 failures, 0 mismatches" in line, p.stdout[-2000:]
+
+
+def test_two_engines_on_two_threads(pkg, S):
+    """Two engines of one process driven from two threads at once (rebuild + align, each on its own
+    stream, mailbox and result buffers): pre-launched kernels of one wait on the device while the
+    other builds (fused sort passes) and evaluates.  Every result equals the single-threaded one."""
+    import threading
+    cfgs = [S.config_c2(), S.config_c1()]
+    kws = [dict(resolution=1.0, step_size=0.1, trans_epsilon=1e-4, max_iterations=35)] * 2
+    refs = []
+    for cfg, kw in zip(cfgs, kws):
+        ndt = pkg.NormalDistributionsTransform(device_id=0, **kw)
+        ndt.setInputTarget(cfg["target"]); ndt.setInputSource(cfg["source"])
+        refs.append((ndt.align(cfg["guess"]).copy(), ndt.getResult()["score"], ndt.getLeaves()["count"].sum()))
+    errors = []
+
+    def worker(k):
+        try:
+            cfg, kw = cfgs[k], kws[k]
+            ndt = pkg.NormalDistributionsTransform(device_id=0, **kw)
+            for i in range(150):
+                ndt.setInputTarget(cfg["target"])
+                ndt.setInputSource(cfg["source"])
+                T = ndt.align(cfg["guess"])
+                if not np.array_equal(T, refs[k][0]) or ndt.getResult()["score"] != refs[k][1]:
+                    errors.append((k, i, "result"))
+                if i % 50 == 0 and ndt.getLeaves()["count"].sum() != refs[k][2]:
+                    errors.append((k, i, "leaves"))
+        except Exception as e:   # noqa: BLE001 -- reported below
+            errors.append((k, "exception", repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in ts: t.start()
+    for t in ts: t.join(timeout=300)
+    assert not any(t.is_alive() for t in ts)
+    assert errors == []
