@@ -181,7 +181,7 @@ typedef struct ndt_grid_info {
   int64_t n_leaves;        /* valid voxels */
   int64_t n_cells;         /* dx*dy*dz of the dense index grid */
   int64_t n_target_points;
-  double ms_build;         /* device time of the last target build */
+  double ms_build;         /* time of the last target build: device time (HIP events) while kernel timing is enabled, wall time of the call otherwise */
 } ndt_grid_info;
 
 /* one derivative evaluation: [score, g(6), H upper-tri (21), nvtl_sum,

@@ -351,7 +351,13 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
     h->run_seq = 0;
   }
 
-  HIP_TRY(h, hipEventRecord(h->ev0, s));
+  // device time of the build by HIP events when kernel timing is on (ndt_enable_kernel_timing; bench.py's
+  // instrumented pass); otherwise ms_build is the wall time of this call and the two event records, the
+  // event query and the elapsed-time call (3-4 us of host time) are saved
+  static const int events_env = [] { const char* e = getenv("NDT_BUILD_EVENTS"); return e ? atoi(e) : -1; }();
+  const bool build_events = events_env >= 0 ? events_env != 0 : h->timing;
+  const auto t_build0 = std::chrono::steady_clock::now();
+  if (build_events) HIP_TRY(h, hipEventRecord(h->ev0, s));
   bool built = false;
   static const bool poll_env = [] { const char* e = getenv("NDT_BUILD_WAIT"); return !(e && std::strcmp(e, "sync") == 0); }();
   const bool poll_done = poll_env && h->prm.wait_mode == NDT_WAIT_SPIN;
@@ -395,7 +401,7 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
                            fp, h->leaf_sums.p, h->rec.p, h->stats.p, h->cell2leaf.p, h->fin_counts.p, h->tickets.p + 2,
                            h->small.d + 8, done_tag, s);
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipEventRecord(h->ev1, s));
+    if (build_events) HIP_TRY(h, hipEventRecord(h->ev1, s));
     if (poll_done) {
       // the last block of the last kernel writes {slots, accepted, tag} to pinned memory in one
       // store: watching that word costs less than a stream synchronisation (which wakes this
@@ -410,9 +416,11 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
             std::chrono::steady_clock::now() - t_wait > std::chrono::seconds(2)) break;
       }
       if (*done == done_tag) {
-        hipError_t q;
-        while ((q = hipEventQuery(h->ev1)) == hipErrorNotReady) _mm_pause();
-        HIP_TRY(h, q);
+        if (build_events) {
+          hipError_t q;
+          while ((q = hipEventQuery(h->ev1)) == hipErrorNotReady) _mm_pause();
+          HIP_TRY(h, q);
+        }
       } else {
         HIP_TRY(h, hipStreamSynchronize(s));
       }
@@ -446,7 +454,8 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
   }
   if (!built) return fail(h, NDT_ERR_HIP, "voxel-grid build did not go through (internal)");
   float ms = 0;
-  HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  if (build_events) HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  else ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_build0).count();
   h->ms_build = ms;
   h->tm.ms_last_build = ms;
   h->n_slots = h->small.h[8];

@@ -22,10 +22,8 @@ gi = ndt.getGridInfo()
 print("%%-44s build wall %%.1f us  device %%.1f us  (leaves %%d)" %% (sys.argv[1], 1e6 * float(np.median(W)), 1e3 * float(np.median(D)), gi["n_leaves"]), flush=True)
 ''' % ROOT
 SETS = [
-    ("bounds 256 blocks x 8 points per trip", {}),
-    ("bounds 256 blocks x 16 points per trip", {"NDT_BOUNDS_UNROLL": "16"}),
-    ("bounds 128 blocks x 16", {"NDT_BOUNDS_UNROLL": "16", "NDT_BOUNDS_BLOCKS": "128"}),
-    ("bounds 512 blocks x 8", {"NDT_BOUNDS_BLOCKS": "512"}),
+    ("build timed by events (device time)", {"NDT_BUILD_EVENTS": "1"}),
+    ("no events (ms_build = wall)", {"NDT_BUILD_EVENTS": "0"}),
 ]
 for rep in range(2):
     for name, env in SETS:
