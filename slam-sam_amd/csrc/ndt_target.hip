@@ -1441,8 +1441,7 @@ void launch_transform_append(const float* x, const float* y, const float* z, siz
 // environment overrides are A/B knobs (profiles/r02_build_tickets.txt).
 struct BuildTuning {
   int bounds_blocks;     // NDT_BOUNDS_BLOCKS   (<= BOUNDS_BLOCKS)
-  int bounds_unroll;     // NDT_BOUNDS_UNROLL   4 | 8 | 16
-  int run_keys;          // NDT_RUN_KEYS        8 | 16 keys per thread in k_runs
+  int bounds_unroll;     // NDT_BOUNDS_UNROLL   4 | 8 (16 measured: no change)
   int finalize_threads;  // NDT_FINALIZE_THREADS 64 | 256
   int fused_sort;        // NDT_FUSED_SORT      0 | 1: one launch per sort digit where the cloud allows it
 };
@@ -1455,9 +1454,7 @@ const BuildTuning& build_tuning() {
     BuildTuning b;
     b.bounds_blocks = env("NDT_BOUNDS_BLOCKS", 256);
     if (b.bounds_blocks < 1 || b.bounds_blocks > BOUNDS_BLOCKS) b.bounds_blocks = BOUNDS_BLOCKS;
-    b.bounds_unroll = env("NDT_BOUNDS_UNROLL", 8);
-    if (b.bounds_unroll != 4 && b.bounds_unroll != 16) b.bounds_unroll = 8;
-    b.run_keys = env("NDT_RUN_KEYS", 8) == 16 ? 16 : 8;
+    b.bounds_unroll = env("NDT_BOUNDS_UNROLL", 8) == 4 ? 4 : 8;
     b.finalize_threads = env("NDT_FINALIZE_THREADS", 256) == 64 ? 64 : 256;
     b.fused_sort = env("NDT_FUSED_SORT", 1) != 0 ? 1 : 0;
     return b;
@@ -1482,11 +1479,7 @@ void launch_bounds_geometry(const float* x, const float* y, const float* z, size
                             long long cell_capacity, int planned_passes, int* rows, unsigned int* ticket,
                             BuildGeom* gd, BuildGeom* gd_host, const LeafStats* old_stats, int dirty_slots,
                             int* cell2leaf, size_t c2l_cap, int* d_nleaf, hipStream_t s) {
-  if (build_tuning().bounds_unroll == 16)
-    hipLaunchKernelGGL(k_bounds<16>, dim3((unsigned)bounds_rows(n)), dim3(256), 0, s, x, y, z, n, rows, ticket, leaf,
-                       inv_leaf, cell_capacity, planned_passes, gd, gd_host, old_stats, dirty_slots, cell2leaf, c2l_cap,
-                       d_nleaf);
-  else if (build_tuning().bounds_unroll == 8)
+  if (build_tuning().bounds_unroll == 8)
     hipLaunchKernelGGL(k_bounds<8>, dim3((unsigned)bounds_rows(n)), dim3(256), 0, s, x, y, z, n, rows, ticket, leaf,
                        inv_leaf, cell_capacity, planned_passes, gd, gd_host, old_stats, dirty_slots, cell2leaf, c2l_cap,
                        d_nleaf);
@@ -1628,28 +1621,15 @@ hipError_t launch_find_runs(const uint32_t* keys_sorted, size_t n, BuildGeom* gd
     }
     *seq = tag;
   }
-  if (build_tuning().run_keys == 16) {
-    const int blocks = (int)((n + 256 * 16 - 1) / (256 * 16));
-    if (run_tags) {
-      hipLaunchKernelGGL((k_runs<RUNS_FUSED, 16>), dim3(blocks), dim3(256), 0, s, keys_sorted, (int)n, gd, gd_host, min_pts,
-                         block_counts, block_offsets, ticket, run_tags, tag, d_nleaf, leaf_start, leaf_cnt);
-    } else {
-      hipLaunchKernelGGL((k_runs<RUNS_COUNT, 16>), dim3(blocks), dim3(256), 0, s, keys_sorted, (int)n, gd, gd_host, min_pts,
-                         block_counts, block_offsets, ticket, run_tags, tag, d_nleaf, leaf_start, leaf_cnt);
-      hipLaunchKernelGGL((k_runs<RUNS_EMIT, 16>), dim3(blocks), dim3(256), 0, s, keys_sorted, (int)n, gd, gd_host, min_pts,
-                         block_counts, block_offsets, ticket, run_tags, tag, d_nleaf, leaf_start, leaf_cnt);
-    }
+  const int blocks = runs_blocks(n);
+  if (run_tags) {
+    hipLaunchKernelGGL((k_runs<RUNS_FUSED, 8>), dim3(blocks), dim3(256), 0, s, keys_sorted, (int)n, gd, gd_host, min_pts,
+                       block_counts, block_offsets, ticket, run_tags, tag, d_nleaf, leaf_start, leaf_cnt);
   } else {
-    const int blocks = runs_blocks(n);
-    if (run_tags) {
-      hipLaunchKernelGGL((k_runs<RUNS_FUSED, 8>), dim3(blocks), dim3(256), 0, s, keys_sorted, (int)n, gd, gd_host, min_pts,
-                         block_counts, block_offsets, ticket, run_tags, tag, d_nleaf, leaf_start, leaf_cnt);
-    } else {
-      hipLaunchKernelGGL((k_runs<RUNS_COUNT, 8>), dim3(blocks), dim3(256), 0, s, keys_sorted, (int)n, gd, gd_host, min_pts,
-                         block_counts, block_offsets, ticket, run_tags, tag, d_nleaf, leaf_start, leaf_cnt);
-      hipLaunchKernelGGL((k_runs<RUNS_EMIT, 8>), dim3(blocks), dim3(256), 0, s, keys_sorted, (int)n, gd, gd_host, min_pts,
-                         block_counts, block_offsets, ticket, run_tags, tag, d_nleaf, leaf_start, leaf_cnt);
-    }
+    hipLaunchKernelGGL((k_runs<RUNS_COUNT, 8>), dim3(blocks), dim3(256), 0, s, keys_sorted, (int)n, gd, gd_host, min_pts,
+                       block_counts, block_offsets, ticket, run_tags, tag, d_nleaf, leaf_start, leaf_cnt);
+    hipLaunchKernelGGL((k_runs<RUNS_EMIT, 8>), dim3(blocks), dim3(256), 0, s, keys_sorted, (int)n, gd, gd_host, min_pts,
+                       block_counts, block_offsets, ticket, run_tags, tag, d_nleaf, leaf_start, leaf_cnt);
   }
   return hipGetLastError();
 }

@@ -616,3 +616,33 @@ def test_build_at_tile_boundaries_of_the_fused_passes(pkg, O, n):
         assert np.array_equal(L["cell"], OL["cell"]) and np.array_equal(L["count"], OL["count"])
         np.testing.assert_allclose(L["mean"], OL["mean"], rtol=1e-12, atol=0)
     assert ndt.buildCounters()[0] == 0
+
+
+def test_one_engine_many_targets_in_turn(pkg, S):
+    """One engine voxelises very different clouds one after the other (the dense index, the dirty-cell
+    reset, the sort plan, the tag tables of the fused launches and the optimistic path all carry state
+    from build to build): every grid equals the one a fresh engine builds, bit for bit."""
+    rng = np.random.default_rng(11)
+    clouds = [S.config_c1()["target"], S.config_c2()["target"], rng.uniform(-3, 3, (7, 3)).astype(np.float32),
+              S.config_c3()["target"][:300000], rng.uniform(-40, 40, (50000, 3)).astype(np.float32),
+              S.config_c2()["target"][:9000], S.config_c3()["target"][::3] + np.float32(250.0)]
+    kw = dict(resolution=1.0, step_size=0.1, trans_epsilon=1e-4, max_iterations=5)
+    fresh = []
+    for c in clouds:
+        e = pkg.NormalDistributionsTransform(device_id=0, **kw)
+        try:
+            e.setInputTarget(c); fresh.append(e.getLeaves())
+        except pkg.NdtError:
+            fresh.append(None)
+    ndt = pkg.NormalDistributionsTransform(device_id=0, **kw)
+    order = [0, 3, 2, 1, 4, 6, 5, 3, 3, 0, 2, 6, 1, 4, 5, 0]
+    for k in order:
+        if fresh[k] is None:
+            with pytest.raises(pkg.NdtError):
+                ndt.setInputTarget(clouds[k])
+            continue
+        ndt.setInputTarget(clouds[k])
+        L = ndt.getLeaves()
+        for f in ("cell", "count", "mean", "cov", "icov", "evals"):
+            assert np.array_equal(L[f], fresh[k][f]), (k, f)
+    assert ndt.buildCounters()[0] == 0
