@@ -332,7 +332,48 @@ __device__ __forceinline__ void point_pairs_kd(PairAcc& a, float x, float y, flo
   // column `threadIdx.x` of lds_list[KD_CELLS][blockDim.x]: conflict-free for a wave
   const int stride = (int)blockDim.x;
   int count = 0;
-  if (RADIUS && !CHAIN) {
+  bool filtered = false;  // the LDS column holds leaves that already passed the distance test
+  if (RADIUS && CHAIN) {
+    // multi-grid union: as for KDTREE below, with the chains walked at listing time (a lane follows
+    // the `pad` links of its own cells; only cells that several grids share have any).  A lane with
+    // more than KD_CELLS centroids within the radius (seven or more grids on top of each other) makes
+    // its wave take the unfiltered path below instead.
+    bool overflow = false;
+#pragma unroll
+    for (int n0 = 0; n0 < KD_CELLS; n0 += 9) {
+      double m[9][3], nxt[9];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        const VoxelRecord* rp = rec + (slot[n0 + q] >= 0 ? slot[n0 + q] : 0);
+        m[q][0] = rp->mean[0]; m[q][1] = rp->mean[1]; m[q][2] = rp->mean[2]; nxt[q] = rp->pad;
+      }
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        if (slot[n0 + q] < 0) continue;
+        int sl = slot[n0 + q];
+        double m0 = m[q][0], m1 = m[q][1], m2 = m[q][2], nx = nxt[q];
+        for (;;) {
+          const float ex = xt - (float)m0, ey = yt - (float)m1, ez = zt - (float)m2;
+          float d = ex * ex;
+          d = d + ey * ey;
+          d = d + ez * ez;
+          if (d < ec.kd_radius2) {
+            if (count < KD_CELLS) { lds_list[count * stride + (int)threadIdx.x] = sl; ++count; }
+            else overflow = true;
+          }
+          sl = (int)nx;
+          if (sl < 0) break;
+          const VoxelRecord* rp = rec + sl;
+          m0 = rp->mean[0]; m1 = rp->mean[1]; m2 = rp->mean[2]; nx = rp->pad;
+        }
+      }
+    }
+    filtered = __ballot(overflow) == 0ull;  // wave-uniform
+    if (!filtered) count = 0;
+  }
+  if (RADIUS && CHAIN && filtered) {
+    // (listed above)
+  } else if (RADIUS && !CHAIN) {
     // KDTREE: the distance test comes BEFORE the listing, on the centroids alone (24 bytes per occupied
     // cell, nine cells in flight at a time): a point has 9-11 occupied cells around it but only 3-4
     // centroids within one leaf size, and the wave runs max-over-lanes(listed) full pair updates --
@@ -378,6 +419,10 @@ __device__ __forceinline__ void point_pairs_kd(PairAcc& a, float x, float y, flo
       const int sl = have ? lds_list[j * stride + (int)threadIdx.x] : 0;
       const VoxelRecord r = rec[sl];
       pair_update<MODE>(a, r, xt, yt, zt, ec, have);  // (KDTREE: only centroids within the radius were listed)
+    } else if (RADIUS && filtered) {
+      const int sl = have ? lds_list[j * stride + (int)threadIdx.x] : 0;
+      const VoxelRecord r = rec[sl];
+      pair_update<MODE>(a, r, xt, yt, zt, ec, have);
     } else {
       int sl = have ? lds_list[j * stride + (int)threadIdx.x] : -1;
       while (__ballot(sl >= 0) != 0ull) {  // every lane of the wave leaves together

@@ -111,6 +111,17 @@ def test_one_grid_union_equals_kdtree_target_and_stacked_grids_add_up(pkg, O, S)
     assert e5["n_pairs"] == 5 * e0["n_pairs"] and e5["n_with_neighbors"] == e0["n_with_neighbors"]
     assert e5["score"] == pytest.approx(5 * e0["score"], rel=1e-12)
     np.testing.assert_allclose(e5["hessian"], 5 * e0["hessian"], rtol=1e-10, atol=1e-9 * np.abs(e0["hessian"]).max())
+    # nine copies: more than 27 centroids within the radius of many points -- their waves leave the
+    # filtered listing for the chain walk over all occupied cells
+    for k in range(4):
+        ndt.addTarget(cfg["target"], 40 + k)
+    ndt.createVoxelKdtree()
+    e9 = ndt.evalDerivatives(p)[0]
+    assert e9["n_pairs"] == 9 * e0["n_pairs"]
+    assert e9["score"] == pytest.approx(9 * e0["score"], rel=1e-12)
+    np.testing.assert_allclose(e9["gradient"], 9 * e0["gradient"], rtol=1e-10, atol=1e-9 * np.abs(e0["gradient"]).max())
+    for k in range(4):
+        ndt.removeTarget(40 + k)
     # grid parameters changed after a tile was stored: refused until the tile is added again
     ndt.setResolution(2.0)
     with pytest.raises(pkg.NdtError):
