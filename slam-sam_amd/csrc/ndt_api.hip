@@ -11,6 +11,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <limits>
 #include <string>
 #include <thread>
@@ -71,6 +75,59 @@ struct PinBuf {  // pinned, device-mapped host memory
 
 }  // namespace
 
+// A few persistent host threads for the AoS -> SoA repack of large uploads (spawning six std::threads
+// per upload cost more than 0.1 ms of a 0.6 ms hand-over).  Idle workers sleep on a condition variable.
+struct RepackPool {
+  std::vector<std::thread> th;
+  std::mutex m;
+  std::condition_variable cv, done_cv;
+  std::function<void()> job;
+  unsigned long gen = 0;
+  int pending = 0;
+  bool stop = false;
+  void ensure(unsigned n) {
+    while (th.size() < n)
+      th.emplace_back([this] {
+        unsigned long seen = 0;
+        for (;;) {
+          std::function<void()> f;
+          {
+            std::unique_lock<std::mutex> lk(m);
+            cv.wait(lk, [&] { return stop || gen != seen; });
+            if (stop) return;
+            seen = gen;
+            f = job;
+          }
+          f();
+          {
+            std::lock_guard<std::mutex> lk(m);
+            if (--pending == 0) done_cv.notify_all();
+          }
+        }
+      });
+  }
+  // every worker runs f once (f claims chunks from a shared counter); returns at once
+  void run(std::function<void()> f) {
+    std::lock_guard<std::mutex> lk(m);
+    job = std::move(f);
+    ++gen;
+    pending = (int)th.size();
+    cv.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(m);
+    done_cv.wait(lk, [&] { return pending == 0; });
+  }
+  ~RepackPool() {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      stop = true;
+      cv.notify_all();
+    }
+    for (auto& t : th) t.join();
+  }
+};
+
 struct ndt_handle {
   ndt_params prm;
   int device = -1;
@@ -88,6 +145,8 @@ struct ndt_handle {
   DevBuf<char> sort_tmp;
   DevBuf<int> nleaf;                 // [0] slots, [1] valid
   DevBuf<int> leaf_start, leaf_cnt, run_counts, run_offsets, fin_counts;
+  DevBuf<float> upl_tmp;              // device twin of the pinned staging buffer (chunk-major cloud)
+  std::unique_ptr<RepackPool> pool;   // repack workers of large uploads, created on first use
   DevBuf<uint32_t> sort_tags;         // tagged tile counts of the fused sort passes
   uint32_t sort_seq = 0;              // ... and their launch tag counter
   DevBuf<uint32_t> run_tags;          // tagged block leaf counts of the fused run search
@@ -231,36 +290,44 @@ int upload_soa(ndt_handle* h, const float* xyz, const float* x, const float* y, 
   HIP_TRY(h, dz.ensure(n));
   if (n == 0) return NDT_OK;
   HIP_TRY(h, h->stage.ensure(3 * n));
+  HIP_TRY(h, h->upl_tmp.ensure(3 * n));
   float* s = h->stage.h;
+  // Pinned staging and its device twin hold the cloud CHUNK BY CHUNK as [x | y | z] of the chunk's
+  // points, so that a chunk crosses PCIe in ONE copy (three per chunk were 24 copies of 0.5 MB for a
+  // 1M-point map: 0.45 ms where one 12 MB copy takes 0.22, tests/gpu_h2d_probe.py); one small kernel
+  // then writes the three SoA arrays.
+  // chunks of 128 k points: the copy of a chunk runs under the repack of the next (a scan of < 256 k points
+  // goes as one chunk on the calling thread: waking workers for it costs more than it saves)
+  constexpr size_t kChunk = 131072;
   auto repack = [=](size_t lo, size_t hi) {
+    float* b = s + 3 * lo;
+    const size_t len = hi - lo;
     if (xyz) {
       const char* base = reinterpret_cast<const char*>(xyz);
       for (size_t i = lo; i < hi; ++i) {
         const float* p = reinterpret_cast<const float*>(base + i * stride);
-        s[i] = p[0];
-        s[n + i] = p[1];
-        s[2 * n + i] = p[2];
+        b[i - lo] = p[0];
+        b[len + (i - lo)] = p[1];
+        b[2 * len + (i - lo)] = p[2];
       }
     } else {
-      std::memcpy(s + lo, x + lo, (hi - lo) * sizeof(float));
-      std::memcpy(s + n + lo, y + lo, (hi - lo) * sizeof(float));
-      std::memcpy(s + 2 * n + lo, z + lo, (hi - lo) * sizeof(float));
+      std::memcpy(b, x + lo, len * sizeof(float));
+      std::memcpy(b + len, y + lo, len * sizeof(float));
+      std::memcpy(b + 2 * len, z + lo, len * sizeof(float));
     }
   };
   auto copy_chunk = [&](size_t lo, size_t hi) -> hipError_t {
-    const size_t bytes = (hi - lo) * sizeof(float);
-    hipError_t e = hipMemcpyAsync(dx.p + lo, s + lo, bytes, hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(dy.p + lo, s + n + lo, bytes, hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(dz.p + lo, s + 2 * n + lo, bytes, hipMemcpyHostToDevice, h->stream);
-    return e;
+    return hipMemcpyAsync(h->upl_tmp.p + 3 * lo, s + 3 * lo, 3 * (hi - lo) * sizeof(float), hipMemcpyHostToDevice, h->stream);
   };
-  constexpr size_t kChunk = 131072;
   if (n < 2 * kChunk) {
+    // one chunk: [x | y | z] of all n points -- the unchunk kernel is told so through chunk = n
     repack(0, n);
     HIP_TRY(h, copy_chunk(0, n));
+    launch_unchunk_soa(h->upl_tmp.p, n, n, dx.p, dy.p, dz.p, h->stream);
   } else {
     const size_t nchunks = (n + kChunk - 1) / kChunk;
-    const unsigned nthreads = (unsigned)std::min<size_t>(n >= (size_t)1 << 19 ? 6 : 3, nchunks);
+    static const int threads_env = [] { const char* e = getenv("NDT_UPLOAD_THREADS"); return e ? atoi(e) : 0; }();
+    const unsigned nthreads = (unsigned)std::min<size_t>(threads_env > 0 ? (size_t)threads_env : (n >= (size_t)1 << 19 ? 6 : 3), nchunks);
     std::vector<std::atomic<int>> done(nchunks);
     for (auto& d : done) d.store(0, std::memory_order_relaxed);
     std::atomic<size_t> next{0};
@@ -272,17 +339,19 @@ int upload_soa(ndt_handle* h, const float* xyz, const float* x, const float* y, 
         done[c].store(1, std::memory_order_release);
       }
     };
-    std::vector<std::thread> pool;
-    pool.reserve(nthreads);
-    for (unsigned t = 0; t < nthreads; ++t) pool.emplace_back(worker);
+    if (!h->pool) h->pool.reset(new RepackPool());
+    h->pool->ensure(nthreads);
+    h->pool->run(worker);   // (workers beyond nthreads, left from a larger upload, just find no chunk)
     hipError_t err = hipSuccess;
     for (size_t c = 0; c < nchunks; ++c) {
-      while (!done[c].load(std::memory_order_acquire)) std::this_thread::yield();
+      while (!done[c].load(std::memory_order_acquire)) _mm_pause();
       if (err == hipSuccess) err = copy_chunk(c * kChunk, std::min(n, (c + 1) * kChunk));
     }
-    for (auto& t : pool) t.join();
+    h->pool->wait();        // `worker` and its captures live on this frame
     HIP_TRY(h, err);
+    launch_unchunk_soa(h->upl_tmp.p, n, kChunk, dx.p, dy.p, dz.p, h->stream);
   }
+  HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipStreamSynchronize(h->stream));  // staging buffer is reused
   return NDT_OK;
 }
@@ -883,7 +952,7 @@ int ndt_destroy(ndt_handle* h) {
   h->keys.release(); h->vals.release(); h->keys2.release(); h->vals2.release();
   h->sort_tmp.release(); h->nleaf.release(); h->leaf_start.release(); h->leaf_cnt.release();
   h->cell2leaf.release(); h->rec.release(); h->stats.release();
-  h->run_counts.release(); h->run_offsets.release(); h->fin_counts.release(); h->sort_tags.release(); h->run_tags.release(); h->xyz4.release(); h->leaf_sums.release();
+  h->run_counts.release(); h->run_offsets.release(); h->fin_counts.release(); h->upl_tmp.release(); h->sort_tags.release(); h->run_tags.release(); h->xyz4.release(); h->leaf_sums.release();
   h->brows.release(); h->tickets.release(); h->gd.release(); h->gdh.release();
   for (auto& kv : h->keyframes) { kv.second.x.release(); kv.second.y.release(); kv.second.z.release(); }
   h->keyframes.clear();

@@ -61,6 +61,8 @@ struct FinalizeParams {
   double eig_ratio;
   int cov_mode;  // 0 svn, 1 pcl (recalled)
 };
+// tmp: the cloud chunk by chunk as [x | y | z] of `chunk` points (the last chunk shorter) -> SoA arrays
+void launch_unchunk_soa(const float* tmp, size_t n, size_t chunk, float* x, float* y, float* z, hipStream_t s);
 // multi-grid union table: cell2leaf[cells[i]] = slots[i], i < n (device arrays)
 void launch_scatter_heads(const int* cells, const int* slots, size_t n, int* cell2leaf, hipStream_t s);
 int finalize_blocks(int max_leaves);

@@ -1397,6 +1397,19 @@ hipError_t sort_source_by_blocks(const float* x, const float* y, const float* z,
 }
 
 // three SoA arrays in one launch (three hipMemcpyAsync cost three dispatches)
+// host upload: tmp holds the cloud chunk by chunk as [x(chunk) | y(chunk) | z(chunk)] (one H2D copy per
+// chunk instead of three); this puts it into the three SoA arrays
+__global__ void __launch_bounds__(256) k_unchunk_soa(const float* __restrict__ tmp, size_t n, size_t chunk,
+                                                    float* __restrict__ x, float* __restrict__ y, float* __restrict__ z) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t lo = i / chunk * chunk, len = (n - lo < chunk) ? n - lo : chunk, off = i - lo;
+  const float* b = tmp + 3 * lo;
+  x[i] = b[off];
+  y[i] = b[len + off];
+  z[i] = b[2 * len + off];
+}
+
 // multi-grid union table: cell2leaf[cells[i]] = slots[i] for the first leaf of every occupied cell
 __global__ void __launch_bounds__(256) k_scatter_heads(const int* __restrict__ cells, const int* __restrict__ slots,
                                                       int n, int* __restrict__ cell2leaf) {
@@ -1641,6 +1654,11 @@ int build_read_stamps(unsigned long long* out) {
   (void)out;
   return 0;
 #endif
+}
+
+void launch_unchunk_soa(const float* tmp, size_t n, size_t chunk, float* x, float* y, float* z, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_unchunk_soa, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, tmp, n, chunk, x, y, z);
 }
 
 void launch_scatter_heads(const int* cells, const int* slots, size_t n, int* cell2leaf, hipStream_t s) {
