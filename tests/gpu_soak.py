@@ -41,6 +41,26 @@ for name, src, n in shapes:
             bad += 1
             print("MISMATCH (iterations)", name, i, flush=True)
     print("%-28s %6d aligns, %8d evaluations, %.1f s: %s" % (name, n, evals, time.perf_counter() - t0, "identical" if not bad else "MISMATCHES"), flush=True)
+# the whole step: rebuild (fused launches, tagged tables, done word) + align
+import hashlib
+def leaf_hash():
+    L = ndt.getLeaves()
+    h = hashlib.sha256()
+    for k in ("cell", "count", "mean", "icov"): h.update(np.ascontiguousarray(L[k]).tobytes())
+    return h.hexdigest()
+ndt.setInputTarget(cfg["target"]); ndt.setInputSource(cfg["source"])
+ndt.align(g); ref = ndt.getResult(); href = leaf_hash()
+t0 = time.perf_counter(); nsteps = max(500, reps // 4)
+for i in range(nsteps):
+    ndt.setInputTarget(cfg["target"] if i % 2 == 0 else cfg["target"][:900000])   # two sizes in turn: 123 / 110 tiles
+    if i % 2 == 0:
+        ndt.align(g, return_transform=False)
+        if ndt.getFinalNumIteration() != ref["iterations"]: bad += 1; print("MISMATCH (step, iterations)", i, flush=True)
+        if i % 200 == 0:
+            r = ndt.getResult()
+            if r["score"] != ref["score"] or not np.array_equal(r["T"], ref["T"]) or leaf_hash() != href:
+                bad += 1; print("MISMATCH (step)", i, flush=True)
+print("%-28s %6d steps, %.1f s: %s (fused-sort fallbacks %d)" % ("rebuild + align", nsteps, time.perf_counter() - t0, "identical" if not bad else "MISMATCHES", ndt.buildCounters()[0]), flush=True)
 # batched path
 p = ref["pose"]
 ndt.setInputSource(cfg["source"])
