@@ -225,7 +225,7 @@ struct ndt_handle {
   // pre-launched evaluation (ndt_prelaunch): mailbox in BAR-mapped fine-grained device memory
   PoseMailbox* mbox = nullptr;
   bool mbox_tried = false;
-  bool mbox_tagged = true;            // the pose is published as tagged 16-byte slots
+  bool mbox_tagged = true;            // the pose is published as tagged 8-byte granules
   bool mbox_preload = false;          // the waiting kernel fetches its points before the pose arrives (measured: no gain)
   bool prelaunch_armed = false;       // inside ndt_align
   unsigned long long pre_seq = 0;     // sequence number of the kernel that is waiting, 0 = none

@@ -84,11 +84,9 @@ struct PoseMailbox {
   unsigned int pad2[40];
   // tagged form: 82 self-validating 8-byte granules {32-bit launch tag, 32-bit word} -- granule k < 81
   // carries pose word k, granule 81 the control word (0, or MBOX_CTRL_QUIT).  The host writes every
-  // granule with ONE aligned 64-bit store: the largest store x86 and a partially flushed
-  // write-combining buffer are certain to keep whole.  (A first version used 16-byte slots written
-  // through _mm_store_si128, which the compiler may -- and did -- emit as narrower stores: a
-  // write-combining buffer flushed between them showed the kernel a new tag beside old bytes, once in
-  // some 10^5 evaluations on a loaded host.)  Lane k < 41 of wave 0 reads granules 2k and 2k + 1 with one
+  // granule with ONE aligned 64-bit store: the largest store that the compiler, x86 and a partially
+  // flushed write-combining buffer are all certain to keep whole (a first version used 16-byte slots
+  // written through _mm_store_si128).  Lane k < 41 of wave 0 reads granules 2k and 2k + 1 with one
   // 16-byte load and checks both tags.
   unsigned int gran[MBOX_GRANULES][2];
 };
