@@ -454,7 +454,7 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
     HIP_TRY(h, h->stats.ensure((size_t)max_leaves));
     bool in_b = false;
     if (fused && fused_sort) {
-      HIP_TRY(h, sort_cloud_fused(x, y, z, n, h->gd.p, h->gdh.d, h->xyz4.p, h->keys.p, h->keys2.p, h->vals.p, h->vals2.p,
+      HIP_TRY(h, sort_cloud_fused(x, y, z, n, fused_tile_for(n, h->n_cus), h->gd.p, h->gdh.d, h->xyz4.p, h->keys.p, h->keys2.p, h->vals.p, h->vals2.p,
                                   passes, h->sort_tags.p, &h->sort_seq, s, &in_b));
     } else {
       launch_cell_keys(x, y, z, n, h->gd.p, h->keys.p, h->xyz4.p, h->sort_tmp.p, s);

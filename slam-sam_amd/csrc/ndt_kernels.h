@@ -41,10 +41,12 @@ void launch_sort_first_count(const uint32_t* keys, size_t n, const BuildGeom* gd
 // that had to give up waiting leaves BG_SPIN in *gd / *gd_host (repeat it with the classic passes).
 bool fused_build_enabled();  // NDT_FUSED_SORT != 0 (default): fused sort passes and the fused run search
 bool fused_sort_fits(size_t n, int compute_units);
+int fused_tile_for(size_t n, int compute_units);  // pairs per tile (8192 up to 2 M points on 256 CUs, 16384 up to 4 M), 0 = classic passes
 size_t fused_table_words();
-hipError_t sort_cloud_fused(const float* x, const float* y, const float* z, size_t n, BuildGeom* gd, BuildGeom* gd_host,
-                            float* xyz4, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
-                            int passes, uint32_t* table, uint32_t* seq, hipStream_t s, bool* result_in_b);
+hipError_t sort_cloud_fused(const float* x, const float* y, const float* z, size_t n, int tile, BuildGeom* gd,
+                            BuildGeom* gd_host, float* xyz4, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a,
+                            uint32_t* vals_b, int passes, uint32_t* table, uint32_t* seq, hipStream_t s,
+                            bool* result_in_b);
 
 // runs of equal cell key with >= min_pts points get a leaf slot (ascending cell order);
 // block_counts / block_offsets: runs_blocks(n) ints each; d_nleaf[0] receives the total

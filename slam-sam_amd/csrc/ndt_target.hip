@@ -480,20 +480,23 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_scatter(const uint32_t* _
 // build with classic passes.
 constexpr int FUSED_THREADS = 1024;
 constexpr int FUSED_WAVES = FUSED_THREADS / 64;
-constexpr int FUSED_TILE = FUSED_THREADS * SORT_ROUNDS;
+constexpr int FUSED_TILE = FUSED_THREADS * SORT_ROUNDS;          // 8192 pairs: clouds up to 256 tiles = 2 M points
+constexpr int FUSED_BIG_ROUNDS = 2 * SORT_ROUNDS;
+constexpr int FUSED_BIG_TILE = FUSED_THREADS * FUSED_BIG_ROUNDS;  // 16384 pairs (128 KB of LDS staging): up to 4 M points
 constexpr int FUSED_MAX_TILES = 256;
 constexpr int FUSED_COLS = FUSED_THREADS / 64;  // tile rows read per trip (one per wave)
 constexpr unsigned long long FUSED_TIMEOUT_TICKS = 5000000ull;  // 50 ms of the 100 MHz clock
 
+template <int ROUNDS>
 __device__ __forceinline__ int fused_index(int tile, int wave, int round, int lane) {
-  return tile * FUSED_TILE + wave * (FUSED_TILE / FUSED_WAVES) + round * 64 + lane;
+  return tile * (FUSED_THREADS * ROUNDS) + wave * (ROUNDS * 64) + round * 64 + lane;
 }
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
 // FROM_POINTS: pass 0 straight from the cloud -- the cell key is computed here (k_cell_keys is
 // not launched), the packed float4 copy is written, and the values are the identity permutation.
-template <bool FROM_POINTS>
+template <bool FROM_POINTS, int ROUNDS>
 __global__ void __launch_bounds__(FUSED_THREADS) k_sort_pass(const float* __restrict__ x, const float* __restrict__ y,
                                                             const float* __restrict__ z, float4* __restrict__ xyz4,
                                                             const uint32_t* __restrict__ keys_in,
@@ -503,13 +506,14 @@ __global__ void __launch_bounds__(FUSED_THREADS) k_sort_pass(const float* __rest
                                                             int mute_tile /* test seam: this tile never publishes */,
                                                             uint32_t* __restrict__ keys_out,
                                                             uint32_t* __restrict__ vals_out) {
+  constexpr int TILE = FUSED_THREADS * ROUNDS;
   __shared__ int cnt[FUSED_WAVES][SORT_BINS];
   // the column partial sums, and later -- once they have been folded -- the tile in sorted order
-  __shared__ uint32_t scratch[2 * FUSED_TILE];
+  __shared__ uint32_t scratch[2 * TILE];
   int (*part_total)[SORT_BINS] = reinterpret_cast<int (*)[SORT_BINS]>(scratch);
   int (*part_before)[SORT_BINS] = reinterpret_cast<int (*)[SORT_BINS]>(scratch + FUSED_COLS * SORT_BINS);
   uint32_t* stage_k = scratch;
-  uint32_t* stage_v = scratch + FUSED_TILE;
+  uint32_t* stage_v = scratch + TILE;
   __shared__ int gbase[SORT_BINS];
   __shared__ int lbase[SORT_BINS];
   __shared__ int wsum[2 * SORT_BINS / 64];
@@ -520,22 +524,25 @@ __global__ void __launch_bounds__(FUSED_THREADS) k_sort_pass(const float* __rest
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tile = blockIdx.x;
   NDT_BSTAMP(pass, 0);
-  uint32_t key[SORT_ROUNDS], val[SORT_ROUNDS];
-  int rank[SORT_ROUNDS];
+  // the 16-round tile keeps 48 registers of (key, value, rank) per thread: its values are fetched only
+  // after the ranking (the loads land while the block waits for the table)
+  constexpr bool LATE_VALS = ROUNDS > 8;
+  uint32_t key[ROUNDS], val[ROUNDS];
+  int rank[ROUNDS];
   if (FROM_POINTS) {
     const GridGeom g = gd->g;
-    float a[SORT_ROUNDS], b[SORT_ROUNDS], c[SORT_ROUNDS];
+    float a[ROUNDS], b[ROUNDS], c[ROUNDS];
 #pragma unroll
-    for (int r = 0; r < SORT_ROUNDS; ++r) {  // all loads of the tile in flight before any use
-      const int i = fused_index(tile, wave, r, lane);
+    for (int r = 0; r < ROUNDS; ++r) {  // all loads of the tile in flight before any use
+      const int i = fused_index<ROUNDS>(tile, wave, r, lane);
       const int j = i < n ? i : 0;
       a[r] = x[j]; b[r] = y[j]; c[r] = z[j];
     }
 #pragma unroll
-    for (int r = 0; r < SORT_ROUNDS; ++r) {
-      const int i = fused_index(tile, wave, r, lane);
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int i = fused_index<ROUNDS>(tile, wave, r, lane);
       key[r] = (uint32_t)g.ncells;  // sentinel sorts behind every real cell
-      val[r] = (uint32_t)i;
+      if (!LATE_VALS) val[r] = (uint32_t)i;
       if (i < n) {
         xyz4[i] = make_float4(a[r], b[r], c[r], 0.0f);  // one 16-byte line per point for the per-voxel gather
         if (finite3(a[r], b[r], c[r])) {
@@ -546,10 +553,10 @@ __global__ void __launch_bounds__(FUSED_THREADS) k_sort_pass(const float* __rest
     }
   } else {
 #pragma unroll
-    for (int r = 0; r < SORT_ROUNDS; ++r) {
-      const int i = fused_index(tile, wave, r, lane);
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int i = fused_index<ROUNDS>(tile, wave, r, lane);
       key[r] = i < n ? keys_in[i] : 0u;
-      val[r] = i < n ? vals_in[i] : 0u;
+      if (!LATE_VALS) val[r] = i < n ? vals_in[i] : 0u;
     }
   }
   for (int d = threadIdx.x; d < FUSED_WAVES * SORT_BINS; d += FUSED_THREADS) (&cnt[0][0])[d] = 0;
@@ -563,8 +570,8 @@ __global__ void __launch_bounds__(FUSED_THREADS) k_sort_pass(const float* __rest
   // rank among the equal digits before it in the wave's 512 pairs (8 ballots per round)
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
-  for (int r = 0; r < SORT_ROUNDS; ++r) {
-    const bool valid = fused_index(tile, wave, r, lane) < n;
+  for (int r = 0; r < ROUNDS; ++r) {
+    const bool valid = fused_index<ROUNDS>(tile, wave, r, lane) < n;
     const uint32_t d = (key[r] >> shift) & digit_mask;
     unsigned long long same = __ballot(valid);
 #pragma unroll
@@ -579,6 +586,13 @@ __global__ void __launch_bounds__(FUSED_THREADS) k_sort_pass(const float* __rest
     __builtin_amdgcn_wave_barrier();
     if (valid && lower == 0) cnt[wave][d] = before + __popcll(same);
     __builtin_amdgcn_wave_barrier();
+  }
+  if (LATE_VALS) {
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int i = fused_index<ROUNDS>(tile, wave, r, lane);
+      val[r] = FROM_POINTS ? (uint32_t)i : (i < n ? vals_in[i] : 0u);
+    }
   }
   __syncthreads();
   NDT_BSTAMP(pass, 2);  // ranked
@@ -602,7 +616,7 @@ __global__ void __launch_bounds__(FUSED_THREADS) k_sort_pass(const float* __rest
     const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(table, 0, 0xFFFFFFFFu, 0x00020000);
     int tot[4] = {0, 0, 0, 0}, bef[4] = {0, 0, 0, 0};
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    constexpr int BATCH = 8;
+    constexpr int BATCH = ROUNDS <= 8 ? 8 : 2;  // (the 16-round variant holds 48 registers of pairs: fewer table words in flight)
     for (int r0 = wave; r0 < ntiles; r0 += BATCH * FUSED_COLS) {
       u32x4_t w[BATCH];
       for (;;) {
@@ -663,8 +677,8 @@ __global__ void __launch_bounds__(FUSED_THREADS) k_sort_pass(const float* __rest
   // contiguous runs instead of 64 separate places (a scattered wave store occupies the address
   // path for 64 cycles; 256 of them per CU were 7 us of a 16 us launch)
 #pragma unroll
-  for (int r = 0; r < SORT_ROUNDS; ++r) {
-    if (fused_index(tile, wave, r, lane) >= n) break;
+  for (int r = 0; r < ROUNDS; ++r) {
+    if (fused_index<ROUNDS>(tile, wave, r, lane) >= n) break;
     const uint32_t d = (key[r] >> shift) & digit_mask;
     const int p = lbase[d] + cnt[wave][d] + rank[r];
     stage_k[p] = key[r];
@@ -672,9 +686,9 @@ __global__ void __launch_bounds__(FUSED_THREADS) k_sort_pass(const float* __rest
   }
   __syncthreads();
   NDT_BSTAMP(pass, 4);  // staged
-  const int tile_n = min(FUSED_TILE, n - tile * FUSED_TILE);
+  const int tile_n = min(TILE, n - tile * TILE);
 #pragma unroll
-  for (int r = 0; r < SORT_ROUNDS; ++r) {
+  for (int r = 0; r < ROUNDS; ++r) {
     const int j = r * FUSED_THREADS + (int)threadIdx.x;
     if (j >= tile_n) break;
     const uint32_t k = stage_k[j];
@@ -1567,25 +1581,50 @@ hipError_t sort_pairs(void* temp, uint32_t* keys_a, uint32_t* keys_b, uint32_t* 
 
 // sized for the smaller tile, whatever the tuning
 // ---- fused passes (one launch per digit) ----
-int fused_tiles(size_t n) { return (int)((n + FUSED_TILE - 1) / FUSED_TILE); }
+int fused_tiles(size_t n, int tile) { return (int)((n + tile - 1) / tile); }
+// the tile size a cloud gets on a device with `compute_units` CUs (one tile per CU at most): 0 = none fits
+int fused_tile_for(size_t n, int compute_units) {
+  if (n == 0) return 0;
+  const int cap = compute_units < FUSED_MAX_TILES ? compute_units : FUSED_MAX_TILES;
+  if (fused_tiles(n, FUSED_TILE) <= cap) return FUSED_TILE;
+  if (fused_tiles(n, FUSED_BIG_TILE) <= cap) return FUSED_BIG_TILE;
+  return 0;
+}
 bool fused_build_enabled() { return build_tuning().fused_sort != 0; }
 // every block of a fused pass waits for all the others: one tile per compute unit at most (a
 // partitioned device -- CPX mode: 32 CUs -- takes the classic passes for anything above 256 k points)
 bool fused_sort_fits(size_t n, int compute_units) {
-  return n > 0 && fused_tiles(n) <= FUSED_MAX_TILES && fused_tiles(n) <= compute_units;
+  return fused_tile_for(n, compute_units) != 0;
 }
 size_t fused_table_words() { return (size_t)FUSED_MAX_TILES * SORT_BINS; }
 
-// Cell keys + stable sort by cell in `passes` launches, straight from the cloud.  `table`
-// (fused_table_words() words, zeroed at allocation and whenever *seq wraps) carries the tagged tile
-// counts; *seq is the engine's launch tag counter.  The result lands in (keys_b, vals_b) for an
+// Cell keys + stable sort by cell in `passes` launches, straight from the cloud.  `tile`: fused_tile_for();
+// `table` (fused_table_words() words, zeroed at allocation and whenever *seq wraps) carries the tagged
+// tile counts; *seq is the engine's launch tag counter.  The result lands in (keys_b, vals_b) for an
 // odd number of passes, (keys_a, vals_a) otherwise.
-hipError_t sort_cloud_fused(const float* x, const float* y, const float* z, size_t n, BuildGeom* gd, BuildGeom* gd_host,
-                            float* xyz4, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
-                            int passes, uint32_t* table, uint32_t* seq, hipStream_t s, bool* result_in_b) {
+template <int ROUNDS>
+static void launch_sort_pass(bool from_points, int ntiles, hipStream_t s, const float* x, const float* y, const float* z,
+                             float* xyz4, const uint32_t* kin, const uint32_t* vin, int n, int p, BuildGeom* gd,
+                             BuildGeom* gd_host, uint32_t* table, uint32_t tag, int mute_tile, uint32_t* kout,
+                             uint32_t* vout) {
+  if (from_points)
+    hipLaunchKernelGGL((k_sort_pass<true, ROUNDS>), dim3((unsigned)ntiles), dim3(FUSED_THREADS), 0, s, x, y, z,
+                       reinterpret_cast<float4*>(xyz4), (const uint32_t*)nullptr, (const uint32_t*)nullptr, n, p, gd,
+                       gd_host, ntiles, table, tag, mute_tile, kout, vout);
+  else
+    hipLaunchKernelGGL((k_sort_pass<false, ROUNDS>), dim3((unsigned)ntiles), dim3(FUSED_THREADS), 0, s,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float4*)nullptr, kin, vin, n,
+                       p, gd, gd_host, ntiles, table, tag, mute_tile, kout, vout);
+}
+
+hipError_t sort_cloud_fused(const float* x, const float* y, const float* z, size_t n, int tile, BuildGeom* gd,
+                            BuildGeom* gd_host, float* xyz4, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a,
+                            uint32_t* vals_b, int passes, uint32_t* table, uint32_t* seq, hipStream_t s,
+                            bool* result_in_b) {
   *result_in_b = false;
   if (n == 0) return hipSuccess;
-  const int ntiles = fused_tiles(n);
+  if (tile != FUSED_TILE && tile != FUSED_BIG_TILE) return hipErrorInvalidValue;
+  const int ntiles = fused_tiles(n, tile);
   // test seam: NDT_DEBUG_FUSED_MUTE_TILE=<t> makes tile t withhold its counts, so every block times out
   static const int mute_tile = [] { const char* e = getenv("NDT_DEBUG_FUSED_MUTE_TILE"); return e && *e ? atoi(e) : -1; }();
   uint32_t *kin = keys_a, *kout = keys_b, *vin = vals_a, *vout = vals_b;
@@ -1597,16 +1636,11 @@ hipError_t sort_cloud_fused(const float* x, const float* y, const float* z, size
       tag = 1u;
     }
     *seq = tag;
-    if (p == 0) {
-      // pass 0 writes into the "a" buffers' partners so that the ping-pong below stays uniform
-      hipLaunchKernelGGL(k_sort_pass<true>, dim3((unsigned)ntiles), dim3(FUSED_THREADS), 0, s, x, y, z,
-                         reinterpret_cast<float4*>(xyz4), (const uint32_t*)nullptr, (const uint32_t*)nullptr, (int)n, p,
-                         gd, gd_host, ntiles, table, tag, mute_tile, kout, vout);
-    } else {
-      hipLaunchKernelGGL(k_sort_pass<false>, dim3((unsigned)ntiles), dim3(FUSED_THREADS), 0, s, (const float*)nullptr,
-                         (const float*)nullptr, (const float*)nullptr, (float4*)nullptr, kin, vin, (int)n, p, gd, gd_host,
-                         ntiles, table, tag, mute_tile, kout, vout);
-    }
+    // (pass 0 reads the cloud and writes into the "b" buffers, so that the ping-pong below stays uniform)
+    if (tile == FUSED_TILE)
+      launch_sort_pass<SORT_ROUNDS>(p == 0, ntiles, s, x, y, z, xyz4, kin, vin, (int)n, p, gd, gd_host, table, tag, mute_tile, kout, vout);
+    else
+      launch_sort_pass<FUSED_BIG_ROUNDS>(p == 0, ntiles, s, x, y, z, xyz4, kin, vin, (int)n, p, gd, gd_host, table, tag, mute_tile, kout, vout);
     uint32_t* t = kin; kin = kout; kout = t;
     t = vin; vin = vout; vout = t;
   }

@@ -598,11 +598,12 @@ def test_crowded_voxels_across_sort_and_run_tiles(pkg, O):
         assert_leaves_match(L, OL)
 
 
-@pytest.mark.parametrize("n", [8191, 8192, 8193, 16384, 24577, 65536, 100003, 262144, 300000])
+@pytest.mark.parametrize("n", [8191, 8192, 8193, 16384, 24577, 65536, 100003, 262144, 300000, 2097152, 2097153, 2600001])
 def test_build_at_tile_boundaries_of_the_fused_passes(pkg, O, n):
     """Cloud sizes at and around multiples of the fused sort pass's 8192-pair tile (and of the run
-    search's 2048-key tile): voxel membership and counts bit for bit against the oracle, twice
-    (waiting build, optimistic build), with a few non-finite points thrown in."""
+    search's 2048-key tile), and around 256 tiles = 2 097 152 points where the 16384-pair tile takes
+    over: voxel membership and counts bit for bit against the oracle, twice (waiting build,
+    optimistic build), with a few non-finite points thrown in."""
     rng = np.random.default_rng(n)
     tgt = (rng.normal(0, 1, (n, 3)) * np.array([14.0, 9.0, 1.5])).astype(np.float32)
     tgt[rng.integers(0, n, 5)] = np.nan
