@@ -396,6 +396,18 @@ class NormalDistributionsTransform
     if (status_ == NDT_OK) n_src_ = 0;  // align()'s output cloud is not filled on this path
   }
 
+  // ---- clouds that are already in HBM (SoA float arrays on this engine's device) ----
+  // the target arrays are consumed by the build; the source arrays are viewed in place until the source
+  // is replaced (setInputSource's shared_ptr contract) -- or copied with copy = true
+  void setInputTargetDevice(const float* dx, const float* dy, const float* dz, size_t n) {
+    status_ = h_ ? ndt_set_target_device(h_, dx, dy, dz, n) : NDT_ERR_NO_DEVICE;
+  }
+  void setInputSourceDevice(const float* dx, const float* dy, const float* dz, size_t n, bool copy = false) {
+    if (!h_) { status_ = NDT_ERR_NO_DEVICE; return; }
+    status_ = copy ? ndt_set_source_device(h_, dx, dy, dz, n) : ndt_set_source_device_view(h_, dx, dy, dz, n);
+    if (status_ == NDT_OK) n_src_ = 0;  // align()'s output cloud is not filled on this path
+  }
+
   // ---- multi-grid target [RECALLED: tier4 ndt_omp multigrid_ndt_omp.h -- addTarget / removeTarget /
   // createVoxelKdtree with string ids; the reference names the class only in its build,
   // CMakeLists.txt:41-42, and no driver instantiates it] ----
