@@ -219,6 +219,11 @@ int ndt_set_source_device(ndt_handle* h, const float* dx, const float* dy, const
  * so they must stay valid and unchanged until the source is replaced -- pcl::Registration::
  * setInputSource's contract (it keeps the caller's shared_ptr; ref: run/pipeline.cpp:558). */
 int ndt_set_source_device_view(ndt_handle* h, const float* dx, const float* dy, const float* dz, size_t n);
+/* The engine may cache a block-ordered COPY of a viewed source (ndt_source_order).  After rewriting
+ * the viewed arrays in place (a reused scan buffer) call ndt_set_source_device_view again, or this
+ * notice (no copy, no launch): later aligns then re-derive whatever was cached from the arrays.
+ * Freeing the arrays while they are the source is the caller's error, as with the shared_ptr. */
+int ndt_source_changed(ndt_handle* h);
 
 /* Multi-grid target [RECALLED: tier4 ndt_omp's MultiGridNormalDistributionsTransform -- addTarget /
  * removeTarget / createVoxelKdtree -- named by the reference's build (CMakeLists.txt:41-42); its

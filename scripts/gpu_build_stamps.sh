@@ -1,5 +1,5 @@
 set -e
-cd $GRAFT_REPO_ROOT/slam-sam_amd/csrc
-rm -f build/ndt_target.o build/ndt_api.o
-make CXXFLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result -DNDT_STAMPS" > /dev/null 2>&1
-python $GRAFT_REPO_ROOT/tests/gpu_build_stamps.py 2>&1 | grep -v amdgpu.ids | tee $GRAFT_REPO_ROOT/gpurun_out/r02_build_stamps.txt
+# in-kernel stamps of the build kernels: a SEPARATE library (own object directory), the production
+# libndt_hip.so is not touched
+make -C $GRAFT_REPO_ROOT/slam-sam_amd/csrc VARIANT=stamps -j8 > /dev/null 2>&1
+NDT_HIP_LIB=$GRAFT_REPO_ROOT/slam-sam_amd/libndt_hip_stamps.so python $GRAFT_REPO_ROOT/tests/gpu_build_stamps.py 2>&1 | grep -v amdgpu.ids | tee $GRAFT_REPO_ROOT/gpurun_out/build_stamps.txt

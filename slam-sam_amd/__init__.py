@@ -132,7 +132,7 @@ ABI_SYMBOLS = [
     "ndt_result_covariance", "ndt_set_source_from_keyframe",
     "ndt_params_preset", "ndt_score_transform", "ndt_comm_info", "ndt_score_transforms",
     "ndt_xy_covariance_laplace", "ndt_propose_poses_to_search", "ndt_xy_covariance_multi_ndt",
-    "ndt_xy_covariance_multi_ndt_score",
+    "ndt_xy_covariance_multi_ndt_score", "ndt_source_changed",
 ]
 
 _lib = None
@@ -163,6 +163,7 @@ def lib():
         L.ndt_set_source_soa.argtypes = [vp, vp, vp, vp, C.c_size_t]
         L.ndt_set_source_device.argtypes = [vp, vp, vp, vp, C.c_size_t]
         L.ndt_set_source_device_view.argtypes = [vp, vp, vp, vp, C.c_size_t]
+        L.ndt_source_changed.argtypes = [vp]
         L.ndt_set_regularization_pose.argtypes = [vp, fp]
         L.ndt_clear_regularization_pose.argtypes = [vp]
         L.ndt_align.argtypes = [vp, fp, C.POINTER(Result)]
@@ -396,6 +397,10 @@ class NormalDistributionsTransform:
         (pcl::Registration::setInputSource keeps the caller's shared_ptr the same way)."""
         self._check(lib().ndt_set_source_device_view(self._h, dx, dy, dz, n))
         self._n_src = int(n)
+
+    def sourceChanged(self):
+        """The arrays of a viewed source were rewritten in place: drop whatever the engine cached of them."""
+        self._check(lib().ndt_source_changed(self._h))
 
     # --- multi-grid target [RECALLED: tier4 MultiGridNormalDistributionsTransform] ---
     def addTarget(self, cloud, target_id):

@@ -27,6 +27,7 @@
 #include "ndt_comm.h"
 #include "ndt_kernels.h"
 #include "ndt_newton.h"
+#include "ndt_repack_pool.h"
 
 using namespace ndt;
 
@@ -75,59 +76,6 @@ struct PinBuf {  // pinned, device-mapped host memory
 };
 
 }  // namespace
-
-// A few persistent host threads for the AoS -> SoA repack of large uploads (spawning six std::threads
-// per upload cost more than 0.1 ms of a 0.6 ms hand-over).  Idle workers sleep on a condition variable.
-struct RepackPool {
-  std::vector<std::thread> th;
-  std::mutex m;
-  std::condition_variable cv, done_cv;
-  std::function<void()> job;
-  unsigned long gen = 0;
-  int pending = 0;
-  bool stop = false;
-  void ensure(unsigned n) {
-    while (th.size() < n)
-      th.emplace_back([this] {
-        unsigned long seen = 0;
-        for (;;) {
-          std::function<void()> f;
-          {
-            std::unique_lock<std::mutex> lk(m);
-            cv.wait(lk, [&] { return stop || gen != seen; });
-            if (stop) return;
-            seen = gen;
-            f = job;
-          }
-          f();
-          {
-            std::lock_guard<std::mutex> lk(m);
-            if (--pending == 0) done_cv.notify_all();
-          }
-        }
-      });
-  }
-  // every worker runs f once (f claims chunks from a shared counter); returns at once
-  void run(std::function<void()> f) {
-    std::lock_guard<std::mutex> lk(m);
-    job = std::move(f);
-    ++gen;
-    pending = (int)th.size();
-    cv.notify_all();
-  }
-  void wait() {
-    std::unique_lock<std::mutex> lk(m);
-    done_cv.wait(lk, [&] { return pending == 0; });
-  }
-  ~RepackPool() {
-    {
-      std::lock_guard<std::mutex> lk(m);
-      stop = true;
-      cv.notify_all();
-    }
-    for (auto& t : th) t.join();
-  }
-};
 
 struct ndt_handle {
   ndt_params prm;
@@ -232,6 +180,9 @@ struct ndt_handle {
   unsigned long long pre_seq = 0;     // sequence number of the kernel that is waiting, 0 = none
   int pre_buf = 0;                    // ... and the result buffer (0 / 1) it will write
   int prelaunch_strikes = 0;          // consecutive aligns in which a waiting kernel gave up
+  bool prelaunch_suspended = false;   // three such aligns in a row (a chronically starved host): no more pre-launching
+                                      // on this handle until ndt_set_params is called -- the caller's ndt_params
+                                      // are never rewritten
   int flag_toggle = 0;                // result buffer of the latest single-pose launch
   bool pre_need_h = false;
   int64_t n_prelaunch_used = 0, n_prelaunch_quit = 0, n_prelaunch_timeouts = 0;
@@ -506,11 +457,14 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
       continue;
     }
     if (fused && bg.status == BG_SPIN) {
-      // a fused sort pass gave up waiting for its sibling blocks (the CUs were held by other
-      // work): no leaf was published and the old cells are already reset.  Once more with the
-      // classic three-launch passes, which never wait inside a kernel.
+      // a fused launch gave up waiting for its sibling blocks (the CUs were held by other work).
+      // Once more with the classic three-launch passes, which never wait inside a kernel.
+      // (k_runs<RUNS_FUSED> publishes a block's tag BEFORE it waits, so its last block can set nleaf > 0
+      // while a middle block gave up: k_leaf_finalize may then have written indices of stale slots into
+      // the grid.  The retry therefore does not trust the grid: full clear, geometry awaited.)
       fused = false;
       dirty_slots = 0;
+      clean_cap = 0;
       ++h->n_fused_sort_fallbacks;
       continue;
     }
@@ -637,6 +591,13 @@ bool slots_complete(const volatile unsigned long long* slots, unsigned long long
   return true;
 }
 
+// How long the host polls before it hands the wait to the runtime: every wait INSIDE the kernel is
+// bounded by MBOX_TIMEOUT_TICKS (20 ms: a pre-launched kernel waiting for its pose), and the launch
+// itself runs for tens of microseconds, so slots that have not appeared after 3 x that bound are not
+// "late" -- the kernel is queued behind foreign work, or it is gone.  hipStreamSynchronize is always
+// safe (it loses nothing): afterwards the slots are either there or the launch has failed.
+constexpr auto kHostSpinLimit = std::chrono::microseconds(3 * (MBOX_TIMEOUT_TICKS / 100));
+
 int wait_slots(ndt_handle* h, unsigned long long seq, int K = 1, int first = 0) {
   const volatile unsigned long long* f = h->flag.h + (size_t)first * 2 * EV_WORDS;
   const auto t0 = std::chrono::steady_clock::now();
@@ -647,8 +608,7 @@ int wait_slots(ndt_handle* h, unsigned long long seq, int K = 1, int first = 0) 
     return true;
   };
   while (!all_complete()) {
-    if ((++spins & 0xFFFF) == 0 &&
-        std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+    if ((++spins & 0x3FFF) == 0 && std::chrono::steady_clock::now() - t0 > kHostSpinLimit) {
       HIP_TRY(h, hipStreamSynchronize(h->stream));
       if (!all_complete()) {
         h->counters_zeroed = 0;  // the ticket words may be stale: re-zero them before the next launch
@@ -742,8 +702,8 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
   const float* px = h->src_sorted ? h->ox.p : h->vx;
   const float* py = h->src_sorted ? h->oy.p : h->vy;
   const float* pz = h->src_sorted ? h->oz.p : h->vz;
-  const bool prelaunch = spin && !score_only && h->prelaunch_armed && h->prm.prelaunch == NDT_PRELAUNCH_AUTO &&
-                         ensure_mailbox(h);
+  const bool prelaunch = spin && !score_only && h->prelaunch_armed && !h->prelaunch_suspended &&
+                         h->prm.prelaunch == NDT_PRELAUNCH_AUTO && ensure_mailbox(h);
   unsigned long long seq = 0;
   bool via_mailbox = false;
   // Consecutive single-pose launches write their results to ALTERNATING host buffers: a pre-launched
@@ -758,10 +718,12 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
       seq = h->pre_seq;
       buf = h->pre_buf;
       h->pre_seq = 0;
-      {  // test seam: hold the pose back so that the waiting kernel gives up (NDT_DEBUG_PUBLISH_DELAY_MS)
+#ifdef NDT_TEST_SEAMS
+      {  // test seam (libndt_hip_seams.so only): hold the pose back so that the waiting kernel gives up
         static const int delay_ms = [] { const char* e = getenv("NDT_DEBUG_PUBLISH_DELAY_MS"); return e ? atoi(e) : 0; }();
         if (delay_ms > 0 && h->n_prelaunch_used == 3) std::this_thread::sleep_for(std::chrono::milliseconds(delay_ms));
       }
+#endif
       publish_pose(h, seq, pc);
       via_mailbox = true;
       h->n_prelaunch_used++;
@@ -826,7 +788,20 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
     h->n_prelaunch_timeouts++;
     quit_prelaunched(h);
     h->prelaunch_armed = false;  // ordinary launches for the rest of this align; the next align tries again
-    if (++h->prelaunch_strikes >= 3) h->prm.prelaunch = NDT_PRELAUNCH_OFF;  // three aligns in a row: a chronically starved host
+    if (++h->prelaunch_strikes >= 3) h->prelaunch_suspended = true;  // three aligns in a row: a chronically starved host
+    return evaluate(h, p, T, need_h, out, score_only);
+  }
+  if (words[EV_FAIL] == 1.0 && via_mailbox) {
+    // Every block of a pre-launched kernel times out on its OWN clock: when the pose lands near the
+    // deadline (or the grid is larger than the machine, so that late blocks start after the first
+    // wave's 20 ms) some blocks compute while others have left, and the final sum then misses rows.
+    // Nothing usable was evaluated -- same remedy as a time-out: an ordinary launch of the same pose.
+    h->n_prelaunch_timeouts++;
+    quit_prelaunched(h);
+    h->prelaunch_armed = false;
+    h->counters_zeroed = 0;  // ticket mode: the partial tickets of the abandoned launch are not zero
+    HIP_TRY(h, hipStreamSynchronize(s));  // the abandoned grid has drained before its rows are reused
+    if (++h->prelaunch_strikes >= 3) h->prelaunch_suspended = true;
     return evaluate(h, p, T, need_h, out, score_only);
   }
   if (words[EV_FAIL] != 0.0 || !std::isfinite(words[EV_SCORE])) {
@@ -927,6 +902,7 @@ int ndt_create(const ndt_params* p, ndt_handle** out) {
   {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) h->n_cus = cus;
+    if (h->n_cus > 0) derivs_set_compute_units(h->n_cus);  // one block per CU is sized for THIS device (CPX partitions: 32)
   }
   {  // A/B knobs of the pose hand-over to pre-launched kernels (profiles/r02_mailbox_ab.txt)
     const char* t = getenv("NDT_MBOX_TAGGED");
@@ -993,6 +969,8 @@ int ndt_set_params(ndt_handle* h, const ndt_params* p) {
   if (p->source_order != h->prm.source_order) h->src_sorted = false;
   h->prm = *p;
   h->prm.device_id = dev;  // a handle never migrates
+  h->prelaunch_suspended = false;  // the caller has spoken: try again
+  h->prelaunch_strikes = 0;
   if (grid_changed && !rebuild) {
     // the target came through ndt_set_target_device and was consumed there: the grid cannot be
     // re-voxelised, and the old one must not be evaluated with the new constants.  The next
@@ -1092,6 +1070,14 @@ int ndt_set_source_device_view(ndt_handle* h, const float* dx, const float* dy, 
   if (rc) return rc;
   h->vx = dx; h->vy = dy; h->vz = dz;
   h->n_src = n;
+  h->src_sorted = false;
+  return NDT_OK;
+}
+
+// The caller has rewritten the arrays of a viewed source in place (a reused scan buffer): the cached
+// block-ordered copy (maybe_sort_source) is stale.  Cheap: no copy, no launch.
+int ndt_source_changed(ndt_handle* h) {
+  if (!h) return NDT_ERR_INVALID_ARG;
   h->src_sorted = false;
   return NDT_OK;
 }

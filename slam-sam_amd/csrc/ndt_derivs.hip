@@ -526,7 +526,7 @@ constexpr int ROW_WORDS = 2 * EV_WORDS;   // 32 x {tag, value}
 constexpr int AUX_AGENT = 16;             // sc1
 constexpr int AUX_SYSTEM = 17;            // sc0 sc1
 constexpr int SUM_BATCH = 20;             // rows per thread and memory round trip (80 VGPRs in flight; 25 would spill)
-constexpr unsigned int SPIN_LIMIT = 1u << 22;
+constexpr unsigned long long SUM_TIMEOUT_TICKS = 10000000ull;  // 100 ms of the 100 MHz clock: no launch of this kernel runs that long
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t slots_rsrc(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xFFFFFFFFu, 0x00020000);
@@ -561,7 +561,7 @@ __device__ __forceinline__ void sum_rows(__amdgpu_buffer_rsrc_t rows, unsigned i
   double s = 0.0;
   for (int b0 = first + c; b0 < end; b0 += SUM_BATCH * ncols) {
     u32x4 t[SUM_BATCH];
-    unsigned int tries = 0;
+    const unsigned long long t_wait0 = __builtin_amdgcn_s_memrealtime();
     for (;;) {
       asm volatile("" ::: "memory");  // the loads below must be re-issued on every trip
       bool ok = true;
@@ -577,9 +577,10 @@ __device__ __forceinline__ void sum_rows(__amdgpu_buffer_rsrc_t rows, unsigned i
 #pragma unroll
       for (int k = 0; k < SUM_BATCH; ++k) ok = ok && t[k].x == tag_lo && t[k].y == tag_hi;
       if (ok) break;
-      if (++tries > SPIN_LIMIT) {
-        // cannot happen (every row was issued before its ticket); exit anyway and say so: word 31
-        // of an evaluation is 0 by construction, the host turns anything else into NDT_ERR_HIP
+      if (__builtin_amdgcn_s_memrealtime() - t_wait0 > SUM_TIMEOUT_TICKS) {
+        // a row that never comes (its block left without computing: a pre-launched grid whose blocks
+        // timed out unevenly); exit anyway and say so: word 31 of an evaluation is 0 by construction,
+        // the host re-evaluates a pre-launched pose and turns anything else into NDT_ERR_HIP
         *s_fail = 1;
         break;
       }
@@ -896,6 +897,10 @@ int derivs_read_stamps(unsigned long long* out, int nblocks) {
 // which keeps every CU at <= 4 waves/SIMD and leaves <= 256 rows for the final sum
 // (profiles/r02_block_sweep.txt: 16.6 us at 832, 17.2 at 1024, 20.3 at 512).
 // NDT_DERIV_BLOCK overrides it for tuning.
+// compute units of the device the engine runs on (ndt_create sets it; all devices of a node are alike)
+static int g_compute_units = 256;
+void derivs_set_compute_units(int n) { if (n > 0) g_compute_units = n; }
+
 int derivs_block_threads(size_t n_src, int K) {
   static const int forced = [] {
     const char* e = getenv("NDT_DERIV_BLOCK");  // multiple of 64, 64..1024
@@ -903,7 +908,7 @@ int derivs_block_threads(size_t n_src, int K) {
     return (v >= 64 && v <= MAX_BLOCK && v % 64 == 0) ? v : 0;
   }();
   if (forced) return forced;
-  constexpr size_t kCUs = 256;
+  const size_t kCUs = (size_t)g_compute_units;
   if (K == 1 && n_src > (size_t)512 * kCUs && n_src <= (size_t)MAX_BLOCK * kCUs) {
     const size_t per_cu = (n_src + kCUs - 1) / kCUs;
     return (int)(((per_cu + 63) / 64) * 64);

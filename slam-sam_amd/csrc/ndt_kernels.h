@@ -97,6 +97,7 @@ hipError_t sort_source_by_blocks(const float* x, const float* y, const float* z,
                                  float* oz, hipStream_t s);
 
 // ---- derivative evaluation (ndt_derivs.hip) ---------------------------------
+void derivs_set_compute_units(int n);  // CUs of the device: single-pose launches of mid-sized scans are shaped one block per CU
 int derivs_grid_blocks(size_t n_src, int K);
 int derivs_block_threads(size_t n_src, int K);
 size_t derivs_partials_words(size_t n_src, int K);  // doubles needed in d_partials

@@ -1625,8 +1625,12 @@ hipError_t sort_cloud_fused(const float* x, const float* y, const float* z, size
   if (n == 0) return hipSuccess;
   if (tile != FUSED_TILE && tile != FUSED_BIG_TILE) return hipErrorInvalidValue;
   const int ntiles = fused_tiles(n, tile);
-  // test seam: NDT_DEBUG_FUSED_MUTE_TILE=<t> makes tile t withhold its counts, so every block times out
+#ifdef NDT_TEST_SEAMS
+  // test seam (libndt_hip_seams.so only): NDT_DEBUG_FUSED_MUTE_TILE=<t> makes tile t withhold its counts, so every block times out
   static const int mute_tile = [] { const char* e = getenv("NDT_DEBUG_FUSED_MUTE_TILE"); return e && *e ? atoi(e) : -1; }();
+#else
+  constexpr int mute_tile = -1;
+#endif
   uint32_t *kin = keys_a, *kout = keys_b, *vin = vals_a, *vout = vals_b;
   for (int p = 0; p < passes; ++p) {
     uint32_t tag = (*seq + 1u) & 0xffffu;

@@ -61,6 +61,12 @@ class _HipMem:
         self.live.append(p)
         return p.value
 
+    def write(self, ptr, arr):
+        """Overwrites an existing device buffer in place (a caller re-filling its scan buffer)."""
+        import numpy as np
+        a = np.ascontiguousarray(arr)
+        assert self.rt.hipMemcpy(self.C.c_void_p(ptr), a.ctypes.data, a.nbytes, 1) == 0
+
     def free_all(self):
         for p in self.live:
             self.rt.hipFree(p)

@@ -5,10 +5,12 @@
 //     evaluations that fail and evaluations that return non-finite values;
 //   * the 6x6 solve (Cholesky fast path and eigen route), result_covariance, pose <-> matrix;
 //   * the shared-memory reducer with 4 threads x 2000 rounds (bit-identical sums on every rank);
-//   * SE(3) exp / log round trips.
+//   * SE(3) exp / log round trips;
+//   * the upload path's worker pool growing between two jobs whose captures live on dead frames.
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <unistd.h>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -21,6 +23,7 @@
 
 #include "../../slam-sam_amd/csrc/ndt_comm.h"
 #include "../../slam-sam_amd/csrc/ndt_newton.h"
+#include "../../slam-sam_amd/csrc/ndt_repack_pool.h"
 #include "../../slam-sam_amd/csrc/ndt_se3.h"
 
 static int fails = 0;
@@ -186,6 +189,39 @@ int main() {
     CHECK(a.allreduce_host(wa, NDT_EVAL_WORDS, &ea) == NDT_OK);
     tb.join();
     for (int i = 0; i < NDT_EVAL_WORDS; ++i) CHECK(wa[i] == 101.0 + i && wb[i] == wa[i]);
+  }
+
+  // ---- upload worker pool: growth between two jobs ------------------------------
+  // Every job captures its caller's stack frame by reference, as upload_soa's does.  A worker added
+  // by ensure() between two run() calls must never run the PREVIOUS job: that frame is gone.  The
+  // frames below are heap blocks freed right after wait(), so ASan sees a stale job as use-after-free;
+  // the counters catch it without ASan too.
+  {
+    for (int trial = 0; trial < 300; ++trial) {
+      ndt::RepackPool pool;
+      auto upload = [&](unsigned workers, int chunks) {
+        struct Frame { std::atomic<int> next{0}, done{0}; int chunks = 0; };
+        Frame* f = new Frame();
+        f->chunks = chunks;
+        pool.ensure(workers);
+        pool.run([f] {
+          for (;;) {
+            const int c = f->next.fetch_add(1);
+            if (c >= f->chunks) return;
+            f->done.fetch_add(1);
+          }
+        });
+        pool.wait();
+        const bool ok = f->done.load() == chunks;
+        delete f;  // the frame is dead from here on
+        return ok;
+      };
+      CHECK(upload(3, 8));
+      CHECK(upload(6, 31));   // grows 3 -> 6 with gen already at 1: the new workers must wait for THIS job
+      CHECK(upload(2, 5));    // more workers than asked for: the extra ones find no chunk
+      CHECK(upload(9, 64));
+      CHECK(pool.pending == 0 && !pool.job);
+    }
   }
 
   // ---- SE(3) ---------------------------------------------------------------------------------------

@@ -5,7 +5,8 @@
 The reference holds no golden vectors for this path and cannot be built here
 (SURVEY.md section 8c), so these vectors are ORACLE outputs: they pin the oracle (and the
 HIP path) against regressions; parity with the reference itself is pinned only by the
-reference test's own assertions (tests/test_oracle_reference_fixture.py).
+reference test's own assertions (tests/test_oracle.py::test_reference_fixture_pins_oracle,
+tests/test_svn.py).
 Inputs and expected outputs only -- no reference source text.
 """
 import hashlib

@@ -234,3 +234,21 @@ def test_xy_covariance_laplace_and_search_poses(pkg):
         mirrored = T[:2, 3] - R @ np.array([ox[i], oy[i]])
         assert np.allclose(P[:2, 3], want, atol=1e-5) or np.allclose(P[:2, 3], mirrored, atol=1e-5)
         assert np.allclose(P[:3, :3], np.eye(3)) and P[2, 3] == np.float32(1.5)
+
+
+def test_quoted_hbm_traffic_matches_the_newest_pmc_summary():
+    """bench.py quotes profiles/traffic_k_derivatives.json as the kernel's HBM traffic (a static figure:
+    the PMC pass is a separate rocprofv3 run).  It must equal FETCH_SIZE x 2 + WRITE_SIZE of the newest
+    committed profiles/rNN_pmc_summary.txt (scripts/traffic_from_pmc.py regenerates it)."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("traffic_from_pmc", os.path.join(ROOT, "scripts", "traffic_from_pmc.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = mod.traffic(mod.newest_summary())
+    have = json.load(open(os.path.join(ROOT, "profiles", "traffic_k_derivatives.json")))
+    assert have["kernel"] == want["kernel"]
+    assert have["hbm_bytes_per_launch"] == pytest.approx(want["hbm_bytes_per_launch"], rel=2e-3)
+    assert have["FETCH_SIZE_KB"] == pytest.approx(want["FETCH_SIZE_KB"], rel=2e-3)
+    assert have["WRITE_SIZE_KB"] == pytest.approx(want["WRITE_SIZE_KB"], rel=2e-3)
+    assert os.path.basename(mod.newest_summary()) in have["source"]

@@ -1,10 +1,15 @@
 """GPU tests of the round-2 surface: DIRECT26, the scoring-only entry point, wait modes, the
 evaluation memo of the line search, parameter changes on a consumed device target, and the
 RCCL reducer on a one-rank communicator."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+SEAMS_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "slam-sam_amd",
+                         "libndt_hip_seams.so")
 
 KW = dict(resolution=1.0, step_size=0.1, trans_epsilon=1e-4, max_iterations=35)
 
@@ -291,7 +296,9 @@ print("counters", used, quit, timeouts, "equal", bool(np.array_equal(T0, T1)))
 T2 = ndt.align(cfg["guess"])
 print("again equal", bool(np.array_equal(T0, T2)))
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, NDT_DEBUG_PUBLISH_DELAY_MS="60")
+    # the fault-injection seams are compiled into libndt_hip_seams.so only (make VARIANT=seams), never
+    # into the production library
+    env = dict(os.environ, NDT_DEBUG_PUBLISH_DELAY_MS="60", NDT_HIP_LIB=SEAMS_LIB)
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
     assert p.returncode == 0, p.stderr[-2000:]
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("counters")][0].split()
@@ -389,7 +396,10 @@ def test_fused_sort_passes_equal_classic_passes_and_fall_back():
     classic = _leaf_dump({"NDT_FUSED_SORT": "0"})
     assert fused[1] > 1000 and fused[2] == 0 and classic[2] == 0
     assert fused[:2] == classic[:2]
-    muted = _leaf_dump({"NDT_FUSED_SORT": "1", "NDT_DEBUG_FUSED_MUTE_TILE": "0"})
+    muted = _leaf_dump({"NDT_FUSED_SORT": "1", "NDT_DEBUG_FUSED_MUTE_TILE": "0", "NDT_HIP_LIB": SEAMS_LIB})
+    # the production library carries no such seam: the variable changes nothing there
+    inert = _leaf_dump({"NDT_FUSED_SORT": "1", "NDT_DEBUG_FUSED_MUTE_TILE": "0"})
+    assert inert == fused
     assert muted[:2] == classic[:2]
     assert muted[2] == 3          # every one of the three builds fell back
 
@@ -463,3 +473,34 @@ def test_two_engines_on_two_threads(pkg, S):
     for t in ts: t.join(timeout=300)
     assert not any(t.is_alive() for t in ts)
     assert errors == []
+
+
+def test_viewed_source_rewritten_in_place(pkg, S, hipmem):
+    """ndt_set_source_device_view keeps the caller's arrays; with source ordering on, the engine caches a
+    block-ordered COPY of them.  A caller that re-fills the same device buffers (a reused scan buffer) says
+    so with ndt_source_changed (or sets the view again): the next align then sees the new points, exactly
+    as an engine that was handed the new scan from scratch."""
+    cfg = S.config_c2()
+    kw = dict(KW, source_order=pkg.SOURCE_ORDER_SORT)
+    src_a = cfg["source"]
+    rng = np.random.default_rng(3)
+    src_b = (src_a[rng.permutation(len(src_a))] + rng.normal(0, 0.01, src_a.shape)).astype(np.float32)
+    ndt = _ndt(pkg, **kw)
+    ndt.setInputTarget(cfg["target"])
+    ptr = [hipmem.upload(src_a[:, a]) for a in range(3)]
+    ndt.setInputSourceDeviceView(ptr[0], ptr[1], ptr[2], len(src_a))
+    Ta = ndt.align(cfg["guess"])
+    for a in range(3):
+        hipmem.write(ptr[a], src_b[:, a])
+    ndt.sourceChanged()
+    Tb = ndt.align(cfg["guess"])
+    fresh = _ndt(pkg, **kw)
+    fresh.setInputTarget(cfg["target"])
+    fresh.setInputSource(src_b)
+    assert np.array_equal(Tb, fresh.align(cfg["guess"]))
+    assert not np.array_equal(Ta, Tb)
+    # ... and setting the view again does the same
+    for a in range(3):
+        hipmem.write(ptr[a], src_a[:, a])
+    ndt.setInputSourceDeviceView(ptr[0], ptr[1], ptr[2], len(src_a))
+    assert np.array_equal(ndt.align(cfg["guess"]), Ta)
