@@ -5,12 +5,19 @@ A "step" is one scan registration of workload C3 (a 200 000-point scan into a
 1 000 000-point voxelised submap, 0.5 m voxels, DIRECT7): setInputTarget (voxel-grid
 build) + setInputSource + align(), with both clouds already resident in HBM when the
 timed region starts.  `value` = Newton iterations / wall second over the K timed steps
-(build time included), whole job.  With N > 1 (one process per GPU under
-torch.distributed.run) the target is replicated, the source is sharded and every
-derivative evaluation ends in one 256-byte all-reduce (RCCL over xGMI by default,
-NDT_BENCH_REDUCE=shm for the shared-memory reducer): strong scaling.
+(build time included), whole job.  With N > 1 (one process per GPU) the target is replicated,
+the source is sharded and every derivative evaluation ends in one 256-byte sum over the ranks:
+strong scaling.  Every transport of that sum is timed back to back -- shared memory (pinned-host
+partials), the in-kernel xGMI peer-write exchange, and RCCL's all-reduce -- and reported under
+config.reduce_variants; NDT_BENCH_REDUCE=shm|p2p|rccl pins one.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1 runs either way: launched by `python -m torch.distributed.run --nproc-per-node N ...` (RANK /
+LOCAL_RANK / WORLD_SIZE from the environment), or as a plain `python bench.py --gpus N`, which then
+becomes a parent that touches no GPU and starts its N ranks itself (slam-sam_amd/ranks.py).  No torch
+in either case: device buffers come from the HIP runtime the engine links, the ranks meet on a
+shared-memory board, so libndt_hip.so is the only HIP / RCCL user in a rank's process.
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (k_derivatives):
 algorithmic bytes per launch = N_src * (12 + 7*4 + nbar*48) over its mean
@@ -35,9 +42,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import torch  # noqa: E402  (device buffers + torch.distributed plumbing)
-import torch.distributed as dist  # noqa: E402
 
 import __graft_entry__ as ge  # noqa: E402
 
@@ -163,32 +167,29 @@ BUILD_BYTES = lambda n_tgt, v: n_tgt * 60.0 + v * 52.0  # noqa: E731  SURVEY.md 
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    pkg = ge.load_package()   # imports only: the HIP library is loaded on first use, in the ranks
+    R = pkg.ranks
+    # NDT_BENCH_FORCE_DIST=1: run the multi-rank code path (board, every reducer, watchdog) even with
+    # one rank -- the only way to execute the RCCL leg end to end on a 1-GPU box
+    force_dist = os.environ.get("NDT_BENCH_FORCE_DIST", "0") == "1"
+    w = R.env_world()
+    if w is None and (args.gpus > 1 or force_dist):
+        # plain `python bench.py --gpus N`: this process is the parent of N ranks and touches no GPU
+        limit = float(os.environ.get("NDT_BENCH_LAUNCH_TIMEOUT", "1500"))
+        raise SystemExit(R.launch(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], timeout=limit))
+    rank, local_rank, world = w if w is not None else (0, 0, 1)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    # rehearsal knob for a 1-GPU box: every rank on device 0, gloo rendezvous, shm reducer
+    # rehearsal knob for a 1-GPU box: every rank on device 0 (RCCL refuses two ranks on one device)
     rehearsal = os.environ.get("NDT_BENCH_SINGLE_DEVICE", "0") == "1"
     if rehearsal:
         local_rank = 0
-        os.environ.setdefault("NDT_BENCH_REDUCE", "shm")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    # NDT_BENCH_FORCE_DIST=1: run the multi-rank code path (process group, both reducers, watchdog)
-    # even with one rank -- the only way to execute the RCCL leg end to end on a 1-GPU box
-    force_dist = os.environ.get("NDT_BENCH_FORCE_DIST", "0") == "1"
+    hip = R.Hip()
+    if hip.device_count() <= 0:
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    hip.set_device(local_rank)
     multi = world > 1 or force_dist
-    if multi:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    board = R.Board(R.board_path(), rank, world) if multi else None
 
     pkg = ge.load_package()
     S = pkg.synth
@@ -198,15 +199,13 @@ def main():
     b, c = pkg.shard_range(n_src_total, rank, world)
 
     # inputs resident in HBM before the timed region (SoA float32)
-    tgt = [torch.from_numpy(np.ascontiguousarray(cfg["target"][:, a])).to(dev) for a in range(3)]
-    src = [torch.from_numpy(np.ascontiguousarray(cfg["source"][b:b + c, a])).to(dev) for a in range(3)]
-    torch.cuda.synchronize()
+    tptr = [hip.upload(cfg["target"][:, a]) for a in range(3)]
+    sptr = [hip.upload(cfg["source"][b:b + c, a]) for a in range(3)]
+    hip.synchronize()
 
     ndt = pkg.NormalDistributionsTransform(device_id=local_rank, **params)
 
     # what a C++ caller hands over without any per-call work: raw pointers and guess.data()
-    tptr = [t.data_ptr() for t in tgt]
-    sptr = [t.data_ptr() for t in src]
     n_tgt = len(cfg["target"])
     guess_cm = pkg.ColMajor4f(cfg["guess"])
 
@@ -221,8 +220,8 @@ def main():
 
     def fence():
         if multi:
-            dist.barrier()
-        torch.cuda.synchronize()
+            board.barrier()
+        hip.synchronize()
 
     def timed_region():
         """W warm-up steps, then exactly K steps between two fences; max wall time over ranks."""
@@ -243,31 +242,30 @@ def main():
         fence()
         elapsed = time.perf_counter() - t0
         if multi:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+            elapsed = board.allmax(elapsed)
         pre1 = ndt.prelaunchCounters()
         return dict(elapsed=elapsed, iters=iters, evals=evals, reused=reused, t_build=t_build, t_align=t_align,
                     prelaunched=pre1[0] - pre0[0], prelaunch_timeouts=pre1[2] - pre0[2])
 
     def init_reducer(mode):
         """Creates the engine's cross-rank reducer on every rank; False if any rank failed."""
-        ok = torch.ones(1, dtype=torch.int32, device="cpu" if rehearsal else dev)
+        ok = 1.0
         try:
-            if mode == "rccl":  # the engine's own RCCL communicator; its id travels through torch.distributed
-                box = [pkg.comm_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                ndt.commInitRccl(box[0], rank, world)
-            else:               # host-side sum through POSIX shared memory
-                box = ["/ndt_bench_%d" % os.getpid() if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                shm_name["name"] = box[0]
-                ndt.commInitShm(box[0], rank, world)
-        except pkg.NdtError as e:
+            if mode == "rccl":   # the engine's own RCCL communicator; rank 0's id travels over the board
+                if rehearsal and world > 1:
+                    raise pkg.NdtError(-9, "ranks share one device: RCCL refuses duplicate GPUs")
+                ndt.commInitRccl(board.bcast(pkg.comm_unique_id() if rank == 0 else b""), rank, world)
+            elif mode == "p2p":  # in-kernel peer-write exchange: every rank's slot array, opened by all
+                handles = board.allgather(ndt.commP2pHandle())
+                ndt.commInitP2p(b"".join(handles), rank, world)
+            else:                # host-side sum through POSIX shared memory
+                name = board.bcast(("/ndt_bench_%d" % os.getpid()).encode() if rank == 0 else b"").decode()
+                shm_name["name"] = name
+                ndt.commInitShm(name, rank, world)
+        except (pkg.NdtError, AttributeError) as e:
             print("rank %d: %s reducer failed (%s)" % (rank, mode, e), file=sys.stderr, flush=True)
-            ok.zero_()
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0:
+            ok = 0.0
+        if board.allmin(ok) == 0.0:
             ndt.commDestroy()
             return False
         ndt.setGlobalSourceSize(n_src_total)
@@ -320,7 +318,10 @@ def main():
                        "reduce": reduce_mode, "reduce_variants": variants},
             "ms_target_build_device": gi["ms_build"],
             "final_error_vs_ground_truth": {"m": err_t, "rad": err_r},
-            "roofline": {"bound": "hbm", "kernel": "k_derivatives", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            # `bound`: what the evidence shows limits this launch (80 % of the 200 k-point launch is a
+            # fixed latency chain, the rest VALU issue); `roof`: the roofline `achieved` / `peak` / `frac` are
+            # priced against, as the contract defines them (algorithmic bytes over the HBM peak)
+            "roofline": {"bound": "latency/valu", "roof": "hbm", "kernel": "k_derivatives", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_source,
                          "hbm_achieved_from_traffic": (traffic / (ms_kernel * 1e-3) / 1e9) if (traffic and ms_kernel > 0) else None,
@@ -413,14 +414,14 @@ def main():
         big = (big + np.random.default_rng(5).normal(0.0, 0.02, big.shape)).astype(np.float32)
         nb = len(big)
         bb, cb = pkg.shard_range(nb, rank, world)
-        bsrc = [torch.from_numpy(np.ascontiguousarray(big[bb:bb + cb, a])).to(dev) for a in range(3)]
-        torch.cuda.synchronize()
+        bsrc = [hip.upload(big[bb:bb + cb, a]) for a in range(3)]
+        hip.synchronize()
         if multi:
             ndt.setGlobalSourceSize(nb)
 
         def pstep():
-            ndt.setInputTargetDevice(tgt[0].data_ptr(), tgt[1].data_ptr(), tgt[2].data_ptr(), len(cfg["target"]))
-            ndt.setInputSourceDevice(bsrc[0].data_ptr(), bsrc[1].data_ptr(), bsrc[2].data_ptr(), cb)
+            ndt.setInputTargetDevice(tptr[0], tptr[1], tptr[2], n_tgt)
+            ndt.setInputSourceDevice(bsrc[0], bsrc[1], bsrc[2], cb)
             ndt.align(cfg["guess"])
             return ndt.getResult()
 
@@ -436,12 +437,10 @@ def main():
         fence()
         el = time.perf_counter() - t0
         if multi:
-            t = torch.tensor([el], dtype=torch.float64, device="cpu" if rehearsal else dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
+            el = board.allmax(el)
             ndt.setGlobalSourceSize(n_src_total)
         err_t, err_r = S.pose_error(r["T"], cfg["gt"])
-        ndt.setInputSourceDeviceView(src[0].data_ptr(), src[1].data_ptr(), src[2].data_ptr(), c)
+        ndt.setInputSourceDeviceView(sptr[0], sptr[1], sptr[2], c)
         return {"workload": "same map, %d-point source (the map seen from the scan pose, 2 cm noise), sharded /%d" % (nb, world),
                 "n_source": nb, "value": iters / el, "unit": "iterations/s", "ms_per_step": 1e3 * el / k,
                 "iterations_per_align": iters / k, "evaluations_per_align": evals / k,
@@ -449,6 +448,11 @@ def main():
 
     variants = {}
     shm_name = {"name": None}
+
+    def comm_record():
+        v, path = pkg.comm_info()
+        return {"version": v, "library": path}
+
     if not multi:
         res = timed_region()
         out = instrumented(res, "none", variants)
@@ -460,27 +464,27 @@ def main():
         if out is not None and probe is not None:
             out["scaling_probe"] = probe
         if out is not None:
-            v, path = pkg.comm_info()
-            out["config"]["rccl"] = {"version": v, "library": path}
+            out["config"]["rccl"] = comm_record()
         if out is not None and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, params, args.cpu_seconds)
     else:
-        # Both transports of the 256-byte evaluation sum are timed back to back on the same
-        # workload: pinned-host partials summed through shared memory, and an RCCL
-        # all-reduce on the engine's stream.  The faster one is the headline and is named in
-        # config.reduce; NDT_BENCH_REDUCE=rccl|shm pins one.  The shared-memory pass comes first
-        # and is complete (JSON line assembled) before RCCL is touched; a watchdog prints that
-        # line and ends the rank if the RCCL pass does not finish in time, so a stuck
-        # communicator cannot cost the whole measurement.
+        # Every transport of the 256-byte evaluation sum is timed back to back on the same workload
+        # (SURVEY 8e): pinned-host partials summed through shared memory, the in-kernel peer-write
+        # exchange over xGMI, and an RCCL all-reduce on the engine's stream.  All are reported under
+        # config.reduce_variants (RCCL always, with the communicator's own rank count); the fastest is
+        # the headline and is named in config.reduce; NDT_BENCH_REDUCE=rccl|p2p|shm pins one.  RCCL
+        # comes last and under a watchdog: every earlier pass is complete (JSON line assembled) before
+        # it is touched, so a stuck communicator cannot cost the whole measurement -- the watchdog
+        # prints that line and ends the rank with status 4.
         forced = os.environ.get("NDT_BENCH_REDUCE")
-        modes = [forced] if forced in ("rccl", "shm") else ["shm", "rccl"]
+        modes = [forced] if forced in ("rccl", "shm", "p2p") else ["shm", "p2p", "rccl"]
         out, best = None, None
         state = {"out": None}
 
         def on_timeout():
-            """The RCCL pass did not finish: print what the shared-memory pass measured (marked as a
-            failed RCCL leg) and end EVERY rank with a non-zero status, so the hang shows in the run
-            record instead of passing as rc 0."""
+            """The RCCL pass did not finish: print what the earlier passes measured (marked as a failed
+            RCCL leg) and end EVERY rank with a non-zero status, so the hang shows in the run record
+            instead of passing as rc 0."""
             if rank == 0 and state["out"] is not None:
                 state["out"]["config"]["reduce_variants"]["rccl"] = "timed out"
                 state["out"]["reduce_failed"] = "rccl"
@@ -503,10 +507,14 @@ def main():
             if not init_reducer(mode):
                 variants[mode] = None
                 if out is not None:
-                    out["reduce_failed"] = mode
+                    out.setdefault("reduce_failed", mode)
             else:
+                n_comm = ndt.commRankCount()
                 res = timed_region()
-                variants[mode] = {"value": res["iters"] / res["elapsed"], "ms_per_step": 1e3 * res["elapsed"] / args.steps}
+                variants[mode] = {"value": res["iters"] / res["elapsed"], "ms_per_step": 1e3 * res["elapsed"] / args.steps,
+                                  "ranks": n_comm, "evaluations_prelaunched_per_align": res["prelaunched"] / args.steps}
+                if mode == "rccl":
+                    variants[mode]["ncclCommCount"] = n_comm
                 if out is None:
                     out = instrumented(res, mode, variants)
                     if rank != 0:
@@ -522,18 +530,20 @@ def main():
             if rank == 0:
                 state["out"] = out
             if dog is not None:
-                dist.barrier()
+                board.barrier()
                 dog.cancel()
         if best is None:
             raise SystemExit("no cross-rank reducer could be created")
         if out is not None and "config" in out:
-            v, path = pkg.comm_info()
-            out["config"]["rccl"] = {"version": v, "library": path}
+            out["config"]["rccl"] = comm_record()
+            out["config"]["launch"] = "self-launched ranks" if "NDT_RANKS_BOARD" in os.environ else "external launcher"
         if rank != 0:
             out = None
-        dist.barrier()
-        dist.destroy_process_group()
+        board.barrier()
     ndt.close()
+    hip.free_all()
+    if board is not None:
+        board.close()
     if out is not None:
         print(json.dumps(out), flush=True)
 

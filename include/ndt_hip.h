@@ -77,7 +77,10 @@ typedef enum ndt_reduce_mode {
   NDT_REDUCE_NONE = 0, /* single GPU */
   NDT_REDUCE_RCCL = 1, /* ncclAllReduce of the 32-double partial over xGMI */
   NDT_REDUCE_SHM = 2,  /* pinned-host partials summed through POSIX shared memory */
-  NDT_REDUCE_HOOK = 3  /* caller-supplied all-reduce callback */
+  NDT_REDUCE_HOOK = 3, /* caller-supplied all-reduce callback */
+  NDT_REDUCE_P2P = 4   /* one-shot peer-write all-gather over xGMI + local sum, INSIDE the derivative
+                          kernel's final sum: no collective launch, no host hop, and the host-polled /
+                          pre-launched fast path of a single GPU stays on */
 } ndt_reduce_mode;
 
 typedef enum ndt_wait_mode {
@@ -343,6 +346,14 @@ int ndt_comm_unique_id(void* out128);
 int ndt_comm_init_rccl(ndt_handle* h, const void* id128, int rank, int nranks);
 /* host-side reduction through a POSIX shared-memory segment named `name` */
 int ndt_comm_init_shm(ndt_handle* h, const char* name, int rank, int nranks);
+/* Peer-write reducer (NDT_REDUCE_P2P).  Every rank calls ndt_comm_p2p_handle (allocates its exchange
+ * area in fine-grained device memory on the handle's device and exports it as an IPC handle of
+ * NDT_P2P_HANDLE_BYTES), the caller all-gathers the handles (bench.py: over its shared-memory board), then
+ * every rank calls ndt_comm_init_p2p with all of them in rank order.  Ranks are processes; all their
+ * devices must be visible to each other (no HIP_VISIBLE_DEVICES masking per rank). */
+#define NDT_P2P_HANDLE_BYTES 64
+int ndt_comm_p2p_handle(ndt_handle* h, void* out_handle);
+int ndt_comm_init_p2p(ndt_handle* h, const void* handles, int rank, int nranks);
 /* caller-supplied all-reduce(sum) over NDT_EVAL_WORDS doubles, in place */
 typedef int (*ndt_allreduce_fn)(void* ctx, double* words, int n);
 int ndt_comm_init_hook(ndt_handle* h, ndt_allreduce_fn fn, void* ctx, int rank, int nranks);
@@ -351,6 +362,9 @@ int ndt_comm_destroy(ndt_handle* h);
  * path of the shared object the symbol was resolved from (the process may hold two librccl.so:
  * ROCm's and the one bundled with PyTorch); returns the version or < 0 */
 int ndt_comm_info(char* path_buf, size_t cap);
+/* ranks of the handle's live reducer as the transport reports them (RCCL: ncclCommCount of the engine's
+ * communicator); 1 without a reducer; < 0 on failure */
+int ndt_comm_rank_count(const ndt_handle* h);
 /* total source points over all ranks (for transform_probability); set by the
  * caller after sharding, defaults to the local count */
 int ndt_set_global_source_size(ndt_handle* h, int64_t n_total);

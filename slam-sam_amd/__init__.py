@@ -16,6 +16,7 @@ import os
 
 import numpy as np
 
+from . import ranks  # noqa: F401  (one process per GPU without torch: launcher, slot board, HIP shim)
 from . import synth  # noqa: F401  (seeded synthetic cloud generators)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -132,7 +133,7 @@ ABI_SYMBOLS = [
     "ndt_result_covariance", "ndt_set_source_from_keyframe",
     "ndt_params_preset", "ndt_score_transform", "ndt_comm_info", "ndt_score_transforms",
     "ndt_xy_covariance_laplace", "ndt_propose_poses_to_search", "ndt_xy_covariance_multi_ndt",
-    "ndt_xy_covariance_multi_ndt_score", "ndt_source_changed",
+    "ndt_xy_covariance_multi_ndt_score", "ndt_source_changed", "ndt_comm_rank_count", "ndt_comm_p2p_handle", "ndt_comm_init_p2p",
 ]
 
 _lib = None
@@ -206,6 +207,9 @@ def lib():
         L.ndt_params_preset.argtypes = [C.POINTER(Params), C.c_int]
         L.ndt_score_transform.argtypes = [vp, fp, C.POINTER(Score)]
         L.ndt_comm_info.argtypes = [C.c_char_p, C.c_size_t]
+        L.ndt_comm_rank_count.argtypes = [vp]
+        L.ndt_comm_p2p_handle.argtypes = [vp, vp]
+        L.ndt_comm_init_p2p.argtypes = [vp, vp, C.c_int, C.c_int]
         L.ndt_score_transforms.argtypes = [vp, fp, C.c_int, C.POINTER(Score)]
         L.ndt_xy_covariance_laplace.argtypes = [dp, dp]
         L.ndt_propose_poses_to_search.argtypes = [C.POINTER(Result), dp, dp, C.c_int, fp]
@@ -586,10 +590,31 @@ class NormalDistributionsTransform:
     def commInitShm(self, name, rank, nranks):
         self._check(lib().ndt_comm_init_shm(self._h, name.encode(), rank, nranks))
 
+    def commP2pHandle(self):
+        """This rank's exchange area of the peer-write reducer as a 64-byte IPC handle (all-gather them)."""
+        buf = C.create_string_buffer(64)
+        self._check(lib().ndt_comm_p2p_handle(self._h, buf))
+        return buf.raw
+
+    def commInitP2p(self, handles, rank, nranks):
+        """handles: the nranks x 64 bytes of every rank's commP2pHandle(), in rank order."""
+        b = bytes(handles)
+        if len(b) != 64 * nranks:
+            raise ValueError("need %d handle bytes" % (64 * nranks))
+        buf = C.create_string_buffer(b, len(b))
+        self._check(lib().ndt_comm_init_p2p(self._h, buf, rank, nranks))
+
     def commInitHook(self, fn, rank, nranks):
         cb = ALLREDUCE_FN(fn)
         self._keep.append(cb)
         self._check(lib().ndt_comm_init_hook(self._h, cb, None, rank, nranks))
+
+    def commRankCount(self):
+        """Ranks of the live reducer as the transport reports them (RCCL: ncclCommCount)."""
+        n = lib().ndt_comm_rank_count(self._h)
+        if n < 0:
+            raise NdtError(n, "ndt_comm_rank_count")
+        return n
 
     def commDestroy(self):
         self._check(lib().ndt_comm_destroy(self._h))

@@ -178,6 +178,7 @@ struct ndt_handle {
   bool mbox_preload = false;          // the waiting kernel fetches its points before the pose arrives (measured: no gain)
   bool prelaunch_armed = false;       // inside ndt_align
   unsigned long long pre_seq = 0;     // sequence number of the kernel that is waiting, 0 = none
+  unsigned long long pre_round = 0;   // ... and the cross-rank round it will exchange under (NDT_REDUCE_P2P)
   int pre_buf = 0;                    // ... and the result buffer (0 / 1) it will write
   int prelaunch_strikes = 0;          // consecutive aligns in which a waiting kernel gave up
   bool prelaunch_suspended = false;   // three such aligns in a row (a chronically starved host): no more pre-launching
@@ -706,6 +707,13 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
                          h->prm.prelaunch == NDT_PRELAUNCH_AUTO && ensure_mailbox(h);
   unsigned long long seq = 0;
   bool via_mailbox = false;
+  // NDT_REDUCE_P2P: the kernel's final sum exchanges the evaluation with the other ranks itself, under
+  // the tag "number of this global evaluation" (identical on every rank: all run the same host loop on
+  // the same sums).  A pre-launched kernel got its tag when it was enqueued; one that is told to leave
+  // has consumed none.
+  const bool p2p = h->red.mode() == NDT_REDUCE_P2P;
+  const XchgInfo* xinfo = p2p ? h->red.p2p_info() : nullptr;
+  unsigned long long xround = p2p ? h->red.p2p_round() + 1 : 0;
   // Consecutive single-pose launches write their results to ALTERNATING host buffers: a pre-launched
   // kernel runs ahead of the host, and one that gives up waiting for its pose (this thread frozen for
   // 20 ms -- a cgroup-throttled or oversubscribed host does that) writes its notice while the result
@@ -717,6 +725,7 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
     if (prelaunch && h->pre_need_h == need_h) {  // the kernel for this evaluation is already waiting on the device
       seq = h->pre_seq;
       buf = h->pre_buf;
+      xround = h->pre_round;
       h->pre_seq = 0;
 #ifdef NDT_TEST_SEAMS
       {  // test seam (libndt_hip_seams.so only): hold the pose back so that the waiting kernel gives up
@@ -736,18 +745,22 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
     buf = (h->flag_toggle ^= 1);
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, s));
     launch_derivatives(px, py, pz, h->n_src, h->geom, h->cell2leaf.p, h->rec.p, pc, nullptr, 1, ec, h->partials.p,
-                       h->counters.p, d_out, s, spin ? h->flag.d + (size_t)buf * 2 * EV_WORDS : nullptr, seq);
+                       h->counters.p, d_out, s, spin ? h->flag.d + (size_t)buf * 2 * EV_WORDS : nullptr, seq, nullptr,
+                       xinfo, xround);
     HIP_TRY(h, hipGetLastError());
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, s));
   }
+  if (p2p) h->red.p2p_set_round(xround);  // this evaluation's tag is spent (a fallback below gives it back)
   if (prelaunch) {
     // the next evaluation's kernel goes onto the stream now, behind the one in flight; it will
     // start when that one has finished and wait for its pose (or for the order to leave)
     h->pre_seq = g_launch_seq.fetch_add(1, std::memory_order_relaxed);
     h->pre_need_h = need_h;
     h->pre_buf = (h->flag_toggle ^= 1);
+    h->pre_round = xround + 1;
     launch_derivatives(px, py, pz, h->n_src, h->geom, h->cell2leaf.p, h->rec.p, pc, nullptr, 1, ec, h->partials.p,
-                       h->counters.p, d_out, s, h->flag.d + (size_t)h->pre_buf * 2 * EV_WORDS, h->pre_seq, h->mbox);
+                       h->counters.p, d_out, s, h->flag.d + (size_t)h->pre_buf * 2 * EV_WORDS, h->pre_seq, h->mbox,
+                       xinfo, h->pre_round);
     HIP_TRY(h, hipGetLastError());
   }
   if (dev_out) {
@@ -775,7 +788,15 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
   } else {
     std::memcpy(words, h->result.h, sizeof(words));
   }
-  if (!dev_out) {
+  if (p2p) {
+    if (words[EV_FAIL] == 3.0) {
+      // this rank's sum is published, a peer was more than 20 ms late (a starved host over there):
+      // the kernel is gone, the host finishes the same exchange -- same rows, same rank order
+      int rc = h->red.p2p_finish_on_host(xround, words, EV_WORDS, &h->err);
+      if (rc) return rc;
+    }
+    // (otherwise the words ARE the global sums already)
+  } else if (!dev_out) {
     int rc = h->red.allreduce_host(words, EV_WORDS, &h->err);
     if (rc) return rc;
   }
@@ -787,6 +808,7 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
     // nothing was evaluated.  Evaluate the ordinary way, and stop pre-launching for this align.
     h->n_prelaunch_timeouts++;
     quit_prelaunched(h);
+    if (p2p) h->red.p2p_set_round(xround - 1);  // nothing was exchanged under this tag: the re-evaluation uses it
     h->prelaunch_armed = false;  // ordinary launches for the rest of this align; the next align tries again
     if (++h->prelaunch_strikes >= 3) h->prelaunch_suspended = true;  // three aligns in a row: a chronically starved host
     return evaluate(h, p, T, need_h, out, score_only);
@@ -798,6 +820,7 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
     // Nothing usable was evaluated -- same remedy as a time-out: an ordinary launch of the same pose.
     h->n_prelaunch_timeouts++;
     quit_prelaunched(h);
+    if (p2p) h->red.p2p_set_round(xround - 1);  // a sum that missed rows is never published (sum_rows)
     h->prelaunch_armed = false;
     h->counters_zeroed = 0;  // ticket mode: the partial tickets of the abandoned launch are not zero
     HIP_TRY(h, hipStreamSynchronize(s));  // the abandoned grid has drained before its rows are reused
@@ -1353,6 +1376,8 @@ int ndt_score_transform(ndt_handle* h, const float T[16], ndt_score* out) {
 
 int ndt_comm_info(char* path_buf, size_t cap) { return Reducer::library_info(path_buf, cap); }
 
+int ndt_comm_rank_count(const ndt_handle* h) { return h ? h->red.rank_count() : NDT_ERR_INVALID_ARG; }
+
 // overlap: host work that does not need this evaluation's results, run between the launch and the wait
 static int eval_batch(ndt_handle* h, const double* poses6, const float* transforms, int K, int compute_hessian,
                       bool score_only, double* out, void (*overlap)(void*) = nullptr, void* overlap_ctx = nullptr) {
@@ -1625,6 +1650,21 @@ int ndt_comm_init_rccl(ndt_handle* h, const void* id128, int rank, int nranks) {
 int ndt_comm_init_shm(ndt_handle* h, const char* name, int rank, int nranks) {
   if (!h) return NDT_ERR_INVALID_ARG;
   return h->red.init_shm(name, rank, nranks, &h->err);
+}
+
+int ndt_comm_p2p_handle(ndt_handle* h, void* out_handle) {
+  if (!h || !out_handle) return NDT_ERR_INVALID_ARG;
+  int rc = bind_device(h);
+  if (rc) return rc;
+  return h->red.p2p_handle(out_handle, &h->err);
+}
+
+int ndt_comm_init_p2p(ndt_handle* h, const void* handles, int rank, int nranks) {
+  if (!h || !handles) return NDT_ERR_INVALID_ARG;
+  int rc = bind_device(h);
+  if (rc) return rc;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return h->red.init_p2p(handles, rank, nranks, &h->err);
 }
 
 int ndt_comm_init_hook(ndt_handle* h, ndt_allreduce_fn fn, void* ctx, int rank, int nranks) {

@@ -62,6 +62,16 @@ int Reducer::library_info(char* path_buf, size_t cap) {
   return v;
 }
 
+int Reducer::rank_count() const {
+  if (mode_ == NDT_REDUCE_NONE) return 1;
+  if (mode_ == NDT_REDUCE_RCCL) {
+    int n = 0;
+    if (ncclCommCount(static_cast<ncclComm_t>(nccl_comm_), &n) != ncclSuccess) return NDT_ERR_COMM;
+    return n;
+  }
+  return nranks_;
+}
+
 int Reducer::init_rccl(const void* id128, int rank, int nranks, std::string* err) {
   destroy();
   if (nranks < 1 || rank < 0 || rank >= nranks) return NDT_ERR_INVALID_ARG;
@@ -165,6 +175,147 @@ int Reducer::init_shm(const char* name, int rank, int nranks, std::string* err) 
   return NDT_OK;
 }
 
+namespace {
+std::string hip_err(const char* what, hipError_t e) { return std::string(what) + ": " + hipGetErrorString(e); }
+}  // namespace
+
+int Reducer::p2p_handle(void* out64, std::string* err) {
+  static_assert(sizeof(hipIpcMemHandle_t) == NDT_P2P_HANDLE_BYTES, "hipIpcMemHandle_t is 64 bytes");
+  if (!out64) return NDT_ERR_INVALID_ARG;
+  if (mode_ != NDT_REDUCE_NONE) destroy();
+  if (!xarea_) {
+    // fine-grained (uncached at the device's L2): peers write it over xGMI while a kernel polls it
+    void* p = nullptr;
+    hipError_t e = hipExtMallocWithFlags(&p, XCHG_AREA_BYTES, hipDeviceMallocFinegrained);
+    if (e != hipSuccess || !p) {
+      (void)hipGetLastError();
+      if (err) *err = hip_err("hipExtMallocWithFlags(fine-grained exchange area)", e);
+      return NDT_ERR_COMM;
+    }
+    xarea_ = p;
+  }
+  hipError_t e = hipMemset(xarea_, 0, XCHG_AREA_BYTES);  // round tags start at 1: zeroed rows never match
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  hipIpcMemHandle_t hd;
+  if (e == hipSuccess) e = hipIpcGetMemHandle(&hd, xarea_);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    if (err) *err = hip_err("hipIpcGetMemHandle(exchange area)", e);
+    (void)hipFree(xarea_);
+    xarea_ = nullptr;
+    return NDT_ERR_COMM;
+  }
+  std::memcpy(out64, &hd, sizeof(hd));
+  return NDT_OK;
+}
+
+int Reducer::init_p2p(const void* handles, int rank, int nranks, std::string* err) {
+  if (!handles || nranks < 1 || nranks > XCHG_MAX_RANKS || rank < 0 || rank >= nranks) return NDT_ERR_INVALID_ARG;
+  if (!xarea_) {
+    if (err) *err = "ndt_comm_init_p2p before ndt_comm_p2p_handle";
+    return NDT_ERR_INVALID_ARG;
+  }
+  // peer access to every other visible device (xGMI): kernels of this device will store into their memory
+  int dev = 0, ndev = 0;
+  (void)hipGetDevice(&dev);
+  (void)hipGetDeviceCount(&ndev);
+  for (int d = 0; d < ndev; ++d) {
+    if (d == dev) continue;
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, dev, d) == hipSuccess && can) {
+      hipError_t e = hipDeviceEnablePeerAccess(d, 0);
+      if (e != hipSuccess) (void)hipGetLastError();  // already enabled: fine
+    }
+  }
+  XchgInfo info;
+  std::memset(&info, 0, sizeof(info));
+  info.rank = rank;
+  info.nranks = nranks;
+  for (int r = 0; r < nranks; ++r) {
+    if (r == rank) { xpeer_[r] = xarea_; continue; }
+    hipIpcMemHandle_t hd;
+    std::memcpy(&hd, static_cast<const char*>(handles) + (size_t)r * NDT_P2P_HANDLE_BYTES, sizeof(hd));
+    void* p = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&p, hd, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess || !p) {
+      (void)hipGetLastError();
+      if (err) *err = hip_err("hipIpcOpenMemHandle(peer exchange area)", e);
+      for (int q = 0; q < r; ++q)
+        if (q != rank && xpeer_[q]) { (void)hipIpcCloseMemHandle(xpeer_[q]); xpeer_[q] = nullptr; }
+      return NDT_ERR_COMM;
+    }
+    xpeer_[r] = p;
+  }
+  for (int r = 0; r < nranks; ++r) info.area[r] = (unsigned long long)reinterpret_cast<uintptr_t>(xpeer_[r]);
+  hipError_t e = hipSuccess;
+  if (!xinfo_dev_) e = hipMalloc(&xinfo_dev_, sizeof(XchgInfo));
+  if (e == hipSuccess) e = hipMemcpy(xinfo_dev_, &info, sizeof(info), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    if (err) *err = hip_err("exchange info upload", e);
+    for (int r = 0; r < nranks; ++r)
+      if (r != rank && xpeer_[r]) { (void)hipIpcCloseMemHandle(xpeer_[r]); xpeer_[r] = nullptr; }
+    return NDT_ERR_COMM;
+  }
+  mode_ = NDT_REDUCE_P2P;
+  rank_ = rank;
+  nranks_ = nranks;
+  xround_ = 0;
+  return NDT_OK;
+}
+
+// one row {round, value} x n of the own rank into every rank's area, from the host (batched evaluations)
+int Reducer::p2p_publish_from_host(uint64_t round, const double* words, int n, std::string* err) {
+  unsigned long long row[2 * NDT_EVAL_WORDS];
+  for (int v = 0; v < NDT_EVAL_WORDS; ++v) {
+    row[2 * v] = round;
+    double w = v < n ? words[v] : 0.0;
+    std::memcpy(&row[2 * v + 1], &w, sizeof(double));
+  }
+  for (int r = 0; r < nranks_; ++r) {
+    hipError_t e = hipMemcpy(static_cast<char*>(xpeer_[r]) + xchg_slot_offset(round, rank_, 0), row, sizeof(row), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      if (err) *err = hip_err("peer-write from the host", e);
+      return NDT_ERR_COMM;
+    }
+  }
+  return NDT_OK;
+}
+
+int Reducer::p2p_finish_on_host(uint64_t round, double* words, int n, std::string* err) {
+  if (mode_ != NDT_REDUCE_P2P || n > NDT_EVAL_WORDS) return NDT_ERR_INVALID_ARG;
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned long long rows[XCHG_MAX_RANKS][2 * NDT_EVAL_WORDS];
+  for (;;) {
+    // the generation's rows of ranks 0 .. nranks-1 are contiguous
+    hipError_t e = hipMemcpy(rows, static_cast<const char*>(xarea_) + xchg_slot_offset(round, 0, 0),
+                             (size_t)nranks_ * sizeof(rows[0]), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+      if (err) *err = hip_err("reading the exchange area", e);
+      return NDT_ERR_COMM;
+    }
+    bool ok = true;
+    for (int r = 0; r < nranks_ && ok; ++r)
+      for (int v = 0; v < NDT_EVAL_WORDS && ok; ++v) ok = rows[r][2 * v] == round;
+    if (ok) break;
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
+      if (err) *err = "peer-write all-reduce timed out waiting for a rank";
+      return NDT_ERR_COMM;
+    }
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+  for (int v = 0; v < n; ++v) {
+    double s = 0.0;
+    for (int r = 0; r < nranks_; ++r) {
+      double w;
+      std::memcpy(&w, &rows[r][2 * v + 1], sizeof(double));
+      s += w;
+    }
+    words[v] = s;
+  }
+  return NDT_OK;
+}
+
 int Reducer::init_hook(ndt_allreduce_fn fn, void* ctx, int rank, int nranks) {
   destroy();
   if (!fn || nranks < 1 || rank < 0 || rank >= nranks) return NDT_ERR_INVALID_ARG;
@@ -185,6 +336,15 @@ void Reducer::destroy() {
     munmap(shm_, shm_bytes_);
     if (rank_ == 0) shm_unlink(shm_name_.c_str());
     shm_ = nullptr;
+  }
+  if (mode_ == NDT_REDUCE_P2P || xarea_) {
+    for (int r = 0; r < XCHG_MAX_RANKS; ++r) {
+      if (xpeer_[r] && xpeer_[r] != xarea_) (void)hipIpcCloseMemHandle(xpeer_[r]);
+      xpeer_[r] = nullptr;
+    }
+    if (xinfo_dev_) { (void)hipFree(xinfo_dev_); xinfo_dev_ = nullptr; }
+    if (xarea_) { (void)hipFree(xarea_); xarea_ = nullptr; }
+    xround_ = 0;
   }
   hook_ = nullptr;
   hook_ctx_ = nullptr;
@@ -212,6 +372,15 @@ int Reducer::allreduce_host(double* words, int n, std::string* err) {
       return NDT_ERR_COMM;
     }
     return NDT_OK;
+  }
+  if (mode_ == NDT_REDUCE_P2P) {
+    // host-side round of the same exchange (batched evaluations; single-pose launches exchange inside
+    // the kernel): publish the row into every rank's area, gather the own area, add in rank order
+    if (n > NDT_EVAL_WORDS) return NDT_ERR_INVALID_ARG;
+    const uint64_t round = ++xround_;
+    int rc = p2p_publish_from_host(round, words, n, err);
+    if (rc) return rc;
+    return p2p_finish_on_host(round, words, n, err);
   }
   if (mode_ != NDT_REDUCE_SHM || n > NDT_EVAL_WORDS) return NDT_ERR_INVALID_ARG;
   // Every rank publishes its partial in the slot of this round's parity, bumps

@@ -10,6 +10,7 @@
 #include <string>
 
 #include "../../include/ndt_hip.h"
+#include "ndt_device.h"
 
 namespace ndt {
 
@@ -25,9 +26,24 @@ class Reducer {
   static int unique_id(void* out128);
   // ncclGetVersion() and the shared object that serves the nccl* symbols of this library
   static int library_info(char* path_buf, size_t cap);
+  // ranks of the live reducer as the transport itself reports them (RCCL: ncclCommCount of the
+  // communicator), 1 without a reducer, < 0 on failure
+  int rank_count() const;
   int init_rccl(const void* id128, int rank, int nranks, std::string* err);
   int init_shm(const char* name, int rank, int nranks, std::string* err);
   int init_hook(ndt_allreduce_fn fn, void* ctx, int rank, int nranks);
+  // NDT_REDUCE_P2P (XchgInfo in ndt_device.h): p2p_handle allocates this rank's exchange area on the
+  // current device and exports its IPC handle (NDT_P2P_HANDLE_BYTES); init_p2p maps every rank's area
+  // (handles: nranks x NDT_P2P_HANDLE_BYTES in rank order; the own entry is not opened)
+  int p2p_handle(void* out64, std::string* err);
+  int init_p2p(const void* handles, int rank, int nranks, std::string* err);
+  // the XchgInfo the derivative kernel reads (device memory), and the tag of the NEXT global evaluation
+  const XchgInfo* p2p_info() const { return static_cast<const XchgInfo*>(xinfo_dev_); }
+  uint64_t p2p_round() const { return xround_; }
+  void p2p_set_round(uint64_t r) { xround_ = r; }
+  // host side of the exchange: the rows of round `round` of the own area, waited for (120 s) and added in
+  // rank order -- the continuation of a kernel that reported EV_FAIL = 3 (its own row is published)
+  int p2p_finish_on_host(uint64_t round, double* words, int n, std::string* err);
   void destroy();
 
   // true when the partial must be produced in DEVICE memory (RCCL reduces there)
@@ -47,6 +63,12 @@ class Reducer {
   size_t shm_bytes_ = 0;
   std::string shm_name_;
   uint64_t shm_round_ = 0;
+  // p2p
+  void* xarea_ = nullptr;                 // own exchange area (fine-grained device memory)
+  void* xpeer_[XCHG_MAX_RANKS] = {};      // every rank's area as mapped here; [rank_] == xarea_
+  void* xinfo_dev_ = nullptr;
+  uint64_t xround_ = 0;                   // global evaluations exchanged so far
+  int p2p_publish_from_host(uint64_t round, const double* words, int n, std::string* err);
   // hook
   ndt_allreduce_fn hook_ = nullptr;
   void* hook_ctx_ = nullptr;

@@ -551,10 +551,47 @@ __device__ __forceinline__ int ticket_is_last(unsigned int* counter, unsigned in
 // blockDim/32); SUM_BATCH loads are issued before the first add so one memory round trip covers
 // SUM_BATCH*ncols rows.  The column sums are then added in order and the result is written to
 // dst as tagged slots (group rows, or the host's result buffer) or as 32 plain doubles.
+// Cross-rank step of the final sum (XchgInfo in ndt_device.h): lane v < 32 holds word v of this rank's
+// sum.  Publish it into every rank's area, gather the N rows of the own area, add in rank order.
+// Returns the global word; *late is set when a peer's row had not arrived in time.
+__device__ __forceinline__ double xchg_allsum(const XchgInfo* __restrict__ xi, unsigned long long round, int v,
+                                              double mine, bool* late) {
+  const int me = xi->rank, n = xi->nranks;
+  for (int r = 0; r < n; ++r)
+    store_slot(slots_rsrc(reinterpret_cast<const void*>(xi->area[r])), xchg_slot_offset(round, me, v), round, mine, true);
+  const __amdgpu_buffer_rsrc_t own = slots_rsrc(reinterpret_cast<const void*>(xi->area[me]));
+  const unsigned int tag_lo = (unsigned int)round, tag_hi = (unsigned int)(round >> 32);
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  double s = 0.0;
+  constexpr int XB = 8;  // rows in flight per lane: one memory round trip for a node of 8
+  for (int r0 = 0; r0 < n; r0 += XB) {
+    u32x4 q[XB];
+    for (;;) {
+      asm volatile("" ::: "memory");  // re-issued on every trip
+      bool ok = true;
+#pragma unroll
+      for (int k = 0; k < XB; ++k) {
+        if (r0 + k < n) q[k] = __builtin_amdgcn_raw_buffer_load_b128(own, xchg_slot_offset(round, r0 + k, v), 0, AUX_SYSTEM);
+        else { q[k].x = tag_lo; q[k].y = tag_hi; q[k].z = 0u; q[k].w = 0u; }
+      }
+#pragma unroll
+      for (int k = 0; k < XB; ++k) ok = ok && q[k].x == tag_lo && q[k].y == tag_hi;
+      if (ok) break;
+      if (__builtin_amdgcn_s_memrealtime() - t0 > XCHG_TIMEOUT_TICKS) { *late = true; break; }  // every lane reaches an exit
+      __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int k = 0; k < XB; ++k)
+      if (r0 + k < n) s += __longlong_as_double((long long)(((unsigned long long)q[k].w << 32) | q[k].z));
+  }
+  return s;
+}
+
 __device__ __forceinline__ void sum_rows(__amdgpu_buffer_rsrc_t rows, unsigned int rows_off, int first, int end,
                                          unsigned long long seq, double (*lds_c)[EV_WORDS],
                                          __amdgpu_buffer_rsrc_t dst, unsigned int dst_off, bool dst_system,
-                                         double* plain_dst, int* s_fail) {
+                                         double* plain_dst, int* s_fail, const XchgInfo* __restrict__ xi = nullptr,
+                                         unsigned long long xround = 0ull) {
   const int v = threadIdx.x & 31, c = threadIdx.x >> 5;
   const int ncols = (int)blockDim.x >> 5;
   const unsigned int tag_lo = (unsigned int)seq, tag_hi = (unsigned int)(seq >> 32);
@@ -596,6 +633,12 @@ __device__ __forceinline__ void sum_rows(__amdgpu_buffer_rsrc_t rows, unsigned i
     double t = 0.0;
     for (int k = 0; k < ncols; ++k) t += lds_c[k][threadIdx.x];
     if (threadIdx.x == EV_WORDS - 1 && *s_fail) t += 1.0;
+    if (xi != nullptr && !*s_fail) {
+      // (a local sum that missed rows is NOT published: the host re-evaluates, peers wait for that)
+      bool late = false;
+      t = xchg_allsum(xi, xround, (int)threadIdx.x, t, &late);
+      if (__ballot(late) != 0ull && threadIdx.x == EV_WORDS - 1) t = 3.0;
+    }
     if (plain_dst) plain_dst[threadIdx.x] = t;
     else store_slot(dst, dst_off + threadIdx.x * 16u, seq, t, dst_system);
   }
@@ -612,7 +655,8 @@ __device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], double
                                                     unsigned int* __restrict__ counters,
                                                     double* __restrict__ out,
                                                     unsigned long long* host_slots, unsigned long long seq,
-                                                    int single_level_max, bool fixed_summer) {
+                                                    int single_level_max, bool fixed_summer,
+                                                    const XchgInfo* __restrict__ xi, unsigned long long xround) {
   __shared__ double lds_w[MAX_WAVES][EV_WORDS];
   __shared__ double lds_c[MAX_COLS][EV_WORDS];
   __shared__ int s_last;
@@ -662,7 +706,7 @@ __device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], double
     if (!s_last) return;
   }
   sum_rows(two_level ? rgroups : rrows, 0u, 0, nrows, seq, lds_c, slots_rsrc(host_slots), 0u, true,
-           host_slots ? nullptr : out, &s_fail);
+           host_slots ? nullptr : out, &s_fail, xi, xround);
   NDT_STAMP(6);
   if (threadIdx.x <= ngroups && !(fixed_summer && !two_level))  // leave the tickets at zero for the next launch
     __hip_atomic_store(counters + threadIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -689,6 +733,8 @@ struct DerivKernArgs {
   unsigned long long* flag;
   unsigned long long seq;
   const PoseMailbox* mbox;
+  const XchgInfo* xinfo;
+  unsigned long long xround;
 };
 constexpr unsigned int KERNARG_TABLES_OFFSET = offsetof(DerivKernArgs, pose) + offsetof(PoseConsts, jang);
 static_assert(offsetof(PoseConsts, hang) == offsetof(PoseConsts, jang) + 24 * sizeof(float) &&
@@ -703,7 +749,8 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
               GridGeom g, const int* __restrict__ cell2leaf, const VoxelRecord* __restrict__ rec,
               PoseConsts pose_arg, const PoseConsts* __restrict__ poses, EvalConsts ec,
               double* __restrict__ partials, unsigned int* __restrict__ counters, double* __restrict__ out,
-              unsigned long long* flag, unsigned long long seq, const PoseMailbox* mbox) {
+              unsigned long long* flag, unsigned long long seq, const PoseMailbox* mbox,
+              const XchgInfo* __restrict__ xinfo, unsigned long long xround) {
   // R|t (12 dwords) stay in scalar registers; the 69 angle-table words are only needed
   // after the pair loop, so they are parked in LDS (81 live SGPRs would spill) and the
   // barrier that publishes them sits behind the memory-latency part of the kernel.
@@ -855,7 +902,7 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
                       out + (size_t)blockIdx.y * EV_WORDS,
                       flag ? flag + (size_t)blockIdx.y * ROW_WORDS : nullptr,  // pose y's 32 host slots
                       seq, ec.single_level_max,
-                      ec.fixed_summer != 0);
+                      ec.fixed_summer != 0, BATCH ? nullptr : xinfo, xround);
 }
 
 __global__ void __launch_bounds__(256) k_transform(const float* __restrict__ sx, const float* __restrict__ sy,
@@ -928,7 +975,8 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
                         const PoseConsts& pose, const PoseConsts* d_poses, int K,
                         const EvalConsts& ec, double* d_partials, unsigned int* d_counters,
                         double* d_out, hipStream_t s, unsigned long long* d_flag,
-                        unsigned long long seq, const PoseMailbox* d_mbox) {
+                        unsigned long long seq, const PoseMailbox* d_mbox, const XchgInfo* d_xinfo,
+                        unsigned long long xround) {
   const int blocks = derivs_grid_blocks(n_src, d_poses ? K : 1);
   const int threads = derivs_block_threads(n_src, d_poses ? K : 1);
   const int mode = ec.score_only ? 3 : (!ec.need_hessian ? 0 : (ec.gauss_newton ? 2 : 1));
@@ -949,7 +997,7 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
 #define NDT_LAUNCH2(B, M, NBH, MB, GY, FLAG, SEQ)                                                            \
   hipLaunchKernelGGL((k_derivatives<B, M, NBH, MB>), dim3(blocks, GY), dim3(threads), dyn_lds, s, sx, sy, sz,  \
                      (int)n_src, g, cell2leaf, rec, pose, d_poses, ecl, d_partials, d_counters, d_out,         \
-                     FLAG, SEQ, d_mbox)
+                     FLAG, SEQ, d_mbox, d_xinfo, xround)
 #define NDT_LAUNCH(B, M, NBH, GY, FLAG, SEQ)                                  \
   do {                                                                         \
     if (!B && d_mbox != nullptr) NDT_LAUNCH2(false, M, NBH, true, GY, FLAG, SEQ);  \

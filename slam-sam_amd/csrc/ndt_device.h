@@ -121,8 +121,32 @@ enum {
   EV_NWITH = 29,
   EV_NPAIRS = 30,
   EV_FAIL = 31,    // 0; 1 = the in-kernel final sum gave up waiting for a partial row,
-                   // 2 = a pre-launched kernel gave up waiting for its pose (nothing was evaluated)
+                   // 2 = a pre-launched kernel gave up waiting for its pose (nothing was evaluated),
+                   // 3 = NDT_REDUCE_P2P: this rank's sum was published, a peer's row had not arrived after
+                   //     XCHG_TIMEOUT_TICKS (the host finishes the exchange itself)
   EV_WORDS = 32
 };
+
+// ---- cross-GPU sum of an evaluation INSIDE the kernel's final sum (NDT_REDUCE_P2P) -------------------
+// Every rank owns an exchange area in fine-grained device memory that all ranks of the node have mapped
+// (hipIpcOpenMemHandle; xGMI peer access).  The block that finishes a rank's local sum writes its 32
+// tagged 16-byte slots {round, value} into EVERY rank's area (row = its own rank), then polls the N rows of
+// its own area until all carry this round's tag, adds them in rank order and hands the GLOBAL evaluation
+// to its host -- one one-shot all-gather + local sum, no second launch, no host
+// hop, and the pre-launched / host-polled fast path of a single GPU stays on.  The round number is the
+// count of global evaluations: every rank runs the identical host loop on identical sums, so the counts
+// agree without being exchanged.  Two generations of rows (round parity): a rank can be at most one round
+// ahead of the slowest -- it cannot publish round k + 2 before every peer has published k + 1, which a
+// peer does only after it has finished reading round k (the lesson of the alternating result buffers).
+constexpr int XCHG_MAX_RANKS = 64;
+constexpr size_t XCHG_AREA_BYTES = (size_t)2 * XCHG_MAX_RANKS * EV_WORDS * 16;  // 64 KB
+struct XchgInfo {
+  int rank, nranks;
+  unsigned long long area[XCHG_MAX_RANKS];  // every rank's exchange area as mapped in THIS process; [rank] is local
+};
+__host__ __device__ inline unsigned int xchg_slot_offset(unsigned long long round, int row, int word) {
+  return (unsigned int)((((unsigned int)(round & 1ull) * XCHG_MAX_RANKS + (unsigned int)row) * EV_WORDS + (unsigned int)word) * 16u);
+}
+constexpr unsigned long long XCHG_TIMEOUT_TICKS = 2000000ull;  // 20 ms: a peer that is later than that is waited for by the host
 
 }  // namespace ndt

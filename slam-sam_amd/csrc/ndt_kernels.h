@@ -118,7 +118,10 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
                         const PoseConsts& pose, const PoseConsts* d_poses, int K,
                         const EvalConsts& ec, double* d_partials, unsigned int* d_counters,
                         double* d_out, hipStream_t s, unsigned long long* d_host_slots,
-                        unsigned long long seq, const PoseMailbox* d_mbox = nullptr);
+                        unsigned long long seq, const PoseMailbox* d_mbox = nullptr,
+                        // NDT_REDUCE_P2P (single-pose launches): the block that finishes the local sum
+                        // exchanges it with the other ranks under the tag `xround` (XchgInfo, ndt_device.h)
+                        const XchgInfo* d_xinfo = nullptr, unsigned long long xround = 0ull);
 
 void launch_transform(const float* sx, const float* sy, const float* sz, size_t n,
                       const PoseConsts& pose, float* out_xyz, hipStream_t s);

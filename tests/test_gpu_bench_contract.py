@@ -27,7 +27,7 @@ def test_bench_line_schema():
     assert d["value"] > 0 and d["ms_per_step"] > 0
     assert abs(d["value"] - d["iterations_per_align"] * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
     rf = d["roofline"]
-    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert rf["bound"] == "latency/valu" and rf["roof"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0 < rf["frac"] < 1
     assert rf["traffic"] is None or (rf["traffic"] > 0 and rf["traffic_source"].startswith("static: profiles/"))
     rb = d["roofline_build"]
@@ -41,3 +41,39 @@ def test_bench_line_schema():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "iterations/s" and cb["sample"]
     assert cb["nproc"] >= cb["cores"] and cb["cpus_usable"] >= 1 and "-O" in cb["build_flags"] and cb["threads_8"]["threads"] <= 8
     assert d["final_error_vs_ground_truth"]["m"] < 0.05
+
+
+def test_bench_gpus_2_from_a_plain_invocation():
+    """`python bench.py --gpus 2` exactly as the driver invokes N = 1 (no launcher, no WORLD_SIZE): the
+    process starts its two ranks itself, torch-free; here both ranks share the box's one device
+    (NDT_BENCH_SINGLE_DEVICE=1), so RCCL is skipped by name (it refuses duplicate GPUs) while the
+    shared-memory and the peer-write transports are both timed.  One JSON line, rc 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NDT_RANKS_BOARD")}
+    env.update(NDT_BENCH_PROBE="0", NDT_BENCH_SINGLE_DEVICE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    v = d["config"]["reduce_variants"]
+    assert set(v) == {"shm", "p2p", "rccl"} and v["rccl"] is None and d.get("reduce_failed") == "rccl"
+    assert v["shm"]["value"] > 0 and v["p2p"]["value"] > 0 and v["shm"]["ranks"] == 2 and v["p2p"]["ranks"] == 2
+    assert d["config"]["reduce"] in ("shm", "p2p") and d["config"]["launch"] == "self-launched ranks"
+    assert d["config"]["sharding"] == "source/2" and d["final_error_vs_ground_truth"]["m"] < 0.05
+
+
+def test_bench_forced_distributed_one_rank_runs_rccl():
+    """NDT_BENCH_FORCE_DIST=1: the whole multi-rank path with ONE rank -- the only way to execute the RCCL
+    leg (ncclCommInitRank + one ncclAllReduce per evaluation) on a 1-GPU box.  The line reports the
+    communicator's own rank count and which librccl served it: the process holds no torch, so it is ROCm's."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NDT_RANKS_BOARD")}
+    env.update(NDT_BENCH_PROBE="0", NDT_BENCH_FORCE_DIST="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
+    v = d["config"]["reduce_variants"]
+    assert v["rccl"]["ncclCommCount"] == 1 and v["rccl"]["value"] > 0 and v["shm"]["value"] > 0 and v["p2p"]["value"] > 0
+    assert "/opt/rocm" in d["config"]["rccl"]["library"] and "torch" not in d["config"]["rccl"]["library"]

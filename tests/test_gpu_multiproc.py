@@ -1,8 +1,10 @@
 """N>1 path on the GPU: two processes share the one MI355X of the test box, each owns a
 handle, builds the (replicated) voxel table, takes its shard of the source and sums the
-32-double evaluation through the shared-memory reducer of the C-ABI.  The sharded align
-must reproduce the single-process align.  (RCCL refuses two ranks on one device, so the
-RCCL reducer is exercised only by bench.py on a multi-GPU node.)"""
+32-double evaluation through the shared-memory reducer of the C-ABI, and through the in-kernel
+peer-write reducer (NDT_REDUCE_P2P; hipIpc works between two processes on one device).  The sharded
+align must reproduce the single-process align, and the two transports must agree bit for bit.
+(RCCL refuses two ranks on one device, so the RCCL reducer is exercised with several ranks only by
+bench.py on a multi-GPU node.)"""
 import os
 import sys
 
@@ -13,10 +15,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, name, out_dir):
+def _worker(rank, world, name, out_dir, mode="shm"):
     sys.path.insert(0, ROOT)
     import __graft_entry__ as ge
     pkg = ge.load_package()
+    board = pkg.ranks.Board("/dev/shm" + name + "_board", rank, world, timeout=120) if mode == "p2p" else None
     S = pkg.synth
     cfg = S.config_c2()
     ndt = pkg.NormalDistributionsTransform(device_id=0, resolution=1.0, step_size=0.1, trans_epsilon=1e-4,
@@ -25,14 +28,26 @@ def _worker(rank, world, name, out_dir):
     b, c = pkg.shard_range(len(cfg["source"]), rank, world)
     ndt.setInputSource(cfg["source"][b:b + c])
     ndt.setGlobalSourceSize(len(cfg["source"]))
-    ndt.commInitShm(name, rank, world)
+    if mode == "p2p":
+        ndt.commInitP2p(b"".join(board.allgather(ndt.commP2pHandle())), rank, world)
+    else:
+        ndt.commInitShm(name, rank, world)
+    assert ndt.commRankCount() == world
     T = ndt.align(cfg["guess"])
     r = ndt.getResult()
-    e = ndt.evalDerivatives(r["pose"])[0]
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), T=T, it=r["iterations"], ev=r["n_evaluations"],
-             H=r["hessian"], tp=r["transform_probability"], n_pairs=e["n_pairs"], score=e["score"])
+    used, quit, timeouts = ndt.prelaunchCounters()
+    e = ndt.evalDerivatives(r["pose"])[0]            # a batch of one: the host-side round of the same exchange
+    sc = ndt.scoreTransform(T)                        # score-only kernel through the in-kernel exchange
+    T2 = ndt.align(cfg["guess"])                      # a second align on the same reducer (round tags keep counting)
+    np.savez(os.path.join(out_dir, "%s_rank%d.npz" % (mode, rank)), T=T, T2=T2, it=r["iterations"], ev=r["n_evaluations"],
+             H=r["hessian"], tp=r["transform_probability"], n_pairs=e["n_pairs"], score=e["score"], g=e["gradient"],
+             sc=sc["score"], used=used, timeouts=timeouts)
+    if board is not None:
+        board.barrier()   # nobody unmaps a peer's area while that peer may still write into it
     ndt.commDestroy()
     ndt.close()
+    if board is not None:
+        board.close()
 
 
 def test_two_processes_one_gpu_shm_reduction(pkg, S, tmp_path):
@@ -53,7 +68,7 @@ def test_two_processes_one_gpu_shm_reduction(pkg, S, tmp_path):
     ndt.setInputSource(cfg["source"])
     T = ndt.align(cfg["guess"])
     r = ndt.getResult()
-    z = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % k)) for k in range(world)]
+    z = [np.load(os.path.join(str(tmp_path), "shm_rank%d.npz" % k)) for k in range(world)]
     # both ranks hold the same global result ...
     assert np.array_equal(z[0]["T"], z[1]["T"]) and np.array_equal(z[0]["H"], z[1]["H"])
     assert int(z[0]["it"]) == int(z[1]["it"]) and int(z[0]["ev"]) == int(z[1]["ev"])
@@ -64,3 +79,30 @@ def test_two_processes_one_gpu_shm_reduction(pkg, S, tmp_path):
     # points sitting on a voxel face can be counted differently
     assert abs(int(z[0]["n_pairs"]) - int(r["n_pairs"])) <= max(2, 1e-4 * r["n_pairs"])
     assert float(z[0]["tp"]) == pytest.approx(r["transform_probability"], rel=1e-6)
+
+
+def test_two_processes_one_gpu_peer_write_reduction_equals_shm(pkg, S, tmp_path):
+    """NDT_REDUCE_P2P: each rank's summing block writes its 32 tagged slots into every rank's exchange area
+    (IPC-mapped device memory), polls its own area and adds the rows in rank order -- inside the derivative
+    kernel.  Same rows, same order as the shared-memory reducer: every number of the align must be
+    identical, on both ranks; and the pre-launched fast path stays on (it is off under RCCL)."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    world = 2
+    for mode in ("shm", "p2p"):
+        name = "/ndt_test_%s_%d" % (mode, os.getpid())
+        procs = [ctx.Process(target=_worker, args=(r, world, name, str(tmp_path), mode)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(600)
+            assert p.exitcode == 0, mode
+    z = {m: [np.load(os.path.join(str(tmp_path), "%s_rank%d.npz" % (m, k))) for k in range(world)] for m in ("shm", "p2p")}
+    for key in ("T", "T2", "H", "it", "ev", "tp", "n_pairs", "score", "g", "sc"):
+        a = z["shm"][0][key]
+        for m in ("shm", "p2p"):
+            for k in range(world):
+                assert np.array_equal(z[m][k][key], a), (key, m, k)
+    assert np.array_equal(z["p2p"][0]["T"], z["p2p"][0]["T2"])
+    # evaluations served by kernels that were already waiting on the device for their pose
+    assert all(int(z["p2p"][k]["used"]) > 0 for k in range(world))
