@@ -184,6 +184,12 @@ def main():
     rehearsal = os.environ.get("NDT_BENCH_SINGLE_DEVICE", "0") == "1"
     if rehearsal:
         local_rank = 0
+    # stdout carries ONE JSON line and nothing else: native libraries write there too (librccl prints
+    # "RCCL version : ..." on its first communicator), so file descriptor 1 is pointed at stderr for the
+    # life of the rank and the line goes out through a private copy of the original descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     hip = R.Hip()
     if hip.device_count() <= 0:
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
@@ -488,7 +494,7 @@ def main():
             if rank == 0 and state["out"] is not None:
                 state["out"]["config"]["reduce_variants"]["rccl"] = "timed out"
                 state["out"]["reduce_failed"] = "rccl"
-                print(json.dumps(state["out"]), flush=True)
+                os.write(json_fd, (json.dumps(state["out"]) + "\n").encode())
             if shm_name["name"]:
                 try:
                     os.unlink("/dev/shm" + shm_name["name"])
@@ -545,7 +551,8 @@ def main():
     if board is not None:
         board.close()
     if out is not None:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":
