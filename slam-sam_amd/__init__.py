@@ -630,8 +630,9 @@ class NormalDistributionsTransform:
         return tuple(out)
 
     def buildCounters(self):
-        """(builds that fell back from the fused sort passes to the classic ones,)."""
-        out = (C.c_int64 * 1)()
+        """(builds that fell back from the fused sort passes to the classic ones, two-launch bucketed builds
+        that were declined and repeated sort-based, builds that went through in two launches)."""
+        out = (C.c_int64 * 3)()
         self._check(lib().ndt_debug_build_counters(self._h, out))
         return tuple(out)
 

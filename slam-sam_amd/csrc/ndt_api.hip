@@ -101,6 +101,8 @@ struct ndt_handle {
   DevBuf<uint32_t> run_tags;          // tagged block leaf counts of the fused run search
   uint32_t run_seq = 0;
   long long n_fused_sort_fallbacks = 0;
+  DevBuf<int> bucket_off;             // first point of every bucket (two-launch bucketed build)
+  long long n_bucket_builds = 0, n_bucket_fallbacks = 0;
   const float* vx = nullptr;          // the source as evaluated: the engine's own copy (sx/sy/sz) or,
   const float* vy = nullptr;          // after ndt_set_source_device_view, the caller's arrays
   const float* vz = nullptr;
@@ -336,14 +338,15 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
   const float leaf = h->prm.resolution, inv_leaf = 1.0f / h->prm.resolution;
 
   HIP_TRY(h, h->small.ensure(16));
-  HIP_TRY(h, h->brows.ensure(8 * (size_t)nrows));
+  HIP_TRY(h, h->brows.ensure(8 * (size_t)std::max(nrows, bucket_build_tiles(n))));
+  HIP_TRY(h, h->bucket_off.ensure(260));
   HIP_TRY(h, h->gd.ensure(1));
   HIP_TRY(h, h->gdh.ensure(1));
   if (!h->tickets.p) {
     HIP_TRY(h, h->tickets.ensure(3));
     HIP_TRY(h, hipMemsetAsync(h->tickets.p, 0, h->tickets.cap * sizeof(unsigned int), s));
   }
-  HIP_TRY(h, h->nleaf.ensure(2));
+  HIP_TRY(h, h->nleaf.ensure(4));  // [0] slots, [1] valid, [2] buckets that declined (two-launch build)
   // a re-allocation of `stats` would lose the cells the previous build published
   if ((size_t)max_leaves > h->stats.cap) clean_cap = 0;
   HIP_TRY(h, h->keys.ensure(n));
@@ -362,7 +365,9 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
   // fused = launches that wait, inside the kernel, for sibling blocks (k_sort_pass, k_runs<RUNS_FUSED>)
   bool fused = fused_build_enabled();
   const bool fused_sort = fused && fused_sort_fits(n, h->n_cus);
-  if (fused_sort && !h->sort_tags.p) {
+  // the two-launch build: steady state only (decided per attempt below), and it shares the tag table
+  bool bucketed_ok = bucket_build_enabled() && bucket_build_fits(n, h->n_cus);
+  if ((fused_sort || bucketed_ok) && !h->sort_tags.p) {
     HIP_TRY(h, h->sort_tags.ensure(fused_table_words()));
     HIP_TRY(h, hipMemsetAsync(h->sort_tags.p, 0, h->sort_tags.cap * sizeof(uint32_t), s));
     h->sort_seq = 0;
@@ -383,14 +388,23 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
   bool built = false;
   static const bool poll_env = [] { const char* e = getenv("NDT_BUILD_WAIT"); return !(e && std::strcmp(e, "sync") == 0); }();
   const bool poll_done = poll_env && h->prm.wait_mode == NDT_WAIT_SPIN;
-  for (int attempt = 0; attempt < 3; ++attempt) {
+  for (int attempt = 0; attempt < 5; ++attempt) {
     const bool optimistic = clean_cap != 0 && clean_cap == h->cell2leaf.cap;
+    const bool bucketed = bucketed_ok && optimistic;
     const long long lim = std::numeric_limits<int32_t>::max();
     const long long cap_cells = optimistic ? (long long)h->cell2leaf.cap : lim;
     int passes = optimistic ? sort_passes_for_cells(cap_cells) : 0;
     h->gdh.h->status = -1;
     const int done_tag = (int)((++h->build_seq << 1) & 0x7fffffffu) | 1;  // odd: never 0, never the previous one
     h->small.h[10] = 0;
+    if (bucketed) {
+      // bounds, partition, sort, sums and statistics in two launches (k_bucket_pass, k_bucket_leaves)
+      FinalizeParams fpb{h->prm.eig_inflation_ratio, h->prm.cov_mode};
+      HIP_TRY(h, launch_bucket_build(x, y, z, n, leaf, inv_leaf, cap_cells, min_pts, fpb, h->gd.p, h->gdh.d, h->sort_tags.p,
+                                     &h->sort_seq, h->stats.p, dirty_slots, h->cell2leaf.p, h->cell2leaf.cap, h->brows.p,
+                                     h->bucket_off.p, h->nleaf.p, h->tickets.p + 2, h->xyz4.p, h->leaf_sums.p, h->rec.p,
+                                     h->stats.p, max_leaves, h->small.d + 8, done_tag, s));
+    } else {
     launch_bounds_geometry(x, y, z, n, leaf, inv_leaf, cap_cells, passes, h->brows.p, h->tickets.p, h->gd.p, h->gdh.d,
                            optimistic ? h->stats.p : nullptr, optimistic ? dirty_slots : 0, h->cell2leaf.p,
                            h->cell2leaf.cap, h->nleaf.p, s);
@@ -422,6 +436,7 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
     launch_finalize_leaves(h->xyz4.p, keys_sorted, vals_sorted, h->nleaf.p, h->leaf_start.p, h->leaf_cnt.p, max_leaves,
                            fp, h->leaf_sums.p, h->rec.p, h->stats.p, h->cell2leaf.p, h->fin_counts.p, h->tickets.p + 2,
                            h->small.d + 8, done_tag, s);
+    }  // (sort-based pipeline)
     HIP_TRY(h, hipGetLastError());
     if (build_events) HIP_TRY(h, hipEventRecord(h->ev1, s));
     if (poll_done) {
@@ -437,6 +452,7 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
         if ((++spins & 0xfffu) == 0 &&
             std::chrono::steady_clock::now() - t_wait > std::chrono::seconds(2)) break;
       }
+      std::atomic_thread_fence(std::memory_order_acquire);  // counts and geometry are read after the tag
       if (*done == done_tag) {
         if (build_events) {
           hipError_t q;
@@ -450,6 +466,18 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
       HIP_TRY(h, hipStreamSynchronize(s));
     }
     const BuildGeom& bg = *h->gdh.h;
+    if (bucketed && (bg.status == BG_BUCKET || bg.status == BG_SPIN)) {
+      // declined (a bucket beyond a block's LDS or table, huge coordinates) or gave up waiting for sibling
+      // blocks.  Once more, sort-based.  BG_SPIN: neither launch has written a leaf and the old cells are
+      // already reset; BG_BUCKET may come late (one bucket's table overflowed after others had published
+      // leaves): that retry does not trust the grid -- full clear, geometry awaited.
+      bucketed_ok = false;
+      dirty_slots = 0;
+      if (bg.status == BG_BUCKET) clean_cap = 0;
+      ++h->n_bucket_fallbacks;
+      continue;
+    }
+    if (bucketed && bg.status == BG_OK) ++h->n_bucket_builds;
     if (optimistic && (bg.status == BG_CAPACITY || bg.status == BG_PASSES)) {
       // the cloud outgrew the dense grid (or the enqueued sort passes): nothing after the bounds
       // kernel ran; the old cells were reset by it.  Once more, waiting for the geometry.
@@ -470,8 +498,13 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
       continue;
     }
     if (bg.status == BG_NO_FINITE) return fail(h, NDT_ERR_NO_TARGET, "target has no finite point");
+    if (bg.status == BG_OVERFLOW)
+      return fail(h, NDT_ERR_GRID_OVERFLOW, std::string("leaf size too small for the target extent (index overflow)") +
+                                                (bucketed ? " [two-launch build" : " [sort-based build") + ", finite points " +
+                                                std::to_string(bg.n_finite) + "]");
     if (bg.status != BG_OK)
-      return fail(h, NDT_ERR_GRID_OVERFLOW, "leaf size too small for the target extent (index overflow)");
+      return fail(h, NDT_ERR_HIP, "voxel-grid build ended without a verdict (internal, status " + std::to_string(bg.status) +
+                                      (bucketed ? ", two-launch build)" : ", sort-based build)"));
     h->geom = bg.g;
     for (int a = 0; a < 3; ++a) h->max_b[a] = bg.max_b[a];
     built = true;
@@ -952,7 +985,7 @@ int ndt_destroy(ndt_handle* h) {
   h->keys.release(); h->vals.release(); h->keys2.release(); h->vals2.release();
   h->sort_tmp.release(); h->nleaf.release(); h->leaf_start.release(); h->leaf_cnt.release();
   h->cell2leaf.release(); h->rec.release(); h->stats.release();
-  h->run_counts.release(); h->run_offsets.release(); h->fin_counts.release(); h->upl_tmp.release(); h->sort_tags.release(); h->run_tags.release(); h->xyz4.release(); h->leaf_sums.release();
+  h->run_counts.release(); h->run_offsets.release(); h->fin_counts.release(); h->bucket_off.release(); h->upl_tmp.release(); h->sort_tags.release(); h->run_tags.release(); h->xyz4.release(); h->leaf_sums.release();
   h->brows.release(); h->tickets.release(); h->gd.release(); h->gdh.release();
   for (auto& kv : h->keyframes) { kv.second.x.release(); kv.second.y.release(); kv.second.z.release(); }
   h->keyframes.clear();
@@ -1693,9 +1726,11 @@ int ndt_debug_prelaunch_counters(const ndt_handle* h, int64_t out[3]) {
 
 // test seam (not in the public header): builds that fell back from the fused sort passes to the
 // classic ones after a block gave up waiting
-int ndt_debug_build_counters(const ndt_handle* h, int64_t out[1]) {
+int ndt_debug_build_counters(const ndt_handle* h, int64_t out[3]) {
   if (!h || !out) return NDT_ERR_INVALID_ARG;
   out[0] = h->n_fused_sort_fallbacks;
+  out[1] = h->n_bucket_fallbacks;   // two-launch builds that were declined and repeated sort-based
+  out[2] = h->n_bucket_builds;      // builds that went through in two launches
   return NDT_OK;
 }
 

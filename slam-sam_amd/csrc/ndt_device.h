@@ -27,7 +27,9 @@ struct GridGeom {
 // Geometry + sort plan of one target build, computed ON THE DEVICE by the last block of the
 // bounds kernel (the host used to stop mid-build for it) and read by every later build kernel
 // from device memory; the host gets a copy through pinned memory at the end of the build.
-enum { BG_OK = 0, BG_NO_FINITE = 1, BG_OVERFLOW = 2, BG_CAPACITY = 3, BG_PASSES = 4, BG_SPIN = 5 };
+enum { BG_OK = 0, BG_NO_FINITE = 1, BG_OVERFLOW = 2, BG_CAPACITY = 3, BG_PASSES = 4, BG_SPIN = 5,
+       BG_BUCKET = 6 /* the two-launch bucketed build declined this cloud (a bucket beyond a block's LDS, huge
+                        coordinates): the host repeats the build with the sort-based pipeline */ };
 struct BuildGeom {
   GridGeom g;
   int max_b[3];

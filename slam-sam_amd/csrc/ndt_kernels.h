@@ -6,6 +6,10 @@
 namespace ndt {
 
 // ---- target voxel-grid build (ndt_target.hip) ------------------------------
+struct FinalizeParams {
+  double eig_ratio;
+  int cov_mode;  // 0 svn, 1 pcl (recalled)
+};
 // One launch: per-block bounds rows (device memory, bounds_rows(n) x 8 ints), the fold of the
 // rows + the grid geometry + the sort plan by the block that draws the last ticket (into *gd,
 // device memory, and *gd_host, a pinned copy for the host to read at the end of the build),
@@ -48,6 +52,21 @@ hipError_t sort_cloud_fused(const float* x, const float* y, const float* z, size
                             uint32_t* vals_b, int passes, uint32_t* table, uint32_t* seq, hipStream_t s,
                             bool* result_in_b);
 
+// The whole build in TWO launches (k_bucket_pass + k_bucket_leaves, ndt_target.hip): steady state only --
+// every buffer exists and the dense grid holds nothing but the `dirty_slots` cells of old_stats.  `table` /
+// *seq: the tagged tile-count table of the fused sort passes (shared with them).  rows: 8 ints per tile of
+// 8192 points; bucket_off: 257 ints; pts4: n float4 (the cloud partitioned by bucket); sums: 9 doubles per
+// leaf slot.  Refusals leave BG_BUCKET / BG_SPIN / BG_CAPACITY / ... in *gd_host with nothing written.
+bool bucket_build_enabled();                            // NDT_BUCKET_BUILD != 0 (default on)
+bool bucket_build_fits(size_t n, int compute_units);
+int bucket_build_tiles(size_t n);
+hipError_t launch_bucket_build(const float* x, const float* y, const float* z, size_t n, float leaf, float inv_leaf,
+                               long long cell_capacity, int min_pts, FinalizeParams fp, BuildGeom* gd, BuildGeom* gd_host,
+                               uint32_t* table, uint32_t* seq, const LeafStats* old_stats, int dirty_slots, int* cell2leaf,
+                               size_t c2l_cap, int* rows, int* bucket_off, int* d_nleaf, unsigned int* ticket, float* pts4,
+                               double* sums, VoxelRecord* rec, LeafStats* stats, int max_leaves, int* nleaf_host,
+                               int done_tag, hipStream_t s);
+
 // runs of equal cell key with >= min_pts points get a leaf slot (ascending cell order);
 // block_counts / block_offsets: runs_blocks(n) ints each; d_nleaf[0] receives the total
 // (count pass; its last block also scans the counts); *ticket as above
@@ -59,10 +78,6 @@ hipError_t launch_find_runs(const uint32_t* keys_sorted, size_t n, BuildGeom* gd
                             int* d_nleaf, int* block_counts, int* block_offsets, unsigned int* ticket, uint32_t* run_tags,
                             size_t run_tags_cap, uint32_t* seq, int* leaf_start, int* leaf_cnt, hipStream_t s);
 
-struct FinalizeParams {
-  double eig_ratio;
-  int cov_mode;  // 0 svn, 1 pcl (recalled)
-};
 // tmp: the cloud chunk by chunk as [x | y | z] of `chunk` points (the last chunk shorter) -> SoA arrays
 void launch_unchunk_soa(const float* tmp, size_t n, size_t chunk, float* x, float* y, float* z, hipStream_t s);
 // multi-grid union table: cell2leaf[cells[i]] = slots[i], i < n (device arrays)

@@ -45,7 +45,7 @@ constexpr int BOUNDS_BLOCKS = 512;
 #ifdef NDT_STAMPS
 // diagnostic build only: 100 MHz wall-clock stamps of thread 0 of every block of the fused build
 // kernels (slot 0-2: sort pass 0-2, 3: run search), written to a side buffer no other code reads
-__device__ unsigned long long g_bstamps[4 * 512 * 8];
+__device__ unsigned long long g_bstamps[6 * 512 * 8];  // slots 4 / 5: k_bucket_pass / k_bucket_leaves
 #define NDT_BSTAMP(slot, k)                                                                  \
   do {                                                                                       \
     if (threadIdx.x == 0 && blockIdx.x < 512)                                                \
@@ -1022,6 +1022,9 @@ __device__ __forceinline__ bool finalize_one(int slot, const uint32_t* __restric
                                              const double* __restrict__ sums, FinalizeParams fp,
                                              VoxelRecord* __restrict__ rec, LeafStats* __restrict__ stats,
                                              int* __restrict__ cell2leaf);
+__device__ __forceinline__ bool finalize_leaf(int slot, int cell, int cnt, const double* __restrict__ in, FinalizeParams fp,
+                                              VoxelRecord* __restrict__ rec, LeafStats* __restrict__ stats,
+                                              int* __restrict__ cell2leaf);
 
 // ref: voxel_grid_covariance_impl.hpp:265-343 -- one thread per leaf: mean, covariance,
 // eigen-decomposition, eigenvalue inflation, inverse, validity checks.  (Fusing this into the
@@ -1090,10 +1093,15 @@ __device__ __forceinline__ bool finalize_one(int slot, const uint32_t* __restric
                                              VoxelRecord* __restrict__ rec, LeafStats* __restrict__ stats,
                                              int* __restrict__ cell2leaf) {
   const int start = leaf_start[slot], cnt = leaf_cnt[slot];
-  const double* in = sums + (size_t)slot * 9;
+  return finalize_leaf(slot, (int)keys[start], cnt, sums + (size_t)slot * 9, fp, rec, stats, cell2leaf);
+}
+
+// one leaf: count, cell, and its nine moment sums -> statistics, record, dense index entry
+__device__ __forceinline__ bool finalize_leaf(int slot, int cell, int cnt, const double* __restrict__ in, FinalizeParams fp,
+                                              VoxelRecord* __restrict__ rec, LeafStats* __restrict__ stats,
+                                              int* __restrict__ cell2leaf) {
   const double s[3] = {in[0], in[1], in[2]};
   const double ss[6] = {in[3], in[4], in[5], in[6], in[7], in[8]};
-  const int cell = (int)keys[start];
   const double n = (double)cnt;
   double mean[3] = {s[0] / n, s[1] / n, s[2] / n};  // ref :278
   double C[9];
@@ -1266,6 +1274,790 @@ __global__ void __launch_bounds__(256) k_leaf_sums(const float4* __restrict__ xy
                       : sub == 4 ? m.ss[1] : sub == 5 ? m.ss[2] : sub == 6 ? m.ss[3] : m.ss[4];
     o[sub] = mine;
     if (sub == 0) o[8] = m.ss[5];
+  }
+}
+
+// ---- bucketed build: TWO launches for the whole voxel grid (round 3) ----------------------------------
+// The sort-based pipeline above moves (key, index) pairs through HBM three times and then gathers the
+// points at random (2.5x the algorithmic traffic, eight dependent launches, profiles/r02_pmc_summary.txt).
+// Grouping points by voxel needs no global ORDER of the voxels, only (a) all points of a voxel in one
+// place and (b) their input order kept (the f64 sums must be bit-reproducible: every rank of a multi-GPU
+// job builds its own table and all must agree).  So:
+//   k_bucket_pass    one pass over the cloud: bounds rows (the geometry is derived later), and a STABLE
+//                    partition of the points themselves into 256 buckets by a hash of the point's absolute
+//                    voxel coordinates (floor(p / leaf): no grid geometry needed, so this launch does not
+//                    wait for the bounds) -- the ranking, the self-validating tile-count table and the
+//                    LDS-staged scatter of k_sort_pass, carrying 16-byte points instead of (key, index).
+//                    A hash of single voxels balances the buckets whatever the scene looks like (C3: 178
+//                    occupied voxels per bucket, largest bucket 1.6x the mean).
+//   k_bucket_leaves  one 1024-thread block per bucket, everything in LDS: derive the geometry (every block
+//                    folds the bounds rows: same f32 arithmetic, same result), cell keys, stable LSD radix
+//                    sort of (key, local index) in LDS, run search, per-voxel sums gathered from LDS in
+//                    input order (no random HBM gathers), Jacobi / inflation / inverse, records + dense
+//                    index.  Leaf slots are handed out by one atomic add per block: slot ORDER differs
+//                    from run to run, nothing observable depends on it (exports sort by cell; a point's
+//                    pairs are added in neighbour order, not slot order).
+// Traffic: 12 MB read + 16 MB written, then 16 MB read + the leaves (C3) -- below SURVEY 8d's algorithmic
+// 61 MB.  Steady state only (every buffer exists, the dense grid is clean); clouds whose largest bucket
+// would not fit a block's LDS (BK_MAXP points: more than ~1.3 M points, or one voxel holding thousands),
+// coordinates beyond 2^23 voxels, devices with fewer CUs than tiles, and first builds take the sort-based
+// pipeline, which stays in the file as the fallback (status BG_BUCKET).
+constexpr int BK_BUCKETS = 256;
+constexpr int BK_THREADS = 1024;
+constexpr int BK_WAVES = BK_THREADS / 64;
+constexpr int BK_ROUNDS = 8;
+constexpr int BK_MAXP = BK_THREADS * BK_ROUNDS;   // 8192 points per bucket block
+constexpr int BK_MAX_LEAVES = BK_MAXP / 3;        // min_points_per_voxel >= 3
+constexpr float BK_COORD_LIMIT = 8388608.0f;      // 2^23 voxels: below it floor(p / leaf) - min_b is exact in f32
+
+// points of one voxel have identical floor(p * inv_leaf) triples, hence one bucket
+__device__ __forceinline__ uint32_t bucket_of(float fx, float fy, float fz) {
+  const uint32_t i = (uint32_t)__float2int_rz(fx), j = (uint32_t)__float2int_rz(fy), k = (uint32_t)__float2int_rz(fz);
+  uint32_t h = (i * 0x9E3779B1u) ^ (j * 0x85EBCA77u) ^ (k * 0xC2B2AE3Du);
+  h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+  return h >> 24;
+}
+
+__global__ void __launch_bounds__(BK_THREADS) k_bucket_pass(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ z, int n, float inv_leaf, int ntiles,
+                                                           uint32_t* __restrict__ table, uint32_t tag, int mute_tile,
+                                                           BuildGeom* __restrict__ gd, BuildGeom* __restrict__ gd_host,
+                                                           const LeafStats* __restrict__ old_stats, int dirty_slots,
+                                                           int* __restrict__ cell2leaf, size_t c2l_cap,
+                                                           int* __restrict__ rows, int* __restrict__ bucket_off,
+                                                           int* __restrict__ d_nleaf, float4* __restrict__ pts_out) {
+  constexpr int ROUNDS = BK_ROUNDS;
+  constexpr int TILE = BK_THREADS * ROUNDS;
+  __shared__ int cnt[BK_WAVES][SORT_BINS];
+  // the column partial sums, and later -- once they have been folded -- the tile in bucket order
+  __shared__ float4 stage[TILE];
+  int (*part_total)[SORT_BINS] = reinterpret_cast<int (*)[SORT_BINS]>(stage);
+  int (*part_before)[SORT_BINS] = reinterpret_cast<int (*)[SORT_BINS]>(reinterpret_cast<int*>(stage) + BK_WAVES * SORT_BINS);
+  __shared__ int gbase[SORT_BINS];
+  __shared__ int lbase[SORT_BINS];
+  __shared__ int wsum[2 * SORT_BINS / 64];
+  __shared__ int wrow[BK_WAVES][8];
+  __shared__ int s_fail;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = blockIdx.x;
+  // the cells the PREVIOUS build published (the dense grid is filled with -1 once per allocation)
+  for (int slot = blockIdx.x * BK_THREADS + threadIdx.x; slot < dirty_slots; slot += gridDim.x * BK_THREADS) {
+    const int cell = old_stats[slot].cell;
+    if (cell >= 0 && (size_t)cell < c2l_cap) cell2leaf[cell] = -1;
+  }
+  if (tile == 0 && threadIdx.x == 0) { d_nleaf[0] = 0; d_nleaf[1] = 0; d_nleaf[2] = 0; }
+  NDT_BSTAMP(4, 0);
+  float a[ROUNDS], b[ROUNDS], c[ROUNDS];
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {  // all loads of the tile in flight before any use
+    const int i = fused_index<ROUNDS>(tile, wave, r, lane);
+    const int j = i < n ? i : 0;
+    a[r] = x[j]; b[r] = y[j]; c[r] = z[j];
+  }
+  uint32_t dig[ROUNDS];
+  int mn[3] = {INT_MAX, INT_MAX, INT_MAX}, mx[3] = {INT_MIN, INT_MIN, INT_MIN}, nfin = 0;
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const int i = fused_index<ROUNDS>(tile, wave, r, lane);
+    dig[r] = 0u;  // non-finite points ride in bucket 0; k_bucket_leaves drops them
+    if (i < n && finite3(a[r], b[r], c[r])) {
+      dig[r] = bucket_of(floorf(a[r] * inv_leaf), floorf(b[r] * inv_leaf), floorf(c[r] * inv_leaf));
+      const int ea = encode_ordered(a[r]), eb = encode_ordered(b[r]), ec = encode_ordered(c[r]);
+      mn[0] = min(mn[0], ea); mx[0] = max(mx[0], ea);
+      mn[1] = min(mn[1], eb); mx[1] = max(mx[1], eb);
+      mn[2] = min(mn[2], ec); mx[2] = max(mx[2], ec);
+      ++nfin;
+    }
+  }
+  for (int d = threadIdx.x; d < BK_WAVES * SORT_BINS; d += BK_THREADS) (&cnt[0][0])[d] = 0;
+  if (threadIdx.x == 0) s_fail = 0;
+  // ref: pcl::getMinMax3D at voxel_grid_covariance_impl.hpp:103 -- this tile's row of the bounds
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      mn[q] = min(mn[q], __shfl_xor(mn[q], off));
+      mx[q] = max(mx[q], __shfl_xor(mx[q], off));
+    }
+    nfin += __shfl_xor(nfin, off);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { wrow[wave][q] = mn[q]; wrow[wave][3 + q] = mx[q]; }
+    wrow[wave][6] = nfin;
+  }
+  __syncthreads();
+  if (threadIdx.x < 7) {
+    const int t = threadIdx.x;
+    int v = wrow[0][t];
+    for (int w = 1; w < BK_WAVES; ++w) {
+      const int o = wrow[w][t];
+      v = t < 3 ? min(v, o) : (t < 6 ? max(v, o) : v + o);
+    }
+    rows[tile * 8 + t] = v;   // read by the NEXT launch
+  }
+  NDT_BSTAMP(4, 1);  // points loaded, bounds row written
+  // stable rank among the equal buckets before it in the wave's 512 points (8 ballots per round)
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  int rank[ROUNDS];
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const bool valid = fused_index<ROUNDS>(tile, wave, r, lane) < n;
+    const uint32_t d = dig[r];
+    unsigned long long same = __ballot(valid);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const bool bit = (d >> q) & 1u;
+      const unsigned long long bal = __ballot(bit);
+      same &= bit ? bal : ~bal;
+    }
+    const int before = cnt[wave][d];
+    const int lower = __popcll(same & lt_mask);
+    rank[r] = before + lower;
+    __builtin_amdgcn_wave_barrier();
+    if (valid && lower == 0) cnt[wave][d] = before + __popcll(same);
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  NDT_BSTAMP(4, 2);  // ranked
+  int my_count = 0;  // bucket threadIdx.x in this tile
+  if (threadIdx.x < SORT_BINS) {
+    int run = 0;
+#pragma unroll
+    for (int w = 0; w < BK_WAVES; ++w) {
+      const int t = cnt[w][threadIdx.x];
+      cnt[w][threadIdx.x] = run;
+      run += t;
+    }
+    my_count = run;
+    if (tile != mute_tile)
+      __hip_atomic_store(table + (size_t)tile * SORT_BINS + threadIdx.x, (tag << 16) | (uint32_t)run, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+  }
+  {  // the whole table, 16 bytes (four buckets) per lane and one tile row per wave and trip (as k_sort_pass)
+    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(table, 0, 0xFFFFFFFFu, 0x00020000);
+    int tot[4] = {0, 0, 0, 0}, bef[4] = {0, 0, 0, 0};
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    constexpr int BATCH = 8;
+    for (int r0 = wave; r0 < ntiles; r0 += BATCH * BK_WAVES) {
+      u32x4_t w[BATCH];
+      for (;;) {
+        asm volatile("" ::: "memory");  // the loads below must be re-issued on every trip
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+          const int row = r0 + k * BK_WAVES;
+          if (row < ntiles)
+            w[k] = __builtin_amdgcn_raw_buffer_load_b128(rt, ((unsigned int)row * SORT_BINS + 4u * lane) * 4u, 0, 16 /* sc1 */);
+          else
+            w[k].x = w[k].y = w[k].z = w[k].w = tag << 16;
+        }
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k)
+          ok = ok && (w[k].x >> 16) == tag && (w[k].y >> 16) == tag && (w[k].z >> 16) == tag && (w[k].w >> 16) == tag;
+        if (ok) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > FUSED_TIMEOUT_TICKS) { s_fail = 1; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+#pragma unroll
+      for (int k = 0; k < BATCH; ++k) {
+        const int row = r0 + k * BK_WAVES;
+        const int c0 = w[k].x & 0xffff, c1 = w[k].y & 0xffff, c2 = w[k].z & 0xffff, c3 = w[k].w & 0xffff;
+        tot[0] += c0; tot[1] += c1; tot[2] += c2; tot[3] += c3;
+        if (row < tile) { bef[0] += c0; bef[1] += c1; bef[2] += c2; bef[3] += c3; }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { part_total[wave][4 * lane + q] = tot[q]; part_before[wave][4 * lane + q] = bef[q]; }
+  }
+  __syncthreads();
+  NDT_BSTAMP(4, 3);  // table read
+  if (s_fail) {
+    if (threadIdx.x == 0) { gd->status = BG_SPIN; gd_host->status = BG_SPIN; }
+    return;
+  }
+  int g_excl = 0, l_excl = 0, b_total = 0;  // bucket threadIdx.x: first output slot over all tiles / inside this tile
+  if (threadIdx.x < SORT_BINS) {
+    int t = 0, bsum = 0;
+#pragma unroll
+    for (int q = 0; q < BK_WAVES; ++q) { t += part_total[q][threadIdx.x]; bsum += part_before[q][threadIdx.x]; }
+    const int incl = wave_inclusive_scan(t, lane);
+    const int lincl = wave_inclusive_scan(my_count, lane);
+    if (lane == 63) { wsum[wave] = incl; wsum[4 + wave] = lincl; }
+    g_excl = incl - t + bsum;
+    l_excl = lincl - my_count;
+    b_total = incl - t;
+  }
+  __syncthreads();  // part_total / part_before are dead from here on: `stage` becomes the staging tile
+  if (threadIdx.x < SORT_BINS) {
+    int before = 0, lbefore = 0;
+    for (int w = 0; w < wave; ++w) { before += wsum[w]; lbefore += wsum[4 + w]; }
+    gbase[threadIdx.x] = before + g_excl;
+    lbase[threadIdx.x] = lbefore + l_excl;
+    if (tile == 0) {  // first point of every bucket in the partitioned cloud, for the next launch
+      bucket_off[threadIdx.x] = before + b_total;
+      if (threadIdx.x == SORT_BINS - 1) bucket_off[SORT_BINS] = n;
+    }
+  }
+  __syncthreads();
+  // the tile in bucket order through LDS, so that a wave's global stores fall into a few contiguous runs
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    if (fused_index<ROUNDS>(tile, wave, r, lane) >= n) break;
+    const uint32_t d = dig[r];
+    stage[lbase[d] + cnt[wave][d] + rank[r]] = make_float4(a[r], b[r], c[r], __uint_as_float(d));
+  }
+  __syncthreads();
+  NDT_BSTAMP(4, 4);  // staged
+  const int tile_n = min(TILE, n - tile * TILE);
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const int j = r * BK_THREADS + (int)threadIdx.x;
+    if (j >= tile_n) break;
+    const float4 q = stage[j];
+    const uint32_t d = __float_as_uint(q.w);
+    pts_out[gbase[d] + (j - lbase[d])] = q;
+  }
+#ifdef NDT_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);
+  NDT_BSTAMP(4, 5);  // thread 0's stores acknowledged
+#endif
+}
+
+// What one bucket block keeps of a leaf between the run search and the finalize phase (aliases the hash
+// table and the sorted ids, which are dead by then)
+struct BucketLeaf {
+  int cell;
+  unsigned short start, cnt;
+};
+
+constexpr int BK_TAB = 4096;             // LDS hash table of the distinct voxels of a bucket (C3: ~180 per bucket)
+constexpr int BK_MAX_DISTINCT = 3584;    // beyond it (a cloud of isolated points) the bucket declines
+constexpr uint32_t BK_EMPTY = 0xFFFFFFFEu;
+
+// Grid geometry in f32 exactly as derive_geometry() (ref: voxel_grid_covariance_impl.hpp:108-140), written field by
+// field into LDS: no stack object (derive_geometry's indexed plan arrays live in scratch), no sort plan.
+__device__ __forceinline__ void derive_geometry_lean(const int mnmx[6], int n_finite, float leaf, float inv_leaf,
+                                                     long long cell_capacity, BuildGeom* out) {
+  GridGeom& g = out->g;
+  g.leaf = leaf;
+  g.inv_leaf = inv_leaf;
+  out->n_finite = n_finite;
+  out->bits = 1;
+  out->passes = 1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { out->width[i] = 0; out->shift[i] = 0; }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { g.min_b[a] = 0; g.div_b[a] = 0; g.lo[a] = 0.0f; g.hi[a] = 0.0f; out->max_b[a] = 0; }
+  g.mul1 = g.mul2 = g.ncells = 0;
+  int status = BG_OK;
+  if (n_finite == 0) {
+    status = BG_NO_FINITE;
+  } else {
+    float mn[3], mx[3];
+    long long d[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      mn[a] = decode_ordered_dev(mnmx[a]);
+      mx[a] = decode_ordered_dev(mnmx[3 + a]);
+      d[a] = (long long)((mx[a] - mn[a]) * inv_leaf) + 1;
+    }
+    const long long lim = 2147483647ll;
+    if (d[0] < 0 || d[1] < 0 || d[2] < 0 || d[0] > lim || d[1] > lim || d[2] > lim || d[0] * d[1] > lim ||
+        d[0] * d[1] * d[2] > lim) {
+      status = BG_OVERFLOW;
+    } else {
+      long long ncells = 1;
+      int mnb[3], mxb[3], dv[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        mnb[a] = (int)floorf(mn[a] * inv_leaf);
+        mxb[a] = (int)floorf(mx[a] * inv_leaf);
+        dv[a] = mxb[a] - mnb[a] + 1;
+        ncells *= dv[a];
+      }
+      if (ncells >= lim) {
+        status = BG_OVERFLOW;
+      } else {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          g.min_b[a] = mnb[a];
+          out->max_b[a] = mxb[a];
+          g.div_b[a] = dv[a];
+          g.lo[a] = (float)mnb[a] * leaf;
+          g.hi[a] = (float)(mxb[a] + 1) * leaf;
+        }
+        g.mul1 = dv[0];
+        g.mul2 = dv[0] * dv[1];
+        g.ncells = (int)ncells;
+        if (ncells > cell_capacity) status = BG_CAPACITY;
+      }
+    }
+  }
+  out->status = status;
+}
+
+// v + (v of the partner lane) for the three steps of an 8-lane tree and the fourth of a 16-lane one, through DPP
+// (no LDS crossbar round trip): quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror.  Each
+// step pairs a lane with one whose partial sum covers the OTHER half of the group, like the xor tree: the two
+// operands of every addition are the same, so the sums are bit-identical to moments_xor_tree's.
+template <int CTRL>
+__device__ __forceinline__ double dpp_partner(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned int lo = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)u, CTRL, 0xF, 0xF, true);
+  const unsigned int hi = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)(u >> 32), CTRL, 0xF, 0xF, true);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <int WIDTH>
+__device__ __forceinline__ void moments_tree_dpp(Moments& m) {
+#define NDT_TREE_STEP(EXPR)                                   \
+  {                                                           \
+    _Pragma("unroll") for (int a = 0; a < 3; ++a) m.s[a] += EXPR(m.s[a]);   \
+    _Pragma("unroll") for (int a = 0; a < 6; ++a) m.ss[a] += EXPR(m.ss[a]); \
+  }
+  NDT_TREE_STEP(dpp_partner<0xB1>)
+  NDT_TREE_STEP(dpp_partner<0x4E>)
+  NDT_TREE_STEP(dpp_partner<0x141>)
+  if (WIDTH == 64) {
+    NDT_TREE_STEP(dpp_partner<0x140>)
+#pragma unroll
+    for (int off = 16; off < 64; off <<= 1) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) m.s[a] += __shfl_xor(m.s[a], off);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) m.ss[a] += __shfl_xor(m.ss[a], off);
+    }
+  }
+#undef NDT_TREE_STEP
+}
+
+__global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __restrict__ pts, const int* __restrict__ bucket_off,
+                                                             const int* __restrict__ rows, int ntiles, float leaf,
+                                                             float inv_leaf, long long cell_capacity, int min_pts,
+                                                             FinalizeParams fp, BuildGeom* __restrict__ gd,
+                                                             BuildGeom* __restrict__ gd_host, int* __restrict__ d_nleaf,
+                                                             unsigned int* __restrict__ ticket, double* __restrict__ sums,
+                                                             VoxelRecord* __restrict__ rec, LeafStats* __restrict__ stats,
+                                                             int* __restrict__ cell2leaf, int max_leaves,
+                                                             int* __restrict__ nleaf_host, int done_tag) {
+  __shared__ float px[BK_MAXP], py[BK_MAXP], pz[BK_MAXP];
+  // region A, three lives: {hash table of the bucket's distinct cells + their dense ids} -> {ids in sorted order +
+  // the per-wave digit counters} -> {leaf list}
+  __shared__ __align__(16) unsigned char region_a[BK_TAB * 4 + BK_TAB * 2];
+  uint32_t* tab = reinterpret_cast<uint32_t*>(region_a);
+  unsigned short* did = reinterpret_cast<unsigned short*>(region_a + BK_TAB * 4);
+  unsigned short* sid = reinterpret_cast<unsigned short*>(region_a);                                   // BK_MAXP ids
+  unsigned short (*cnt)[SORT_BINS] = reinterpret_cast<unsigned short (*)[SORT_BINS]>(region_a + BK_TAB * 4);  // 16 x 256
+  BucketLeaf* leaves = reinterpret_cast<BucketLeaf*>(region_a);
+  static_assert(BK_MAXP * 2 <= BK_TAB * 4 && BK_WAVES * SORT_BINS * 2 <= BK_TAB * 2, "sorted ids / counters alias the table");
+  static_assert(sizeof(BucketLeaf) * BK_MAX_LEAVES <= sizeof(region_a), "leaf list aliases region A");
+  __shared__ unsigned short sidx[BK_MAXP];
+  __shared__ int dbase[SORT_BINS];
+  __shared__ int wsum[BK_WAVES];
+  __shared__ int wave_head[BK_WAVES], wave_total[BK_WAVES];
+  __shared__ int fold[BK_WAVES][8];
+  __shared__ BuildGeom sg;
+  __shared__ int s_maxb, s_base, s_ok, s_last, s_decline;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bucket = blockIdx.x;
+  NDT_BSTAMP(5, 0);
+  // ---- everything this block reads from HBM is requested now: the bounds rows, the bucket sizes, its points ----
+  // (the launch starts on cold caches: every dependent round trip is ~2 us, so the verdict of the partition
+  // launch travels with the bucket's range instead of in front of it)
+  const int prior_status = gd->status;
+  const int base = bucket_off[bucket], m = bucket_off[bucket + 1] - base;
+  if (prior_status == BG_SPIN) return;  // the partition launch gave up waiting (uniform over the grid)
+  int fm[6] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN};
+  int fc = 0;
+  for (int r = threadIdx.x; r < ntiles; r += BK_THREADS) {
+    const int4 lo4 = *reinterpret_cast<const int4*>(rows + r * 8), hi4 = *reinterpret_cast<const int4*>(rows + r * 8 + 4);
+    fm[0] = min(fm[0], lo4.x); fm[1] = min(fm[1], lo4.y); fm[2] = min(fm[2], lo4.z);
+    fm[3] = max(fm[3], lo4.w); fm[4] = max(fm[4], hi4.x); fm[5] = max(fm[5], hi4.y);
+    fc += hi4.z;
+  }
+  const int my_bucket_size = threadIdx.x < SORT_BINS ? bucket_off[threadIdx.x + 1] - bucket_off[threadIdx.x] : 0;
+  // Position p = wave * C + round * 64 + lane: a wave owns C consecutive positions, so "tile order" is (wave, round,
+  // lane) as in the sort passes above; C is the smallest multiple of 64 that spreads the bucket over all 16 waves
+  // (a bucket of 3906 points: 4 rounds on every wave instead of 8 rounds on half of them).
+  const int C = ((m + BK_WAVES * 64 - 1) / (BK_WAVES * 64)) * 64, R = C >> 6;
+  float4 q[BK_ROUNDS];
+#pragma unroll
+  for (int r = 0; r < BK_ROUNDS; ++r) {
+    const int p = wave * C + r * 64 + lane;
+    q[r] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (r < R && p < m) q[r] = pts[base + p];
+  }
+  // ---- geometry: every block folds the bounds rows and derives the same BuildGeom -------------------
+  {
+    const int nw = min(BK_WAVES, (ntiles + 63) / 64);   // waves that hold any row
+    if (wave < nw) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          fm[k] = min(fm[k], __shfl_xor(fm[k], off));
+          fm[3 + k] = max(fm[3 + k], __shfl_xor(fm[3 + k], off));
+        }
+        fc += __shfl_xor(fc, off);
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) fold[wave][k] = fm[k];
+        fold[wave][6] = fc;
+      }
+    }
+    if (threadIdx.x == 0) { s_maxb = 0; s_ok = 0; s_decline = 0; }
+    for (int t = threadIdx.x; t < BK_TAB; t += BK_THREADS) tab[t] = BK_EMPTY;
+    __syncthreads();
+    if (threadIdx.x < SORT_BINS) {
+      int mb = my_bucket_size;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) mb = max(mb, __shfl_xor(mb, off));
+      if (lane == 0) atomicMax(&s_maxb, mb);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int out[6], total = 0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        int v = fold[0][k];
+        for (int w = 1; w < nw; ++w) v = k < 3 ? min(v, fold[w][k]) : max(v, fold[w][k]);
+        out[k] = v;
+      }
+      for (int w = 0; w < nw; ++w) total += fold[w][6];
+      derive_geometry_lean(out, total, leaf, inv_leaf, cell_capacity, &sg);
+      if (sg.status == BG_OK) {
+        // exactness of floor(p / leaf) - min_b in f32 (one voxel, one bucket), and a bucket must fit a block
+        bool big = false;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) big = big || !(fabsf(floorf(decode_ordered_dev(out[k]) * inv_leaf)) < BK_COORD_LIMIT);
+        if (big || s_maxb > BK_MAXP) sg.status = BG_BUCKET;
+      }
+    }
+    __syncthreads();
+  }
+  if (sg.status != BG_OK) {
+    // refused (the host repeats the build another way, or reports the error): nothing was written
+    if (bucket == 0 && threadIdx.x == 0) {
+      *gd = sg;
+      *gd_host = sg;
+      nleaf_host[0] = 0;
+      nleaf_host[1] = 0;
+      // the verdict first, the tag the host polls for last (gd_host and nleaf_host are __restrict__: without
+      // the release the compiler and the memory system are free to let the tag overtake the verdict)
+      __hip_atomic_store(nleaf_host + 2, done_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
+  }
+  NDT_BSTAMP(5, 1);  // geometry derived
+  const GridGeom g = sg.g;
+  // ---- LDS copy of the points; cell key (ref: voxel_grid_covariance_impl.hpp:222-225); the distinct cells of the
+  // bucket go into an LDS hash table (a few hundred of them): sorting by the table's DENSE ids takes one or two
+  // narrow digit passes instead of three 8-bit passes over the 24-bit cell index -------------------------------
+  unsigned short tslot[BK_ROUNDS];
+#pragma unroll
+  for (int r = 0; r < BK_ROUNDS; ++r) {
+    const int p = wave * C + r * 64 + lane;
+    tslot[r] = 0;
+    if (r < R && p < m) {
+      px[p] = q[r].x; py[p] = q[r].y; pz[p] = q[r].z;
+      uint32_t key = (uint32_t)g.ncells;  // sentinel: never a leaf
+      if (finite3(q[r].x, q[r].y, q[r].z)) {
+        const int c = cell_of(q[r].x, q[r].y, q[r].z, g);
+        if (c >= 0 && c < g.ncells) key = (uint32_t)c;
+      }
+      uint32_t hsl = (key * 0x9E3779B1u) >> (32 - 12);
+      for (int probe = 0; probe < BK_TAB; ++probe) {
+        const uint32_t old = atomicCAS(&tab[hsl], BK_EMPTY, key);
+        if (old == BK_EMPTY || old == key) break;
+        hsl = (hsl + 1) & (BK_TAB - 1);
+        if (probe == BK_TAB - 1) s_decline = 1;  // table full
+      }
+      tslot[r] = (unsigned short)hsl;
+    }
+  }
+  NDT_BSTAMP(5, 2);  // points in LDS, cells in the table
+  __syncthreads();
+  // dense ids: exclusive scan of the table's occupancy (4 slots per thread)
+  int ndistinct;
+  {
+    const uint4 t4 = *reinterpret_cast<const uint4*>(tab + threadIdx.x * 4);
+    const int o0 = t4.x != BK_EMPTY, o1 = t4.y != BK_EMPTY, o2 = t4.z != BK_EMPTY, o3 = t4.w != BK_EMPTY;
+    const int mine = o0 + o1 + o2 + o3;
+    const int incl = wave_inclusive_scan(mine, lane);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int before = incl - mine, total = 0;
+    for (int w = 0; w < BK_WAVES; ++w) {
+      if (w < wave) before += wsum[w];
+      total += wsum[w];
+    }
+    ndistinct = total;
+    unsigned short* dd = did + threadIdx.x * 4;
+    dd[0] = (unsigned short)before;
+    dd[1] = (unsigned short)(before + o0);
+    dd[2] = (unsigned short)(before + o0 + o1);
+    dd[3] = (unsigned short)(before + o0 + o1 + o2);
+    __syncthreads();
+  }
+  const bool decline = s_decline != 0 || ndistinct > BK_MAX_DISTINCT;   // uniform over the block
+  uint32_t key[BK_ROUNDS];   // the dense id of the point's cell from here on
+  unsigned short idx[BK_ROUNDS];
+#pragma unroll
+  for (int r = 0; r < BK_ROUNDS; ++r) {
+    const int p = wave * C + r * 64 + lane;
+    key[r] = (r < R && p < m) ? (uint32_t)did[tslot[r]] : 0u;
+    idx[r] = (unsigned short)p;
+  }
+  __syncthreads();   // table and ids are dead: region A becomes {sorted ids, digit counters}
+  // ---- stable LSD radix sort of (dense id, position) in LDS: ceil(log2(ndistinct) / 8) passes ---------------
+  int idbits = 1;
+  while ((1 << idbits) < ndistinct) ++idbits;
+  const int npass = decline ? 0 : (idbits + 7) / 8;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  for (int pass = 0; pass < npass; ++pass) {
+    const int width = (idbits + npass - 1 - pass) / npass;           // e.g. 11 bits: 6 + 5
+    const int shift = pass == 0 ? 0 : (idbits + npass - 1) / npass;  // (two passes at most: ndistinct <= 3584)
+    const uint32_t digit_mask = (1u << width) - 1u;
+    for (int d = lane; d < SORT_BINS; d += 64) cnt[wave][d] = 0;
+    __builtin_amdgcn_wave_barrier();
+    int rank[BK_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < BK_ROUNDS; ++r) {
+      rank[r] = 0;
+      if (r < R) {
+        const bool valid = wave * C + r * 64 + lane < m;
+        const uint32_t d = (key[r] >> shift) & digit_mask;
+        unsigned long long same = __ballot(valid);
+        for (int k = 0; k < width; ++k) {
+          const bool bit = (d >> k) & 1u;
+          const unsigned long long bal = __ballot(bit);
+          same &= bit ? bal : ~bal;
+        }
+        const int before = cnt[wave][d];
+        const int lower = __popcll(same & lt_mask);
+        rank[r] = before + lower;
+        __builtin_amdgcn_wave_barrier();
+        if (valid && lower == 0) cnt[wave][d] = (unsigned short)(before + __popcll(same));
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < SORT_BINS) {
+      int run = 0;
+#pragma unroll
+      for (int w = 0; w < BK_WAVES; ++w) {
+        const int t = cnt[w][threadIdx.x];
+        cnt[w][threadIdx.x] = (unsigned short)run;
+        run += t;
+      }
+      const int incl = wave_inclusive_scan(run, lane);
+      if (lane == 63) wsum[wave] = incl;
+      dbase[threadIdx.x] = incl - run;
+    }
+    __syncthreads();
+    if (threadIdx.x < SORT_BINS) {
+      int before = 0;
+      for (int w = 0; w < wave; ++w) before += wsum[w];
+      dbase[threadIdx.x] += before;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < BK_ROUNDS; ++r) {
+      if (r < R && wave * C + r * 64 + lane < m) {
+        const uint32_t d = (key[r] >> shift) & digit_mask;
+        const int o = dbase[d] + cnt[wave][d] + rank[r];
+        sid[o] = (unsigned short)key[r];
+        sidx[o] = idx[r];
+      }
+    }
+    __syncthreads();
+    if (pass + 1 < npass) {
+#pragma unroll
+      for (int r = 0; r < BK_ROUNDS; ++r) {
+        const int p = wave * C + r * 64 + lane;
+        if (r < R && p < m) { key[r] = sid[p]; idx[r] = sidx[p]; }
+      }
+      __syncthreads();
+    }
+  }
+  // ---- runs of equal id: thread t owns the 8 consecutive sorted positions [8 t, 8 t + 8) ------------
+  NDT_BSTAMP(5, 3);  // sorted
+  const int ms = decline ? 0 : m;
+  const int s0 = (int)threadIdx.x * BK_ROUNDS;
+  uint32_t k[BK_ROUNDS];
+#pragma unroll
+  for (int j = 0; j < BK_ROUNDS; ++j) k[j] = s0 + j < ms ? (uint32_t)sid[s0 + j] : 0xFFFFFFFFu;
+  const uint32_t prev = (s0 > 0 && s0 - 1 < ms) ? (uint32_t)sid[s0 - 1] : 0xFFFFFFFFu;
+  const uint32_t next = s0 + BK_ROUNDS < ms ? (uint32_t)sid[s0 + BK_ROUNDS] : 0xFFFFFFFFu;
+  int own_head = -1;
+#pragma unroll
+  for (int j = 0; j < BK_ROUNDS; ++j) {
+    const uint32_t before = j == 0 ? prev : k[j - 1];
+    if (s0 + j < ms && (s0 + j == 0 || before != k[j])) own_head = s0 + j;
+  }
+  int incl = own_head;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off);
+    if (lane >= off) incl = max(incl, t);
+  }
+  int head_before = __shfl_up(incl, 1);
+  if (lane == 0) head_before = -1;
+  if (lane == 63) wave_head[wave] = incl;
+  __syncthreads();   // (also: every thread has its ids in registers -- region A may be overwritten below)
+  for (int w = 0; w < wave; ++w) head_before = max(head_before, wave_head[w]);
+  int cur_head = head_before, nleaf = 0;
+  int starts[BK_ROUNDS], counts[BK_ROUNDS], cells[BK_ROUNDS];
+#pragma unroll
+  for (int j = 0; j < BK_ROUNDS; ++j) {
+    const int s = s0 + j;
+    const uint32_t before = j == 0 ? prev : k[j - 1];
+    const uint32_t after = j == BK_ROUNDS - 1 ? next : k[j + 1];
+    const bool valid = s < ms;
+    if (valid && (s == 0 || before != k[j])) cur_head = s;
+    const bool tail = valid && (s == ms - 1 || after != k[j]);
+    counts[j] = 0;
+    starts[j] = 0;
+    cells[j] = 0;
+    if (tail) {
+      const int c = s - cur_head + 1;
+      if (c >= min_pts) {   // ref :270-273
+        // the run's cell, from its first point (every point of a run has the same one); the run of the points
+        // that classify nowhere (non-finite, outside the box) is no leaf
+        const int f = sidx[cur_head];
+        const float fx = px[f], fy = py[f], fz = pz[f];
+        if (finite3(fx, fy, fz)) {
+          const int cell = cell_of(fx, fy, fz, g);
+          if (cell >= 0 && cell < g.ncells) { starts[j] = cur_head; counts[j] = c; cells[j] = cell; ++nleaf; }
+        }
+      }
+    }
+  }
+  int lincl = wave_inclusive_scan(nleaf, lane);
+  if (lane == 63) wave_total[wave] = lincl;
+  __syncthreads();
+  int nl = 0, li0 = lincl - nleaf;
+  for (int w = 0; w < BK_WAVES; ++w) {
+    if (w < wave) li0 += wave_total[w];
+    nl += wave_total[w];
+  }
+#pragma unroll
+  for (int j = 0; j < BK_ROUNDS; ++j)
+    if (counts[j] > 0) {
+      BucketLeaf L;
+      L.cell = cells[j];
+      L.start = (unsigned short)starts[j];
+      L.cnt = (unsigned short)counts[j];
+      leaves[li0++] = L;
+    }
+  // this block's leaf slots: the atomic's round trip runs under the first batch of sums
+  if (threadIdx.x == 0) {
+    s_base = nl > 0 ? atomicAdd(&d_nleaf[0], nl) : 0;
+    if (decline) atomicAdd(&d_nleaf[2], 1);
+  }
+  __syncthreads();   // leaf list complete (s_base is read behind the next barrier only)
+  NDT_BSTAMP(5, 4);  // runs found
+  // ---- per-voxel sums (ref :236-239), from LDS, in input order: 8 lanes per leaf, crowded leaves by the wave ----
+  int slot0 = 0;
+  {
+    const int sub = lane & (LANES_PER_LEAF - 1);
+    for (int l0 = 0; l0 < nl; l0 += BK_THREADS / LANES_PER_LEAF) {
+      const int li = l0 + ((int)threadIdx.x >> 3);
+      const bool have = li < nl;
+      const int start = have ? (int)leaves[li].start : 0, c = have ? (int)leaves[li].cnt : 0;
+      Moments mo{};
+      const int head = c < LEAF_HEAD ? c : LEAF_HEAD;
+      // (same association as k_leaf_sums: a lane adds its points in ascending order, masked lanes add exact zeros)
+      for (int j0 = sub; j0 < head; j0 += SUMS_UNROLL * LANES_PER_LEAF) {
+        float4 pp[SUMS_UNROLL];
+        bool live[SUMS_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SUMS_UNROLL; ++u) {
+          const int j = j0 + u * LANES_PER_LEAF;
+          live[u] = j < head;
+          const int f = sidx[start + (live[u] ? j : 0)];
+          pp[u] = make_float4(px[f], py[f], pz[f], 0.0f);
+        }
+#pragma unroll
+        for (int u = 0; u < SUMS_UNROLL; ++u) moments_add(mo, pp[u], live[u]);
+      }
+      moments_tree_dpp<LANES_PER_LEAF>(mo);
+      unsigned long long crowded = __ballot(c > LEAF_HEAD);
+      while (crowded) {
+        const int src = __ffsll((long long)crowded) - 1;
+        crowded &= ~(0xFFull << (src & ~7));
+        const int bstart = __shfl(start, src), bcnt = __shfl(c, src);
+        Moments t{};
+        for (int j0 = LEAF_HEAD + lane; j0 < bcnt; j0 += SUMS_UNROLL * 64) {
+          float4 pp[SUMS_UNROLL];
+          bool live[SUMS_UNROLL];
+#pragma unroll
+          for (int u = 0; u < SUMS_UNROLL; ++u) {
+            const int j = j0 + u * 64;
+            live[u] = j < bcnt;
+            const int f = sidx[bstart + (live[u] ? j : LEAF_HEAD)];
+            pp[u] = make_float4(px[f], py[f], pz[f], 0.0f);
+          }
+#pragma unroll
+          for (int u = 0; u < SUMS_UNROLL; ++u) moments_add(t, pp[u], live[u]);
+        }
+        moments_tree_dpp<64>(t);
+        if ((lane >> 3) == (src >> 3)) {
+#pragma unroll
+          for (int a = 0; a < 3; ++a) mo.s[a] += t.s[a];
+#pragma unroll
+          for (int a = 0; a < 6; ++a) mo.ss[a] += t.ss[a];
+        }
+      }
+      if (l0 == 0) {   // uniform: the slot base has arrived by now
+        __syncthreads();
+        slot0 = s_base;
+      }
+      if (!have) continue;
+      double* o = sums + (size_t)(slot0 + li) * 9;
+      const double mine = sub == 0 ? mo.s[0] : sub == 1 ? mo.s[1] : sub == 2 ? mo.s[2] : sub == 3 ? mo.ss[0]
+                        : sub == 4 ? mo.ss[1] : sub == 5 ? mo.ss[2] : sub == 6 ? mo.ss[3] : mo.ss[4];
+      o[sub] = mine;
+      if (sub == 0) o[8] = mo.ss[5];
+    }
+  }
+  __syncthreads();   // the sums of this block's leaves are visible to the whole block
+  NDT_BSTAMP(5, 5);  // sums written
+  // ---- ref :265-343: one thread per leaf ---------------------------------------------------------------
+  int ok_here = 0;
+  for (int li = threadIdx.x; li < nl; li += BK_THREADS) {
+    const int slot = slot0 + li;
+    if (slot < max_leaves && finalize_leaf(slot, leaves[li].cell, (int)leaves[li].cnt, sums + (size_t)slot * 9, fp, rec, stats, cell2leaf))
+      ++ok_here;
+  }
+  const int wave_ok = __popcll(__ballot(ok_here == 1)) + 2 * __popcll(__ballot(ok_here == 2)) + 3 * __popcll(__ballot(ok_here >= 3));
+  if (lane == 0 && wave_ok) atomicAdd(&s_ok, wave_ok);
+  __syncthreads();
+  NDT_BSTAMP(5, 6);  // statistics written
+  if (threadIdx.x == 0) {
+    // every add of this block has RETURNED before the ticket is drawn: the block that draws the last one reads
+    // totals that include every block's
+    int seen = 0;
+    if (s_ok) seen = atomicAdd(&d_nleaf[1], s_ok);
+    asm volatile("" ::"v"(seen), "v"(slot0));
+    __builtin_amdgcn_s_waitcnt(0);
+    const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = t == gridDim.x - 1u ? 1 : 0;
+    if (s_last) {
+      const int slots = __hip_atomic_load(&d_nleaf[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int valid = __hip_atomic_load(&d_nleaf[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // a bucket with more distinct cells than its table holds declined AFTER other blocks had published leaves:
+      // the host repeats the build sort-based on a cleared grid
+      if (__hip_atomic_load(&d_nleaf[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) sg.status = BG_BUCKET;
+      *gd = sg;
+      *gd_host = sg;
+      nleaf_host[0] = slots;
+      nleaf_host[1] = valid;
+      // geometry and counts first, the tag the host polls for last (see above)
+      __hip_atomic_store(nleaf_host + 2, done_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -1652,6 +2444,50 @@ hipError_t sort_cloud_fused(const float* x, const float* y, const float* z, size
   return hipGetLastError();
 }
 
+// ---- bucketed build (two launches) ----
+bool bucket_build_enabled() {
+  static const bool on = [] { const char* e = getenv("NDT_BUCKET_BUILD"); return !(e && *e && atoi(e) == 0); }();
+  return on;
+}
+int bucket_build_tiles(size_t n) { return (int)((n + BK_MAXP - 1) / BK_MAXP); }
+// The hash spreads voxels, not points: the largest bucket of a lidar map is ~1.6x the mean (crowded voxels
+// near the sensor), and a bucket must fit BK_MAXP points -- so clouds up to 256 * BK_MAXP / 1.6 points are
+// worth trying (a bucket that overflows anyway costs one refused launch pair, BG_BUCKET).  Every block of
+// the partition launch waits for every other: one tile per compute unit at most.
+bool bucket_build_fits(size_t n, int compute_units) {
+  if (n == 0 || n > (size_t)BK_BUCKETS * BK_MAXP * 5 / 8) return false;
+  return bucket_build_tiles(n) <= (compute_units < FUSED_MAX_TILES ? compute_units : FUSED_MAX_TILES);
+}
+
+hipError_t launch_bucket_build(const float* x, const float* y, const float* z, size_t n, float leaf, float inv_leaf,
+                               long long cell_capacity, int min_pts, FinalizeParams fp, BuildGeom* gd, BuildGeom* gd_host,
+                               uint32_t* table, uint32_t* seq, const LeafStats* old_stats, int dirty_slots, int* cell2leaf,
+                               size_t c2l_cap, int* rows, int* bucket_off, int* d_nleaf, unsigned int* ticket, float* pts4,
+                               double* sums, VoxelRecord* rec, LeafStats* stats, int max_leaves, int* nleaf_host,
+                               int done_tag, hipStream_t s) {
+  if (n == 0) return hipErrorInvalidValue;
+  uint32_t tag = (*seq + 1u) & 0xffffu;
+  if (tag == 0u) {  // wrapped: forget every old tag before tag 1 is handed out again
+    hipError_t e = hipMemsetAsync(table, 0, fused_table_words() * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    tag = 1u;
+  }
+  *seq = tag;
+#ifdef NDT_TEST_SEAMS
+  static const int mute_tile = [] { const char* e = getenv("NDT_DEBUG_FUSED_MUTE_TILE"); return e && *e ? atoi(e) : -1; }();
+#else
+  constexpr int mute_tile = -1;
+#endif
+  const int ntiles = bucket_build_tiles(n);
+  hipLaunchKernelGGL(k_bucket_pass, dim3((unsigned)ntiles), dim3(BK_THREADS), 0, s, x, y, z, (int)n, inv_leaf, ntiles, table,
+                     tag, mute_tile, gd, gd_host, old_stats, dirty_slots, cell2leaf, c2l_cap, rows, bucket_off, d_nleaf,
+                     reinterpret_cast<float4*>(pts4));
+  hipLaunchKernelGGL(k_bucket_leaves, dim3(BK_BUCKETS), dim3(BK_THREADS), 0, s, reinterpret_cast<const float4*>(pts4),
+                     bucket_off, rows, ntiles, leaf, inv_leaf, cell_capacity, min_pts, fp, gd, gd_host, d_nleaf, ticket, sums,
+                     rec, stats, cell2leaf, max_leaves, nleaf_host, done_tag);
+  return hipGetLastError();
+}
+
 int runs_blocks(size_t n) { return (int)((n + 256 * 8 - 1) / (256 * 8)); }
 
 size_t run_tag_words(size_t n) { return (size_t)runs_blocks(n); }
@@ -1687,7 +2523,7 @@ hipError_t launch_find_runs(const uint32_t* keys_sorted, size_t n, BuildGeom* gd
 
 int build_read_stamps(unsigned long long* out) {
 #ifdef NDT_STAMPS
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bstamps), sizeof(unsigned long long) * 4 * 512 * 8) == hipSuccess ? 4 * 512 : -1;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bstamps), sizeof(unsigned long long) * 6 * 512 * 8) == hipSuccess ? 6 * 512 : -1;
 #else
   (void)out;
   return 0;

@@ -1,29 +1,29 @@
-"""A/B of the build's launch shapes on C3 (tuning aid, not collected by pytest): every knob set runs
-in its own process (the knobs are read once), interleaved twice.  Prints build wall / device time."""
+"""A/B of the target build on C3 (tuning aid, not collected by pytest): every knob set runs in its own
+process (the knobs are read once), interleaved twice.  Prints build wall / device time."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
 import os, sys, time
 sys.path.insert(0, %r)
-import numpy as np, torch
+import numpy as np
 import __graft_entry__ as ge
 pkg = ge.load_package(); S = pkg.synth
-torch.cuda.init(); dev = torch.device("cuda:0")
+hip = pkg.ranks.Hip(0)
 cfg = S.config_c3()
 ndt = pkg.NormalDistributionsTransform(device_id=0, resolution=0.5, step_size=0.1, trans_epsilon=1e-4, max_iterations=35)
-tgt = [torch.from_numpy(np.ascontiguousarray(cfg["target"][:, a])).to(dev) for a in range(3)]
-torch.cuda.synchronize()
-tp = [t.data_ptr() for t in tgt]; nt = len(cfg["target"])
+tp = [hip.upload(cfg["target"][:, a]) for a in range(3)]; nt = len(cfg["target"])
 W, D = [], []
 for i in range(60):
     t0 = time.perf_counter(); ndt.setInputTargetDevice(tp[0], tp[1], tp[2], nt); t1 = time.perf_counter()
     if i >= 10: W.append(t1 - t0); D.append(ndt.getGridInfo()["ms_build"])
 gi = ndt.getGridInfo()
-print("%%-44s build wall %%.1f us  device %%.1f us  (leaves %%d)" %% (sys.argv[1], 1e6 * float(np.median(W)), 1e3 * float(np.median(D)), gi["n_leaves"]), flush=True)
+print("%%-44s build wall %%.1f us  ms_build %%.1f us  (leaves %%d, counters %%s)" %% (sys.argv[1], 1e6 * float(np.median(W)), 1e3 * float(np.median(D)), gi["n_leaves"], ndt.buildCounters()), flush=True)
 ''' % ROOT
 SETS = [
-    ("build timed by events (device time)", {"NDT_BUILD_EVENTS": "1"}),
-    ("no events (ms_build = wall)", {"NDT_BUILD_EVENTS": "0"}),
+    ("bucketed (2 launches), device time", {"NDT_BUILD_EVENTS": "1", "NDT_BUCKET_BUILD": "1"}),
+    ("sort-based (8 launches), device time", {"NDT_BUILD_EVENTS": "1", "NDT_BUCKET_BUILD": "0"}),
+    ("bucketed, wall", {"NDT_BUILD_EVENTS": "0", "NDT_BUCKET_BUILD": "1"}),
+    ("sort-based, wall", {"NDT_BUILD_EVENTS": "0", "NDT_BUCKET_BUILD": "0"}),
 ]
 for rep in range(2):
     for name, env in SETS:

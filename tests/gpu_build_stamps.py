@@ -1,5 +1,5 @@
-"""Reads the in-kernel phase stamps of the fused build kernels from a -DNDT_STAMPS diagnostic build
-(not collected by pytest)."""
+"""Reads the in-kernel phase stamps of the build kernels from a -DNDT_STAMPS diagnostic build
+(libndt_hip_stamps.so via NDT_HIP_LIB; not collected by pytest)."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -10,15 +10,22 @@ ndt = pkg.NormalDistributionsTransform(device_id=0, resolution=0.5, step_size=0.
 for _ in range(5): ndt.setInputTarget(cfg["target"])
 L = pkg.lib()
 L.ndt_debug_read_build_stamps.argtypes = [C.c_void_p]
-raw = np.zeros(4 * 512 * 8, np.uint64)
-assert L.ndt_debug_read_build_stamps(raw.ctypes.data) == 4 * 512
-t = raw.reshape(4, 512, 8).astype(np.int64)
+raw = np.zeros(6 * 512 * 8, np.uint64)
+assert L.ndt_debug_read_build_stamps(raw.ctypes.data) == 6 * 512
+t = raw.reshape(6, 512, 8).astype(np.int64)
 n = len(cfg["target"])
-names = {0: ["entry", "keys loaded", "ranked", "table read", "staged", "stores done"], 3: ["entry", "counted", "offset known", "emitted"]}
+print("build counters (fused fallbacks, bucket fallbacks, bucketed builds):", ndt.buildCounters())
+names = {0: ["entry", "keys loaded", "ranked", "table read", "staged", "stores done"], 3: ["entry", "counted", "offset known", "emitted"],
+         4: ["entry", "loaded+bounds", "ranked", "table read", "staged", "stores done"],
+         5: ["entry", "geometry", "points in", "sorted", "runs+slots", "sums", "statistics"]}
 for slot, nb, label in ((0, (n + 8191) // 8192, "sort pass 0 (from points)"), (1, (n + 8191) // 8192, "sort pass 1"),
-                        (2, (n + 8191) // 8192, "sort pass 2"), (3, (n + 2047) // 2048, "run search (fused)")):
-    nm = names[3] if slot == 3 else names[0]
+                        (2, (n + 8191) // 8192, "sort pass 2"), (3, (n + 2047) // 2048, "run search (fused)"),
+                        (4, (n + 8191) // 8192, "k_bucket_pass"), (5, 256, "k_bucket_leaves")):
+    nm = names.get(slot, names[0])
     b = t[slot, :min(nb, 512), :len(nm)]
+    if b[:, 0].max() == 0:
+        print("%s: not run" % label)
+        continue
     rel = (b - b[:, 0].min()) * 0.01
     print("%s: %d blocks (us since the first block's entry)" % (label, nb))
     for k, name in enumerate(nm):

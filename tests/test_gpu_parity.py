@@ -596,6 +596,8 @@ def test_crowded_voxels_across_sort_and_run_tiles(pkg, O):
         L, OL = ndt.getLeaves(), grid.export()
         assert L["count"].max() >= 12289
         assert_leaves_match(L, OL)
+    # a voxel of 12 289 points fits no bucket block: the two-launch build declines (BG_BUCKET), sort-based repeats it
+    assert ndt.buildCounters()[1:] == (1, 0)
 
 
 @pytest.mark.parametrize("n", [8191, 8192, 8193, 16384, 24577, 65536, 100003, 262144, 300000, 2097152, 2097153, 2600001])
@@ -616,7 +618,10 @@ def test_build_at_tile_boundaries_of_the_fused_passes(pkg, O, n):
         L = ndt.getLeaves()
         assert np.array_equal(L["cell"], OL["cell"]) and np.array_equal(L["count"], OL["count"])
         np.testing.assert_allclose(L["mean"], OL["mean"], rtol=1e-12, atol=0)
-    assert ndt.buildCounters()[0] == 0
+    bc = ndt.buildCounters()
+    assert bc[0] == 0
+    # the second (steady-state) build of a cloud that fits goes through in two launches
+    assert bc[1:] == ((0, 1) if n <= 1310720 else (0, 0)), bc
 
 
 def test_one_engine_many_targets_in_turn(pkg, S):
@@ -646,4 +651,6 @@ def test_one_engine_many_targets_in_turn(pkg, S):
         L = ndt.getLeaves()
         for f in ("cell", "count", "mean", "cov", "icov", "evals"):
             assert np.array_equal(L[f], fresh[k][f]), (k, f)
-    assert ndt.buildCounters()[0] == 0
+    bc = ndt.buildCounters()
+    # fresh engines build sort-based (first build), this one mostly in two launches: bit-identical leaves
+    assert bc[0] == 0 and bc[2] >= 8, bc
