@@ -400,7 +400,23 @@ def main():
         # leave the engine as the timed steps use it
         ndt.setInputTargetDevice(tptr[0], tptr[1], tptr[2], n_tgt)
         ndt.setInputSourceDeviceView(sptr[0], sptr[1], sptr[2], c)
+        # What the drivers pay on top when they call align() through pcl::Registration (RegisterCallback::registration;
+        # align is not virtual): identity indices, output.resize, a per-point copy of the 32-byte source points and the
+        # data[3] = 1 pass before computeTransformation -- reproduced in the API mock and timed by a C++ program at
+        # the headline source size (tests/cpp/bench_registration_prework.cpp)
+        pre = None
+        exe = os.path.join(ROOT, "tests", "cpp", "bench_registration_prework")
+        if os.path.exists(exe):
+            try:
+                import subprocess
+                pr = subprocess.run([exe, str(n_src_total), str(n_tgt), "20"], capture_output=True, text=True, timeout=120)
+                pre = json.loads([ln for ln in pr.stdout.splitlines() if ln.startswith("{")][-1])
+                pre["what"] = ("host work of pcl::Registration::align around computeTransformation (API mock that repeats PCL "
+                               "1.14's steps), same source size, synthetic room")
+            except Exception as e:  # noqa: BLE001
+                pre = {"error": str(e)}
         return {"what": "PCIe-inclusive: host PointXYZI (32 B/pt) clouds through ndt_set_target / ndt_set_source, then align",
+                "pcl_registration": pre,
                 "value": iters / el, "unit": "iterations/s", "ms_scan": 1e3 * el / k, "ms_set_target": 1e3 * tt / k,
                 "ms_set_source": 1e3 * ts / k, "ms_align": 1e3 * ta / k, "steps": k}
 

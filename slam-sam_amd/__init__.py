@@ -625,9 +625,21 @@ class NormalDistributionsTransform:
 
     def prelaunchCounters(self):
         """(evaluations served by a pre-launched kernel, pre-launched kernels told to leave, time-outs)."""
-        out = (C.c_int64 * 3)()
+        out = (C.c_int64 * 5)()
         self._check(lib().ndt_debug_prelaunch_counters(self._h, out))
-        return tuple(out)
+        return tuple(out)[:3]
+
+    def prelaunchOverlapped(self):
+        """Pre-launched kernels that were enqueued on the other stream (resident before their predecessor ended)."""
+        out = (C.c_int64 * 5)()
+        self._check(lib().ndt_debug_prelaunch_counters(self._h, out))
+        return int(out[3])
+
+    def p2pHostFinishes(self):
+        """Peer-write evaluations whose cross-rank exchange the host had to finish (a peer's row was > 20 ms late)."""
+        out = (C.c_int64 * 5)()
+        self._check(lib().ndt_debug_prelaunch_counters(self._h, out))
+        return int(out[4])
 
     def buildCounters(self):
         """(builds that fell back from the fused sort passes to the classic ones, two-launch bucketed builds

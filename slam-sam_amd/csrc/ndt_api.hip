@@ -81,6 +81,7 @@ struct ndt_handle {
   ndt_params prm;
   int device = -1;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;       // pre-launched evaluation kernels alternate between `stream` and this one
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
   std::string err;
 
@@ -181,6 +182,11 @@ struct ndt_handle {
   bool prelaunch_armed = false;       // inside ndt_align
   unsigned long long pre_seq = 0;     // sequence number of the kernel that is waiting, 0 = none
   unsigned long long pre_round = 0;   // ... and the cross-rank round it will exchange under (NDT_REDUCE_P2P)
+  int pre_on2 = 0;                    // ... and the stream it is on (0: stream, 1: stream2)
+  int cur_on2 = 0;                    // stream of the evaluation in flight
+  bool two_streams = true;            // NDT_PRELAUNCH_STREAMS != 1
+  DevBuf<unsigned int> arrive_ctr;    // [2] blocks of a pre-launched launch that have started (per result buffer)
+  PinBuf<unsigned long long> arrived; // [2] sequence number of the launch whose blocks are all resident
   int pre_buf = 0;                    // ... and the result buffer (0 / 1) it will write
   int prelaunch_strikes = 0;          // consecutive aligns in which a waiting kernel gave up
   bool prelaunch_suspended = false;   // three such aligns in a row (a chronically starved host): no more pre-launching
@@ -189,6 +195,8 @@ struct ndt_handle {
   int flag_toggle = 0;                // result buffer of the latest single-pose launch
   bool pre_need_h = false;
   int64_t n_prelaunch_used = 0, n_prelaunch_quit = 0, n_prelaunch_timeouts = 0;
+  int64_t n_p2p_host_finishes = 0;     // peer-write evaluations whose exchange the host finished (a peer was late)
+  int64_t n_prelaunch_overlapped = 0; // pre-launches that went to the other stream (resident before their predecessor ended)
 
   bool have_reg = false;
   float reg_pose[16];
@@ -644,6 +652,7 @@ int wait_slots(ndt_handle* h, unsigned long long seq, int K = 1, int first = 0) 
   while (!all_complete()) {
     if ((++spins & 0x3FFF) == 0 && std::chrono::steady_clock::now() - t0 > kHostSpinLimit) {
       HIP_TRY(h, hipStreamSynchronize(h->stream));
+      HIP_TRY(h, hipStreamSynchronize(h->stream2));
       if (!all_complete()) {
         h->counters_zeroed = 0;  // the ticket words may be stale: re-zero them before the next launch
         return fail(h, NDT_ERR_HIP, "derivative kernel finished without publishing its result");
@@ -759,6 +768,7 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
       seq = h->pre_seq;
       buf = h->pre_buf;
       xround = h->pre_round;
+      h->cur_on2 = h->pre_on2;
       h->pre_seq = 0;
 #ifdef NDT_TEST_SEAMS
       {  // test seam (libndt_hip_seams.so only): hold the pose back so that the waiting kernel gives up
@@ -773,9 +783,18 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
       quit_prelaunched(h);
     }
   }
+#ifdef NDT_TEST_SEAMS
+  {  // test seam (libndt_hip_seams.so only): rank 1 of a peer-write job is late for one evaluation, so that the
+     // other ranks' kernels give up waiting for its row (EV_FAIL = 3) and their hosts finish the exchange
+    static const int late_ms = [] { const char* e = getenv("NDT_DEBUG_P2P_LATE_MS"); return e ? atoi(e) : 0; }();
+    if (late_ms > 0 && p2p && h->red.rank() == 1 && h->tm.n_eval_launches == 4)
+      std::this_thread::sleep_for(std::chrono::milliseconds(late_ms));
+  }
+#endif
   if (!via_mailbox) {
     seq = g_launch_seq.fetch_add(1, std::memory_order_relaxed);
     buf = (h->flag_toggle ^= 1);
+    h->cur_on2 = 0;
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, s));
     launch_derivatives(px, py, pz, h->n_src, h->geom, h->cell2leaf.p, h->rec.p, pc, nullptr, 1, ec, h->partials.p,
                        h->counters.p, d_out, s, spin ? h->flag.d + (size_t)buf * 2 * EV_WORDS : nullptr, seq, nullptr,
@@ -791,9 +810,36 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
     h->pre_need_h = need_h;
     h->pre_buf = (h->flag_toggle ^= 1);
     h->pre_round = xround + 1;
+    // Which stream: behind the evaluation in flight (same stream: starts when that launch has ENDED), or on the
+    // other stream, where its blocks take compute units as the blocks of the launch in flight leave -- resident
+    // and polling by the time the host has the next pose (the end-of-launch barrier, the dispatch and the cold
+    // start of a kernel are 2-3 us of every evaluation otherwise).  Only when the launch in flight needs no
+    // more compute units itself (its last-arriving block has said so): the two must never wait for each other.
+    // An ordinary launch (first evaluation of an align) never qualifies.
+    if (!h->arrive_ctr.p) {
+      HIP_TRY(h, h->arrive_ctr.ensure(2));
+      HIP_TRY(h, hipMemsetAsync(h->arrive_ctr.p, 0, h->arrive_ctr.cap * sizeof(unsigned int), s));
+      HIP_TRY(h, hipStreamSynchronize(s));
+      HIP_TRY(h, h->arrived.ensure(2));
+      h->arrived.h[0] = h->arrived.h[1] = 0;
+    }
+    // (The launch in flight has just been given its pose; if it was queued behind its predecessor it is only now
+    // starting.  The next kernel is not needed for another ~10 us, so the host can afford to watch the arrival
+    // word for a few microseconds before it decides.)
+    bool in_flight_resident = false;
+    if (h->two_streams && via_mailbox) {
+      const auto t_arr = std::chrono::steady_clock::now();
+      for (unsigned spins = 0;; ++spins) {
+        if (__atomic_load_n(&h->arrived.h[buf], __ATOMIC_ACQUIRE) == seq) { in_flight_resident = true; break; }
+        if ((spins & 63) == 63 && std::chrono::steady_clock::now() - t_arr > std::chrono::microseconds(6)) break;
+        _mm_pause();
+      }
+    }
+    h->pre_on2 = in_flight_resident ? (h->cur_on2 ^ 1) : h->cur_on2;
+    if (in_flight_resident) h->n_prelaunch_overlapped++;
     launch_derivatives(px, py, pz, h->n_src, h->geom, h->cell2leaf.p, h->rec.p, pc, nullptr, 1, ec, h->partials.p,
-                       h->counters.p, d_out, s, h->flag.d + (size_t)h->pre_buf * 2 * EV_WORDS, h->pre_seq, h->mbox,
-                       xinfo, h->pre_round);
+                       h->counters.p, d_out, h->pre_on2 ? h->stream2 : s, h->flag.d + (size_t)h->pre_buf * 2 * EV_WORDS,
+                       h->pre_seq, h->mbox, xinfo, h->pre_round, h->arrive_ctr.p + h->pre_buf, h->arrived.d + h->pre_buf);
     HIP_TRY(h, hipGetLastError());
   }
   if (dev_out) {
@@ -823,6 +869,7 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
   }
   if (p2p) {
     if (words[EV_FAIL] == 3.0) {
+      h->n_p2p_host_finishes++;
       // this rank's sum is published, a peer was more than 20 ms late (a starved host over there):
       // the kernel is gone, the host finishes the same exchange -- same rows, same rank order
       int rc = h->red.p2p_finish_on_host(xround, words, EV_WORDS, &h->err);
@@ -857,6 +904,7 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
     h->prelaunch_armed = false;
     h->counters_zeroed = 0;  // ticket mode: the partial tickets of the abandoned launch are not zero
     HIP_TRY(h, hipStreamSynchronize(s));  // the abandoned grid has drained before its rows are reused
+    HIP_TRY(h, hipStreamSynchronize(h->stream2));
     if (++h->prelaunch_strikes >= 3) h->prelaunch_suspended = true;
     return evaluate(h, p, T, need_h, out, score_only);
   }
@@ -966,7 +1014,12 @@ int ndt_create(const ndt_params* p, ndt_handle** out) {
     h->mbox_tagged = !(t && atoi(t) == 0);
     h->mbox_preload = q && atoi(q) != 0;
   }
+  {
+    const char* e = getenv("NDT_PRELAUNCH_STREAMS");
+    h->two_streams = !(e && atoi(e) == 1);
+  }
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
       hipEventCreate(&h->ev2) != hipSuccess) {
     delete h;
@@ -980,6 +1033,7 @@ int ndt_destroy(ndt_handle* h) {
   if (!h) return NDT_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->stream2) (void)hipStreamSynchronize(h->stream2);
   h->red.destroy();
   h->tx.release(); h->ty.release(); h->tz.release();
   h->keys.release(); h->vals.release(); h->keys2.release(); h->vals2.release();
@@ -1000,6 +1054,8 @@ int ndt_destroy(ndt_handle* h) {
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->ev2) (void)hipEventDestroy(h->ev2);
   if (h->stream) (void)hipStreamDestroy(h->stream);
+  if (h->stream2) (void)hipStreamDestroy(h->stream2);
+  h->arrive_ctr.release(); h->arrived.release();
   delete h;
   return NDT_OK;
 }
@@ -1718,9 +1774,11 @@ int ndt_result_covariance(const double hessian36[36], double eps, int gtsam_orde
 
 // test seam (not in the public header): evaluations served by a pre-launched kernel, pre-launched
 // kernels told to leave, mailbox time-outs
-int ndt_debug_prelaunch_counters(const ndt_handle* h, int64_t out[3]) {
+int ndt_debug_prelaunch_counters(const ndt_handle* h, int64_t out[5]) {
   if (!h || !out) return NDT_ERR_INVALID_ARG;
   out[0] = h->n_prelaunch_used; out[1] = h->n_prelaunch_quit; out[2] = h->n_prelaunch_timeouts;
+  out[3] = h->n_prelaunch_overlapped;
+  out[4] = h->n_p2p_host_finishes;
   return NDT_OK;
 }
 

@@ -22,6 +22,7 @@
 #include "ndt_kernels.h"
 
 #include <cstddef>
+#include <algorithm>
 #include <cstdlib>
 
 namespace ndt {
@@ -255,9 +256,33 @@ __device__ __forceinline__ void point_pairs(PairAcc& a, float x, float y, float 
   // masked out, so the unrolled pairs carry no exec-mask splits and no accumulator merges.
   // Records are fetched in two batches (4 + 3) so a point pays two L2 round trips for its
   // neighbours instead of seven, within a 128-VGPR budget.
-  // Software-pipelined by hand: four records in flight, each further one requested as soon as
-  // one has been consumed.  The scheduling fences keep the compiler from sinking the loads
+  // Software-pipelined by hand: THREE records in flight, each further one requested as soon as
+  // one has been consumed (four were in flight in rounds 1-2: with the final sum's retry state on top, the
+  // full-Hessian and Gauss-Newton instantiations then spilled 2-3 VGPRs; interleaved A/B on one box,
+  // profiles/r03_step_ab_summer_depth.txt: no difference in wall time per evaluation, 0.7 us less per
+  // ordinary launch by HIP events).  The scheduling fences keep the compiler from sinking the loads
   // back to their first use (it otherwise serialises seven L2 round trips per point).
+#ifndef NDT_PAIR_DEPTH4
+  const VoxelRecord r0 = rec[slot[0] >= 0 ? slot[0] : 0];
+  const VoxelRecord r1 = rec[slot[1] >= 0 ? slot[1] : 0];
+  const VoxelRecord r2 = rec[slot[2] >= 0 ? slot[2] : 0];
+  __builtin_amdgcn_sched_barrier(0);
+  pair_update<MODE>(a, r0, xt, yt, zt, ec, slot[0] >= 0);
+  const VoxelRecord r3 = rec[slot[3] >= 0 ? slot[3] : 0];
+  __builtin_amdgcn_sched_barrier(0);
+  pair_update<MODE>(a, r1, xt, yt, zt, ec, slot[1] >= 0);
+  const VoxelRecord r4 = rec[slot[4] >= 0 ? slot[4] : 0];
+  __builtin_amdgcn_sched_barrier(0);
+  pair_update<MODE>(a, r2, xt, yt, zt, ec, slot[2] >= 0);
+  const VoxelRecord r5 = rec[slot[5] >= 0 ? slot[5] : 0];
+  __builtin_amdgcn_sched_barrier(0);
+  pair_update<MODE>(a, r3, xt, yt, zt, ec, slot[3] >= 0);
+  const VoxelRecord r6 = rec[slot[6] >= 0 ? slot[6] : 0];
+  __builtin_amdgcn_sched_barrier(0);
+  pair_update<MODE>(a, r4, xt, yt, zt, ec, slot[4] >= 0);
+  pair_update<MODE>(a, r5, xt, yt, zt, ec, slot[5] >= 0);
+  pair_update<MODE>(a, r6, xt, yt, zt, ec, slot[6] >= 0);
+#else  // four in flight (rounds 1-2): 8-12 bytes of scratch per lane in the full-Hessian / Gauss-Newton DIRECT7 kernels
   const VoxelRecord r0 = rec[slot[0] >= 0 ? slot[0] : 0];
   const VoxelRecord r1 = rec[slot[1] >= 0 ? slot[1] : 0];
   const VoxelRecord r2 = rec[slot[2] >= 0 ? slot[2] : 0];
@@ -276,6 +301,7 @@ __device__ __forceinline__ void point_pairs(PairAcc& a, float x, float y, float 
   pair_update<MODE>(a, r4, xt, yt, zt, ec, slot[4] >= 0);
   pair_update<MODE>(a, r5, xt, yt, zt, ec, slot[5] >= 0);
   pair_update<MODE>(a, r6, xt, yt, zt, ec, slot[6] >= 0);
+#endif
 }
 
 // FLANN's L2_Simple in f32, accumulated x, y, z, strict `<` (ref: radiusSearch,
@@ -488,6 +514,7 @@ __device__ __forceinline__ void wave_reduce_scatter32(double* acc, int lane) {
 // written to a side buffer no other code reads (cdna_hip_programming.md section 7)
 __device__ unsigned long long g_stamps[4096 * 8];
 __device__ unsigned int g_hwid[4096 * 2];
+__device__ unsigned long long g_mstamps[4096 * 2];  // pre-launched launches that computed: {entry, pose seen}
 #define NDT_STAMP(k)                                                                   \
   do {                                                                                 \
     if (threadIdx.x == 0 && blockIdx.x < 4096 && blockIdx.y == 0) {                    \
@@ -525,7 +552,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int ROW_WORDS = 2 * EV_WORDS;   // 32 x {tag, value}
 constexpr int AUX_AGENT = 16;             // sc1
 constexpr int AUX_SYSTEM = 17;            // sc0 sc1
-constexpr int SUM_BATCH = 20;             // rows per thread and memory round trip (80 VGPRs in flight; 25 would spill)
+constexpr int SUM_BATCH = 16;             // rows per thread and memory round trip (64 VGPRs in flight; 20 spilled once the retry mask joined them)
 constexpr unsigned long long SUM_TIMEOUT_TICKS = 10000000ull;  // 100 ms of the 100 MHz clock: no launch of this kernel runs that long
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t slots_rsrc(const void* p) {
@@ -598,22 +625,29 @@ __device__ __forceinline__ void sum_rows(__amdgpu_buffer_rsrc_t rows, unsigned i
   double s = 0.0;
   for (int b0 = first + c; b0 < end; b0 += SUM_BATCH * ncols) {
     u32x4 t[SUM_BATCH];
+    // Slots that carry this launch's tag are kept; only the MISSING ones are requested again.  (Re-reading the whole
+    // batch on every trip -- 241 rows x 32 slots = 123 KB per trip for the 200 k-point scan -- made a trip ~1.5 us,
+    // and the sum trailed the last row by two trips: round-3 stamps, profiles/r03_stamps_prelaunch.txt.)
+    unsigned int missing = 0u;
+#pragma unroll
+    for (int k = 0; k < SUM_BATCH; ++k) {
+      t[k].x = tag_lo; t[k].y = tag_hi; t[k].z = 0u; t[k].w = 0u;   // (rows beyond `end` add an exact zero)
+      if (b0 + k * ncols < end) missing |= 1u << k;
+    }
     const unsigned long long t_wait0 = __builtin_amdgcn_s_memrealtime();
     for (;;) {
-      asm volatile("" ::: "memory");  // the loads below must be re-issued on every trip
-      bool ok = true;
+      // EVERY load of a slot sits behind this clobber, inside the loop: with a copy of the first batch in front of
+      // the loop the compiler took the in-loop load of slot 0 for the same value and never re-read it (the
+      // summing block then waited 100 ms for its own row)
+      asm volatile("" ::: "memory");
 #pragma unroll
-      for (int k = 0; k < SUM_BATCH; ++k) {
-        const int b = b0 + k * ncols;
-        if (b < end) {
-          t[k] = __builtin_amdgcn_raw_buffer_load_b128(rows, rows_off + ((unsigned int)b * EV_WORDS + v) * 16u, 0, AUX_AGENT);
-        } else {
-          t[k].x = tag_lo; t[k].y = tag_hi; t[k].z = 0u; t[k].w = 0u;
-        }
-      }
+      for (int k = 0; k < SUM_BATCH; ++k)
+        if (missing & (1u << k))
+          t[k] = __builtin_amdgcn_raw_buffer_load_b128(rows, rows_off + ((unsigned int)(b0 + k * ncols) * EV_WORDS + v) * 16u, 0, AUX_AGENT);
 #pragma unroll
-      for (int k = 0; k < SUM_BATCH; ++k) ok = ok && t[k].x == tag_lo && t[k].y == tag_hi;
-      if (ok) break;
+      for (int k = 0; k < SUM_BATCH; ++k)
+        if (t[k].x == tag_lo && t[k].y == tag_hi) missing &= ~(1u << k);
+      if (missing == 0u) break;
       if (__builtin_amdgcn_s_memrealtime() - t_wait0 > SUM_TIMEOUT_TICKS) {
         // a row that never comes (its block left without computing: a pre-launched grid whose blocks
         // timed out unevenly); exit anyway and say so: word 31 of an evaluation is 0 by construction,
@@ -625,7 +659,7 @@ __device__ __forceinline__ void sum_rows(__amdgpu_buffer_rsrc_t rows, unsigned i
     }
 #pragma unroll
     for (int k = 0; k < SUM_BATCH; ++k)
-      s += __longlong_as_double((long long)(((unsigned long long)t[k].w << 32) | t[k].z));
+      s += (missing & (1u << k)) ? 0.0 : __longlong_as_double((long long)(((unsigned long long)t[k].w << 32) | t[k].z));
   }
   lds_c[c][v] = s;
   __syncthreads();
@@ -656,7 +690,9 @@ __device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], double
                                                     double* __restrict__ out,
                                                     unsigned long long* host_slots, unsigned long long seq,
                                                     int single_level_max, bool fixed_summer,
-                                                    const XchgInfo* __restrict__ xi, unsigned long long xround) {
+                                                    const XchgInfo* __restrict__ xi, unsigned long long xround,
+                                                    int my_row /* this block's row */, int nb /* rows = computing blocks */,
+                                                    bool dedicated /* a block without points adds the rows */) {
   __shared__ double lds_w[MAX_WAVES][EV_WORDS];
   __shared__ double lds_c[MAX_COLS][EV_WORDS];
   __shared__ int s_last;
@@ -671,16 +707,16 @@ __device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], double
     double sum = 0.0;
     const int nwaves = (int)blockDim.x >> 6;
     for (int wv = 0; wv < nwaves; ++wv) sum += lds_w[wv][threadIdx.x];
-    store_slot(rrows, ((unsigned int)blockIdx.x * EV_WORDS + threadIdx.x) * 16u, seq, sum, false);
+    store_slot(rrows, ((unsigned int)my_row * EV_WORDS + threadIdx.x) * 16u, seq, sum, false);
   }
   NDT_STAMP(4);
-  const int nb = (int)gridDim.x;
+  if (dedicated) return;  // the summing block (summer_finish) polls the rows; this block is done
   int ngroups = 1;
   const __amdgpu_buffer_rsrc_t rgroups = slots_rsrc(group_rows);
   if (nb > single_level_max) {
     const int gsize = (nb + NGROUPS - 1) / NGROUPS;  // blocks per group
     ngroups = (nb + gsize - 1) / gsize;              // <= NGROUPS
-    const int grp = (int)blockIdx.x / gsize;
+    const int grp = my_row / gsize;
     const int first = grp * gsize, end = min(first + gsize, nb);
     // the row stores above were issued by wave 0, the wave that takes the ticket
     if (threadIdx.x == 0) s_last = ticket_is_last(counters + 1 + grp, (unsigned int)(end - first));
@@ -697,7 +733,7 @@ __device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], double
     // the tags; every other block is done once its row store is issued.  Takes the ticket's
     // atomic round trip out of the launch's critical path.  Block 0 depends on the others, never
     // the other way round, so a grid larger than the machine cannot dead-lock on it.
-    if (blockIdx.x != 0) return;
+    if (my_row != 0) return;
     NDT_STAMP(5);
   } else {
     if (threadIdx.x == 0) s_last = ticket_is_last(counters, (unsigned int)nrows);
@@ -710,6 +746,25 @@ __device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], double
   NDT_STAMP(6);
   if (threadIdx.x <= ngroups && !(fixed_summer && !two_level))  // leave the tickets at zero for the next launch
     __hip_atomic_store(counters + threadIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  NDT_STAMP(7);
+}
+
+// The dedicated summing block (EvalConsts::dedicated_summer): block 0 of the grid owns NO points.  It starts polling
+// the rows' tags at once and keeps every slot that has arrived, so when the last computing block's row lands only
+// that row is still to be fetched -- where a computing block that doubles as the summer first finishes its own
+// points and then pays a whole memory round trip for all the rows (2.6 us behind the last row for the 200 k-point
+// scan, profiles/r03_stamps_prelaunch.txt).  One spare compute unit (the scan's grid is 241 of 256).
+__device__ __forceinline__ void summer_finish(double* __restrict__ rows, double* __restrict__ out,
+                                              unsigned long long* host_slots, unsigned long long seq, int nrows,
+                                              const XchgInfo* __restrict__ xi, unsigned long long xround) {
+  __shared__ double lds_c[MAX_COLS][EV_WORDS];
+  __shared__ int s_fail;
+  if (threadIdx.x == 0) s_fail = 0;
+  __syncthreads();
+  NDT_STAMP(5);
+  sum_rows(slots_rsrc(rows), 0u, 0, nrows, seq, lds_c, slots_rsrc(host_slots), 0u, true, host_slots ? nullptr : out, &s_fail,
+           xi, xround);
+  NDT_STAMP(6);
   NDT_STAMP(7);
 }
 
@@ -735,6 +790,8 @@ struct DerivKernArgs {
   const PoseMailbox* mbox;
   const XchgInfo* xinfo;
   unsigned long long xround;
+  unsigned int* arrive_ctr;
+  unsigned long long* arrived_host;
 };
 constexpr unsigned int KERNARG_TABLES_OFFSET = offsetof(DerivKernArgs, pose) + offsetof(PoseConsts, jang);
 static_assert(offsetof(PoseConsts, hang) == offsetof(PoseConsts, jang) + 24 * sizeof(float) &&
@@ -750,7 +807,8 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
               PoseConsts pose_arg, const PoseConsts* __restrict__ poses, EvalConsts ec,
               double* __restrict__ partials, unsigned int* __restrict__ counters, double* __restrict__ out,
               unsigned long long* flag, unsigned long long seq, const PoseMailbox* mbox,
-              const XchgInfo* __restrict__ xinfo, unsigned long long xround) {
+              const XchgInfo* __restrict__ xinfo, unsigned long long xround,
+              unsigned int* __restrict__ arrive_ctr, unsigned long long* arrived_host) {
   // R|t (12 dwords) stay in scalar registers; the 69 angle-table words are only needed
   // after the pair loop, so they are parked in LDS (81 live SGPRs would spill) and the
   // barrier that publishes them sits behind the memory-latency part of the kernel.
@@ -770,7 +828,9 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
   float tab_word = 0.0f;
   // exactly one source point per thread: the 32 accumulator words are only live from the
   // per-point expansion to the block reduction, not across the pair loop
-  const int i = blockIdx.x * (int)blockDim.x + threadIdx.x;
+  // (with a dedicated summing block the points start at block 1; block 0's threads own none)
+  const bool summing_block = ec.dedicated_summer != 0 && blockIdx.x == 0;
+  const int i = summing_block ? n : ((int)blockIdx.x - ec.dedicated_summer) * (int)blockDim.x + threadIdx.x;
   float x = 0.0f, y = 0.0f, z = 0.0f;
   if (MBOX) {
     // a pre-launched kernel has nothing to do until its pose arrives: its point does not depend
@@ -781,6 +841,17 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
     // profiles/r02_mailbox_prefetch_ab.txt.  Not kept.)
     __shared__ float s_rt[12];
     __shared__ int s_go;
+    // "every block of this launch is resident": the block that arrives last says so in pinned host memory.  The
+    // host only enqueues the NEXT evaluation's kernel on the other stream (where it can take compute units as
+    // this launch's blocks leave, instead of waiting for the launch to end) once this launch needs no more
+    // compute units -- otherwise the two could wait for each other.  Off the critical path: nothing waits for it.
+    if (arrive_ctr != nullptr && threadIdx.x == 0) {
+      const unsigned int t = __hip_atomic_fetch_add(arrive_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t == gridDim.x * gridDim.y - 1u) {
+        __hip_atomic_store(arrive_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(arrived_host, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
     if (ec.mbox_tagged) {
       // the pose as 82 self-validating 8-byte granules {tag, word} (PoseMailbox): lane k < 41 of wave 0
       // watches granules 2k and 2k + 1 with one 16-byte load; when every tag is this launch's the
@@ -828,6 +899,12 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
       __syncthreads();
     }
     const int go = s_go;
+#ifdef NDT_STAMPS
+    if (go == 1 && threadIdx.x == 0 && blockIdx.x < 4096) {
+      g_mstamps[blockIdx.x * 2] = g_stamps[blockIdx.x * 8];   // (this launch's entry stamp)
+      g_mstamps[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     if (go <= 0) {
       // quit: nothing to do.  timed out: say so in the result slots (word 31 = 2), the host
       // evaluates this pose through an ordinary launch instead
@@ -863,6 +940,12 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
       const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();  // constant -> generic address space
       tab_word = reinterpret_cast<const float*>(ka + KERNARG_TABLES_OFFSET)[threadIdx.x];
     }
+  }
+  if (summing_block) {   // uniform
+    double* sbase = partials + (size_t)blockIdx.y * (gridDim.x + NGROUPS) * ROW_WORDS;
+    summer_finish(sbase + (size_t)NGROUPS * ROW_WORDS, out + (size_t)blockIdx.y * EV_WORDS,
+                  flag ? flag + (size_t)blockIdx.y * ROW_WORDS : nullptr, seq, (int)gridDim.x - 1, BATCH ? nullptr : xinfo, xround);
+    return;
   }
   PairAcc a;
   a.w[0] = a.w[1] = a.w[2] = 0.0;
@@ -902,7 +985,8 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
                       out + (size_t)blockIdx.y * EV_WORDS,
                       flag ? flag + (size_t)blockIdx.y * ROW_WORDS : nullptr,  // pose y's 32 host slots
                       seq, ec.single_level_max,
-                      ec.fixed_summer != 0, BATCH ? nullptr : xinfo, xround);
+                      ec.fixed_summer != 0, BATCH ? nullptr : xinfo, xround, (int)blockIdx.x - ec.dedicated_summer,
+                      (int)gridDim.x - ec.dedicated_summer, ec.dedicated_summer != 0);
 }
 
 __global__ void __launch_bounds__(256) k_transform(const float* __restrict__ sx, const float* __restrict__ sy,
@@ -928,7 +1012,9 @@ int derivs_read_stamps(unsigned long long* out, int nblocks) {
   if (nblocks > 4096) nblocks = 4096;
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8 * nblocks) != hipSuccess) return -1;
   // hw ids follow the stamps: nblocks x 2 uint32 packed into nblocks uint64
-  return hipMemcpyFromSymbol(out + (size_t)8 * nblocks, HIP_SYMBOL(g_hwid), sizeof(unsigned int) * 2 * nblocks) == hipSuccess ? nblocks : -1;
+  if (hipMemcpyFromSymbol(out + (size_t)8 * nblocks, HIP_SYMBOL(g_hwid), sizeof(unsigned int) * 2 * nblocks) != hipSuccess) return -1;
+  // ... and {entry, pose seen} of the last pre-launched launch that computed: 2 x nblocks uint64
+  return hipMemcpyFromSymbol(out + (size_t)9 * nblocks, HIP_SYMBOL(g_mstamps), sizeof(unsigned long long) * 2 * nblocks) == hipSuccess ? nblocks : -1;
 #else
   (void)out; (void)nblocks;
   return 0;
@@ -948,6 +1034,28 @@ int derivs_read_stamps(unsigned long long* out, int nblocks) {
 static int g_compute_units = 256;
 void derivs_set_compute_units(int n) { if (n > 0) g_compute_units = n; }
 
+namespace {
+int deriv_single_level_max() {
+  static const int slm = [] {
+    const char* e = getenv("NDT_DERIV_SINGLE_LEVEL_MAX");  // tuning knob
+    int v = e ? atoi(e) : 0;
+    return v > 0 ? v : SINGLE_LEVEL_MAX_DEFAULT;
+  }();
+  return slm;
+}
+int deriv_fixed_summer() {
+  static const int summer = [] {
+    const char* e = getenv("NDT_DERIV_SUMMER");  // A/B knob: 0 = ticket + last block, 1 = a fixed block polls the rows
+    return e ? atoi(e) : NDT_DERIV_SUMMER_DEFAULT;
+  }();
+  return summer;
+}
+bool deriv_dedicated_enabled() {
+  static const bool on = [] { const char* e = getenv("NDT_DERIV_DEDICATED"); return !(e && atoi(e) == 0); }();  // A/B knob
+  return on;
+}
+}  // namespace
+
 int derivs_block_threads(size_t n_src, int K) {
   static const int forced = [] {
     const char* e = getenv("NDT_DERIV_BLOCK");  // multiple of 64, 64..1024
@@ -955,20 +1063,31 @@ int derivs_block_threads(size_t n_src, int K) {
     return (v >= 64 && v <= MAX_BLOCK && v % 64 == 0) ? v : 0;
   }();
   if (forced) return forced;
-  const size_t kCUs = (size_t)g_compute_units;
-  if (K == 1 && n_src > (size_t)512 * kCUs && n_src <= (size_t)MAX_BLOCK * kCUs) {
+  // (one compute unit is left to the dedicated summing block)
+  const size_t kCUs = (size_t)std::max(2, g_compute_units - (deriv_dedicated_enabled() && deriv_fixed_summer() ? 1 : 0));
+  // (up to 512 points per compute unit the 512-thread shape stays: two such blocks share a CU, and a scan of exactly
+  // 128 x 1024 points keeps the same partition -- hence the same sums, bit for bit -- single-pose and batched)
+  if (K == 1 && n_src > (size_t)512 * (size_t)g_compute_units && n_src <= (size_t)MAX_BLOCK * kCUs) {
     const size_t per_cu = (n_src + kCUs - 1) / kCUs;
     return (int)(((per_cu + 63) / 64) * 64);
   }
   return 512;
 }
 
-int derivs_grid_blocks(size_t n_src, int K) {
+// blocks that own points
+static int derivs_point_blocks(size_t n_src, int K) {
   const size_t bt = (size_t)derivs_block_threads(n_src, K);
   size_t blocks = (n_src + bt - 1) / bt;  // one point per thread
   if (blocks < 1) blocks = 1;
   return (int)blocks;
 }
+
+// 1: block 0 of the grid owns no points and adds the rows (single-level grids with the fixed summer)
+static int derivs_dedicated_summer(size_t n_src, int K) {
+  return deriv_dedicated_enabled() && deriv_fixed_summer() != 0 && derivs_point_blocks(n_src, K) <= deriv_single_level_max() ? 1 : 0;
+}
+
+int derivs_grid_blocks(size_t n_src, int K) { return derivs_point_blocks(n_src, K) + derivs_dedicated_summer(n_src, K); }
 
 void launch_derivatives(const float* sx, const float* sy, const float* sz, size_t n_src,
                         const GridGeom& g, const int* cell2leaf, const VoxelRecord* rec,
@@ -976,28 +1095,20 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
                         const EvalConsts& ec, double* d_partials, unsigned int* d_counters,
                         double* d_out, hipStream_t s, unsigned long long* d_flag,
                         unsigned long long seq, const PoseMailbox* d_mbox, const XchgInfo* d_xinfo,
-                        unsigned long long xround) {
+                        unsigned long long xround, unsigned int* d_arrive_ctr, unsigned long long* d_arrived_host) {
   const int blocks = derivs_grid_blocks(n_src, d_poses ? K : 1);
   const int threads = derivs_block_threads(n_src, d_poses ? K : 1);
   const int mode = ec.score_only ? 3 : (!ec.need_hessian ? 0 : (ec.gauss_newton ? 2 : 1));
   EvalConsts ecl = ec;
-  static const int slm = [] {
-    const char* e = getenv("NDT_DERIV_SINGLE_LEVEL_MAX");  // tuning knob
-    int v = e ? atoi(e) : 0;
-    return v > 0 ? v : SINGLE_LEVEL_MAX_DEFAULT;
-  }();
-  ecl.single_level_max = slm;
-  static const int summer = [] {
-    const char* e = getenv("NDT_DERIV_SUMMER");  // A/B knob: 0 = ticket + last block, 1 = block 0 polls the rows
-    return e ? atoi(e) : NDT_DERIV_SUMMER_DEFAULT;
-  }();
-  ecl.fixed_summer = summer;
+  ecl.single_level_max = deriv_single_level_max();
+  ecl.fixed_summer = deriv_fixed_summer();
+  ecl.dedicated_summer = derivs_dedicated_summer(n_src, d_poses ? K : 1);
   const int nb = ec.multigrid ? 4 : (ec.kdtree ? 2 : (ec.direct26 ? 3 : (ec.direct7 ? 1 : 0)));
   const size_t dyn_lds = nb >= 2 ? (size_t)KD_CELLS * threads * sizeof(int) : 0;
 #define NDT_LAUNCH2(B, M, NBH, MB, GY, FLAG, SEQ)                                                            \
   hipLaunchKernelGGL((k_derivatives<B, M, NBH, MB>), dim3(blocks, GY), dim3(threads), dyn_lds, s, sx, sy, sz,  \
                      (int)n_src, g, cell2leaf, rec, pose, d_poses, ecl, d_partials, d_counters, d_out,         \
-                     FLAG, SEQ, d_mbox, d_xinfo, xround)
+                     FLAG, SEQ, d_mbox, d_xinfo, xround, d_arrive_ctr, d_arrived_host)
 #define NDT_LAUNCH(B, M, NBH, GY, FLAG, SEQ)                                  \
   do {                                                                         \
     if (!B && d_mbox != nullptr) NDT_LAUNCH2(false, M, NBH, true, GY, FLAG, SEQ);  \

@@ -109,6 +109,7 @@ struct EvalConsts {
   int direct26;    // 1: every valid voxel of the 3x3x3 block around the point's cell (pclomp DIRECT26)
   int score_only;  // 1: score / NVTL / counts only, no gradient or Hessian (ndt_score_transform)
   int fixed_summer;  // 1: block 0 adds the partial rows (polls their tags), no tickets (single-level grids)
+  int dedicated_summer;  // 1: block 0 of the grid owns no points: it only adds the rows (one extra block per pose)
   int mbox_tagged;  // pre-launched kernels: 1 = the pose arrives as tagged 8-byte granules, 0 = words then sequence number
   int mbox_preload; // pre-launched kernels: 1 = the point is fetched before the wait for the pose
   int multigrid;   // 1: the table is a union of grids (radius search, leaves of a cell chained through VoxelRecord::pad)

@@ -136,7 +136,10 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
                         unsigned long long seq, const PoseMailbox* d_mbox = nullptr,
                         // NDT_REDUCE_P2P (single-pose launches): the block that finishes the local sum
                         // exchanges it with the other ranks under the tag `xround` (XchgInfo, ndt_device.h)
-                        const XchgInfo* d_xinfo = nullptr, unsigned long long xround = 0ull);
+                        const XchgInfo* d_xinfo = nullptr, unsigned long long xround = 0ull,
+                        // pre-launched launches: a zeroed device counter and a pinned host word that receives
+                        // `seq` once every block of the launch is resident
+                        unsigned int* d_arrive_ctr = nullptr, unsigned long long* d_arrived_host = nullptr);
 
 void launch_transform(const float* sx, const float* sy, const float* sz, size_t n,
                       const PoseConsts& pose, float* out_xyz, hipStream_t s);

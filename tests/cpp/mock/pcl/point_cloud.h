@@ -15,6 +15,9 @@ class PointCloud {
   bool is_dense = true;
   size_t size() const { return points.size(); }
   bool empty() const { return points.empty(); }
+  void resize(size_t n) { points.resize(n); }
+  PointT& operator[](size_t i) { return points[i]; }
+  const PointT& operator[](size_t i) const { return points[i]; }
   void push_back(const PointT& p) { points.push_back(p); }
   Ptr makeShared() const { return Ptr(new PointCloud<PointT>(*this)); }
 };

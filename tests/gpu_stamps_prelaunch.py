@@ -1,0 +1,32 @@
+"""In-kernel stamps of the LAST pre-launched evaluation of a C3 align (-DNDT_STAMPS build via NDT_HIP_LIB; not
+collected by pytest): how long a block waited for its pose, how far apart the blocks saw it, and the chain
+from there to the result."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import __graft_entry__ as ge
+pkg = ge.load_package(); S = pkg.synth
+cfg = S.config_c3()
+ndt = pkg.NormalDistributionsTransform(device_id=0, resolution=0.5, step_size=0.1, trans_epsilon=1e-4, max_iterations=35)
+ndt.setInputTarget(cfg["target"])
+ndt.setInputSource(cfg["source"])
+L = pkg.lib()
+L.ndt_debug_read_stamps.argtypes = [C.c_void_p, C.c_int]
+n = len(cfg["source"])
+bt = int(os.environ.get("NDT_DERIV_BLOCK", "0")) or ((((n + 255) // 256 + 63) // 64) * 64 if 131072 < n <= 262144 else 512)
+nb = (n + bt - 1) // bt
+for rep in range(4):
+    ndt.align(cfg["guess"])
+    raw = np.zeros(nb * 11, np.uint64)
+    assert L.ndt_debug_read_stamps(raw.ctypes.data, nb) == nb
+    t = raw[:nb * 8].reshape(nb, 8).astype(np.int64)
+    ms = raw[nb * 9:].reshape(nb, 2).astype(np.int64)
+    seen0 = ms[:, 1].min()
+    rel = (t - seen0) * 0.01
+    print("align %d: blocks %d, counters %s overlapped %d" % (rep, nb, ndt.prelaunchCounters(), ndt.prelaunchOverlapped()))
+    print("  waited for the pose (entry -> seen): min %.2f median %.2f max %.2f us" % tuple(np.percentile((ms[:, 1] - ms[:, 0]) * 0.01, [0, 50, 100])))
+    print("  pose seen, spread over blocks: median %.2f max %.2f us after the first" % tuple(np.percentile((ms[:, 1] - seen0) * 0.01, [50, 100])))
+    names = ["(entry)", "xyz loaded", "pairs done", "expanded", "row stored"]
+    for k in range(1, 5):
+        print("  %-12s  min %6.2f  median %6.2f  max %6.2f   (us after the first block saw the pose)" % (names[k], rel[:, k].min(), np.median(rel[:, k]), rel[:, k].max()))
+    print("  block 0: rows summed %.2f  result stored %.2f" % (rel[0, 6], rel[0, 7]))

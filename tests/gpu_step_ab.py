@@ -1,22 +1,18 @@
-"""Round-2 A/B numbers on the C3 workload (tuning aid, not collected by pytest): device-resident
-step (build + set source + align) as bench.py times it, build time, per-evaluation wall time and
-HIP-event kernel time.  Usage: python tests/gpu_r02_ab.py <tag>; knobs come from the environment
-(NDT_DERIV_SUMMER, NDT_DERIV_BLOCK, ...)."""
+"""A/B numbers on the C3 workload (tuning aid, not collected by pytest): device-resident step (build + set
+source + align) as bench.py times it, build time, per-evaluation wall time and HIP-event kernel time.
+Usage: python tests/gpu_step_ab.py <tag>; knobs come from the environment (NDT_PRELAUNCH_STREAMS,
+NDT_DERIV_BLOCK, NDT_BUCKET_BUILD, ...)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-import torch
 import __graft_entry__ as ge
 pkg = ge.load_package(); S = pkg.synth
 tag = sys.argv[1] if len(sys.argv) > 1 else ""
-torch.cuda.init()
-dev = torch.device("cuda:0")
+hip = pkg.ranks.Hip(0)
 cfg = S.config_c3()
 ndt = pkg.NormalDistributionsTransform(device_id=0, resolution=0.5, step_size=0.1, trans_epsilon=1e-4, max_iterations=35)
-tgt = [torch.from_numpy(np.ascontiguousarray(cfg["target"][:, a])).to(dev) for a in range(3)]
-src = [torch.from_numpy(np.ascontiguousarray(cfg["source"][:, a])).to(dev) for a in range(3)]
-torch.cuda.synchronize()
-tp = [t.data_ptr() for t in tgt]; sp = [t.data_ptr() for t in src]
+tp = [hip.upload(cfg["target"][:, a]) for a in range(3)]; sp = [hip.upload(cfg["source"][:, a]) for a in range(3)]
+hip.synchronize()
 g = pkg.ColMajor4f(cfg["guess"])
 nt, ns = len(cfg["target"]), len(cfg["source"])
 def step():
@@ -34,6 +30,7 @@ for _ in range(10): ndt.align(g, return_transform=False)
 t1 = ndt.getTiming(); ndt.enableKernelTiming(False)
 k_us = 1e3 * (t1["ms_eval_kernel_total"] - t0["ms_eval_kernel_total"]) / (t1["n_timed_evals"] - t0["n_timed_evals"])
 med = lambda v: 1e3 * float(np.median(v))
-print("%-14s step %.3f ms = build %.3f (device %.3f) + source %.3f + align %.3f | it %d ev %d reused %d -> %.2f us/eval wall, kernel %.2f us | %.0f it/s | score %.9f"
+pre = ndt.prelaunchCounters() + (ndt.prelaunchOverlapped(),)
+print("%-22s step %.3f ms = build %.3f (device %.3f) + source %.3f + align %.3f | it %d ev %d reused %d -> %.2f us/eval wall, kernel %.2f us | %.0f it/s | score %.9f | prelaunch %s"
       % (tag, med(B) + med(Sx) + med(A), med(B), float(np.median(dev_build)), med(Sx), med(A), r["iterations"], r["n_evaluations"],
-         r["n_evaluations_reused"], 1e3 * med(A) / r["n_evaluations"], k_us, r["iterations"] / (np.median(B) + np.median(Sx) + np.median(A)), r["score"]), flush=True)
+         r["n_evaluations_reused"], 1e3 * med(A) / r["n_evaluations"], k_us, r["iterations"] / (np.median(B) + np.median(Sx) + np.median(A)), r["score"], pre), flush=True)

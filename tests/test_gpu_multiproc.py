@@ -41,7 +41,7 @@ def _worker(rank, world, name, out_dir, mode="shm"):
     T2 = ndt.align(cfg["guess"])                      # a second align on the same reducer (round tags keep counting)
     np.savez(os.path.join(out_dir, "%s_rank%d.npz" % (mode, rank)), T=T, T2=T2, it=r["iterations"], ev=r["n_evaluations"],
              H=r["hessian"], tp=r["transform_probability"], n_pairs=e["n_pairs"], score=e["score"], g=e["gradient"],
-             sc=sc["score"], used=used, timeouts=timeouts)
+             sc=sc["score"], used=used, timeouts=timeouts, finishes=ndt.p2pHostFinishes())
     if board is not None:
         board.barrier()   # nobody unmaps a peer's area while that peer may still write into it
     ndt.commDestroy()
@@ -106,3 +106,37 @@ def test_two_processes_one_gpu_peer_write_reduction_equals_shm(pkg, S, tmp_path)
     assert np.array_equal(z["p2p"][0]["T"], z["p2p"][0]["T2"])
     # evaluations served by kernels that were already waiting on the device for their pose
     assert all(int(z["p2p"][k]["used"]) > 0 for k in range(world))
+
+
+def test_peer_write_reduction_survives_a_late_rank(pkg, S, tmp_path):
+    """One rank is 60 ms late for one evaluation (test seam of libndt_hip_seams.so): the other rank's kernel has
+    published its sum, waits 20 ms for the missing row, gives up with word 31 = 3, and its HOST finishes the same
+    exchange (same rows, same rank order) once the late rank has published.  Every number still equals the
+    shared-memory reducer's; nobody hangs, nobody re-publishes."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    world = 2
+    seams = os.path.join(ROOT, "slam-sam_amd", "libndt_hip_seams.so")
+    old = {k: os.environ.get(k) for k in ("NDT_HIP_LIB", "NDT_DEBUG_P2P_LATE_MS")}
+    try:
+        for mode in ("shm", "p2p"):
+            os.environ["NDT_HIP_LIB"] = seams                 # inherited by the spawned ranks
+            os.environ["NDT_DEBUG_P2P_LATE_MS"] = "60"
+            name = "/ndt_late_%s_%d" % (mode, os.getpid())
+            procs = [ctx.Process(target=_worker, args=(r, world, name, str(tmp_path), mode)) for r in range(world)]
+            for p in procs:
+                p.start()
+            for p in procs:
+                p.join(600)
+                assert p.exitcode == 0, mode
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    z = {m: [np.load(os.path.join(str(tmp_path), "%s_rank%d.npz" % (m, k))) for k in range(world)] for m in ("shm", "p2p")}
+    for key in ("T", "T2", "H", "it", "ev", "score", "g", "sc"):
+        for k in range(world):
+            assert np.array_equal(z["p2p"][k][key], z["shm"][0][key]), (key, k)
+    assert int(z["p2p"][0]["finishes"]) >= 1 and int(z["p2p"][1]["finishes"]) == 0   # rank 0 waited for rank 1

@@ -30,7 +30,6 @@ def test_derivative_kernels_do_not_spill(tmp_path):
         assert tpl, name
         batch, mode, nb = (int(v) for v in tpl.groups())
         assert u["VGPRs"] <= 128 and u["Occupancy"] >= 4, (name, u)
-        if mode in (0, 1, 3) or nb != 1:
-            assert u["ScratchSize"] == 0, (name, u)
-        else:   # Gauss-Newton x DIRECT7: 3 VGPRs (12 bytes) spilled by the allocator today; must not grow
-            assert u["ScratchSize"] <= 16, (name, u)
+        # no instantiation spills (round 3: three records in flight instead of four; the Gauss-Newton x DIRECT7
+        # kernel -- svn_ndt's default engine -- carried 12 bytes of scratch per lane until then)
+        assert u["ScratchSize"] == 0, (name, u)
