@@ -209,7 +209,10 @@ def main():
     sptr = [hip.upload(cfg["source"][b:b + c, a]) for a in range(3)]
     hip.synchronize()
 
-    ndt = pkg.NormalDistributionsTransform(device_id=local_rank, **params)
+    # ranks that share one device (rehearsal): every engine keeps its pre-launched kernels on its own stream -- a
+    # waiting kernel holds compute units the other rank's running kernel needs (include/ndt_hip.h, ndt_prelaunch)
+    engine_kw = dict(params, prelaunch=pkg.PRELAUNCH_ONE_STREAM) if (rehearsal and world > 1) else dict(params)
+    ndt = pkg.NormalDistributionsTransform(device_id=local_rank, **engine_kw)
 
     # what a C++ caller hands over without any per-call work: raw pointers and guess.data()
     n_tgt = len(cfg["target"])

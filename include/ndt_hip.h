@@ -100,13 +100,18 @@ typedef enum ndt_source_order {
 } ndt_source_order;
 
 typedef enum ndt_prelaunch {
-  NDT_PRELAUNCH_AUTO = 0, /* inside ndt_align (spin wait, no device-side reducer): the kernel of the next
-                             evaluation is enqueued while the current one runs and waits on the device for its
-                             pose, which the host publishes through BAR-mapped device memory -- takes the launch
-                             + dispatch latency (~4 us of ~7) out of every evaluation but the first.  Used when
-                             the device exposes a large BAR; a kernel that waited 20 ms gives up and the pose is
-                             evaluated through an ordinary launch. */
-  NDT_PRELAUNCH_OFF = 1
+  NDT_PRELAUNCH_AUTO = 0, /* inside ndt_align (spin wait, no RCCL reducer): the kernel of the next evaluation is
+                             enqueued while the current one runs and waits on the device for its pose, which the
+                             host publishes through BAR-mapped device memory -- takes the launch + dispatch latency
+                             (~4 us of ~7) out of every evaluation but the first.  Successive kernels alternate
+                             between two streams of the engine, so that the next one takes compute units as the
+                             blocks of the one in flight leave.  Used when the device exposes a large BAR; a kernel
+                             that waited 20 ms gives up and the pose is evaluated through an ordinary launch. */
+  NDT_PRELAUNCH_OFF = 1,
+  NDT_PRELAUNCH_ONE_STREAM = 2 /* as AUTO, but every kernel stays on the engine's one stream (the next starts when the
+                             current one has ENDED).  For several engines / processes that share ONE device: a
+                             waiting kernel holds its compute units, and with two streams it holds them for the
+                             whole evaluation of its predecessor -- units the other engine's running kernel needs. */
 } ndt_prelaunch;
 
 /* Named parameter sets.  ndt_default_params() is the vendored-code hybrid the parity tests pin

@@ -30,7 +30,7 @@ HESSIAN_FULL, HESSIAN_GAUSS_NEWTON = 0, 1
 COV_SVN, COV_PCL_RECALLED = 0, 1
 WAIT_SPIN, WAIT_BLOCK = 0, 1
 SOURCE_ORDER_AUTO, SOURCE_ORDER_KEEP, SOURCE_ORDER_SORT = 0, 1, 2
-PRELAUNCH_AUTO, PRELAUNCH_OFF = 0, 1
+PRELAUNCH_AUTO, PRELAUNCH_OFF, PRELAUNCH_ONE_STREAM = 0, 1, 2
 PRESET_DEFAULT, PRESET_PCLOMP_RECALLED, PRESET_SVN = 0, 1, 2
 
 STATUS = {0: "NDT_OK", -1: "NDT_ERR_INVALID_ARG", -2: "NDT_ERR_NO_DEVICE", -3: "NDT_ERR_HIP",

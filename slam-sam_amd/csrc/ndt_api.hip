@@ -236,7 +236,10 @@ bool params_valid(const ndt_params* p, std::string* why) {
   }
   if (p->wait_mode != NDT_WAIT_SPIN && p->wait_mode != NDT_WAIT_BLOCK) { *why = "unknown wait_mode"; return false; }
   if (p->source_order < NDT_SOURCE_ORDER_AUTO || p->source_order > NDT_SOURCE_ORDER_SORT) { *why = "unknown source_order"; return false; }
-  if (p->prelaunch != NDT_PRELAUNCH_AUTO && p->prelaunch != NDT_PRELAUNCH_OFF) { *why = "unknown prelaunch"; return false; }
+  if (p->prelaunch != NDT_PRELAUNCH_AUTO && p->prelaunch != NDT_PRELAUNCH_OFF && p->prelaunch != NDT_PRELAUNCH_ONE_STREAM) {
+    *why = "unknown prelaunch";
+    return false;
+  }
   if (!(p->outlier_ratio >= 0.0 && p->outlier_ratio < 1.0)) { *why = "outlier_ratio must be in [0,1)"; return false; }
   if (p->max_iterations < 0) { *why = "max_iterations must be >= 0"; return false; }
   return true;
@@ -746,7 +749,7 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
   const float* py = h->src_sorted ? h->oy.p : h->vy;
   const float* pz = h->src_sorted ? h->oz.p : h->vz;
   const bool prelaunch = spin && !score_only && h->prelaunch_armed && !h->prelaunch_suspended &&
-                         h->prm.prelaunch == NDT_PRELAUNCH_AUTO && ensure_mailbox(h);
+                         h->prm.prelaunch != NDT_PRELAUNCH_OFF && ensure_mailbox(h);
   unsigned long long seq = 0;
   bool via_mailbox = false;
   // NDT_REDUCE_P2P: the kernel's final sum exchanges the evaluation with the other ranks itself, under
@@ -827,7 +830,7 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
     // starting.  The next kernel is not needed for another ~10 us, so the host can afford to watch the arrival
     // word for a few microseconds before it decides.)
     bool in_flight_resident = false;
-    if (h->two_streams && via_mailbox) {
+    if (h->two_streams && h->prm.prelaunch == NDT_PRELAUNCH_AUTO && via_mailbox) {
       const auto t_arr = std::chrono::steady_clock::now();
       for (unsigned spins = 0;; ++spins) {
         if (__atomic_load_n(&h->arrived.h[buf], __ATOMIC_ACQUIRE) == seq) { in_flight_resident = true; break; }

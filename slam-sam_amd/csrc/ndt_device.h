@@ -45,6 +45,8 @@ struct BuildGeom {
 // loads.  mean + upper triangle of the inverse covariance in f64 -- the
 // reference keeps both in f64 and forms the Mahalanobis distance in f64
 // (ref: svn_ndt_impl.hpp:418, voxel_grid_covariance.h:125-128).
+// (Padding a record to one 128-byte line was measured in round 3, when the two-launch build stopped handing out leaf
+// slots in cell order: no gain, profiles/r03_step_ab_record_order.txt.)
 struct alignas(16) VoxelRecord {
   double mean[3];
   double icov[6];  // xx, xy, xz, yy, yz, zz

@@ -14,7 +14,10 @@ L = pkg.lib()
 L.ndt_debug_read_stamps.argtypes = [C.c_void_p, C.c_int]
 n = len(cfg["source"])
 bt = int(os.environ.get("NDT_DERIV_BLOCK", "0")) or ((((n + 255) // 256 + 63) // 64) * 64 if 131072 < n <= 262144 else 512)
-nb = (n + bt - 1) // bt
+ded = 0 if os.environ.get("NDT_DERIV_DEDICATED") == "0" else 1   # block 0 owns no points: it only adds the rows
+if not int(os.environ.get("NDT_DERIV_BLOCK", "0")) and 131072 < n <= 262144:
+    bt = (((n + 254) // 255 + 63) // 64) * 64                      # one compute unit is left to the summing block
+nb = (n + bt - 1) // bt + ded
 for rep in range(4):
     ndt.align(cfg["guess"])
     raw = np.zeros(nb * 11, np.uint64)
@@ -23,10 +26,11 @@ for rep in range(4):
     ms = raw[nb * 9:].reshape(nb, 2).astype(np.int64)
     seen0 = ms[:, 1].min()
     rel = (t - seen0) * 0.01
+    comp = slice(ded, nb)   # the blocks that own points
     print("align %d: blocks %d, counters %s overlapped %d" % (rep, nb, ndt.prelaunchCounters(), ndt.prelaunchOverlapped()))
     print("  waited for the pose (entry -> seen): min %.2f median %.2f max %.2f us" % tuple(np.percentile((ms[:, 1] - ms[:, 0]) * 0.01, [0, 50, 100])))
     print("  pose seen, spread over blocks: median %.2f max %.2f us after the first" % tuple(np.percentile((ms[:, 1] - seen0) * 0.01, [50, 100])))
     names = ["(entry)", "xyz loaded", "pairs done", "expanded", "row stored"]
     for k in range(1, 5):
-        print("  %-12s  min %6.2f  median %6.2f  max %6.2f   (us after the first block saw the pose)" % (names[k], rel[:, k].min(), np.median(rel[:, k]), rel[:, k].max()))
-    print("  block 0: rows summed %.2f  result stored %.2f" % (rel[0, 6], rel[0, 7]))
+        print("  %-12s  min %6.2f  median %6.2f  max %6.2f   (us after the first block saw the pose)" % (names[k], rel[comp, k].min(), np.median(rel[comp, k]), rel[comp, k].max()))
+    print("  block 0 (%s): polling since %.2f, rows summed %.2f, result stored %.2f" % ("summing only" if ded else "computes too", rel[0, 5], rel[0, 6], rel[0, 7]))

@@ -22,8 +22,9 @@ def _worker(rank, world, name, out_dir, mode="shm"):
     board = pkg.ranks.Board("/dev/shm" + name + "_board", rank, world, timeout=120) if mode == "p2p" else None
     S = pkg.synth
     cfg = S.config_c2()
+    # (two engines on ONE device: pre-launched kernels stay on each engine's own stream, include/ndt_hip.h)
     ndt = pkg.NormalDistributionsTransform(device_id=0, resolution=1.0, step_size=0.1, trans_epsilon=1e-4,
-                                           max_iterations=35)
+                                           max_iterations=35, prelaunch=pkg.PRELAUNCH_ONE_STREAM)
     ndt.setInputTarget(cfg["target"])
     b, c = pkg.shard_range(len(cfg["source"]), rank, world)
     ndt.setInputSource(cfg["source"][b:b + c])
