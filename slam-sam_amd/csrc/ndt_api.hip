@@ -54,6 +54,24 @@ struct DevBuf {
   }
 };
 
+// The dense cell -> leaf index with four readable ints in front of the first cell and behind the last: the 27-cell
+// neighbourhoods load a row of three x-adjacent cells with ONE 12-byte load, which at the ends of the grid starts one
+// or two ints outside it (those lanes are masked, the bytes only have to be mapped).  Same member names as DevBuf.
+struct IndexGrid {
+  DevBuf<int> raw;
+  int* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t n) {
+    if (n <= cap) return hipSuccess;
+    p = nullptr;
+    cap = 0;
+    hipError_t e = raw.ensure(n + 8);
+    if (e == hipSuccess) { p = raw.p + 4; cap = raw.cap - 8; }
+    return e;
+  }
+  void release() { raw.release(); p = nullptr; cap = 0; }
+};
+
 template <typename T>
 struct PinBuf {  // pinned, device-mapped host memory
   T* h = nullptr;
@@ -115,8 +133,9 @@ struct ndt_handle {
   DevBuf<BuildGeom> gd;              // geometry + sort plan of the build, derived on the device
   PinBuf<BuildGeom> gdh;             // ... and its host-visible copy
   DevBuf<float> xyz4;                // packed float4 copy of the target for the gather
-  DevBuf<int> cell2leaf;
+  IndexGrid cell2leaf;
   DevBuf<VoxelRecord> rec;
+  DevBuf<float> cent;                // 4 floats per leaf slot: f32 centroid (what the radius search tests) + chain link
   DevBuf<LeafStats> stats;
   int n_slots = 0, n_valid = 0;
   // The dense index grid is filled with -1 once per allocation; afterwards only the cells the
@@ -368,6 +387,7 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
   HIP_TRY(h, h->leaf_start.ensure((size_t)max_leaves));
   HIP_TRY(h, h->leaf_cnt.ensure((size_t)max_leaves));
   HIP_TRY(h, h->rec.ensure((size_t)max_leaves));
+  HIP_TRY(h, h->cent.ensure((size_t)max_leaves * 4));
   HIP_TRY(h, h->leaf_sums.ensure((size_t)max_leaves * 9));
   HIP_TRY(h, h->run_counts.ensure((size_t)runs_blocks(n)));
   HIP_TRY(h, h->run_offsets.ensure((size_t)runs_blocks(n)));
@@ -414,7 +434,7 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
       HIP_TRY(h, launch_bucket_build(x, y, z, n, leaf, inv_leaf, cap_cells, min_pts, fpb, h->gd.p, h->gdh.d, h->sort_tags.p,
                                      &h->sort_seq, h->stats.p, dirty_slots, h->cell2leaf.p, h->cell2leaf.cap, h->brows.p,
                                      h->bucket_off.p, h->nleaf.p, h->tickets.p + 2, h->xyz4.p, h->leaf_sums.p, h->rec.p,
-                                     h->stats.p, max_leaves, h->small.d + 8, done_tag, s));
+                                     h->cent.p, h->stats.p, max_leaves, h->small.d + 8, done_tag, s));
     } else {
     launch_bounds_geometry(x, y, z, n, leaf, inv_leaf, cap_cells, passes, h->brows.p, h->tickets.p, h->gd.p, h->gdh.d,
                            optimistic ? h->stats.p : nullptr, optimistic ? dirty_slots : 0, h->cell2leaf.p,
@@ -445,7 +465,7 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
                                 h->leaf_start.p, h->leaf_cnt.p, s));
     FinalizeParams fp{h->prm.eig_inflation_ratio, h->prm.cov_mode};
     launch_finalize_leaves(h->xyz4.p, keys_sorted, vals_sorted, h->nleaf.p, h->leaf_start.p, h->leaf_cnt.p, max_leaves,
-                           fp, h->leaf_sums.p, h->rec.p, h->stats.p, h->cell2leaf.p, h->fin_counts.p, h->tickets.p + 2,
+                           fp, h->leaf_sums.p, h->rec.p, h->cent.p, h->stats.p, h->cell2leaf.p, h->fin_counts.p, h->tickets.p + 2,
                            h->small.d + 8, done_tag, s);
     }  // (sort-based pipeline)
     HIP_TRY(h, hipGetLastError());
@@ -799,7 +819,7 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
     buf = (h->flag_toggle ^= 1);
     h->cur_on2 = 0;
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, s));
-    launch_derivatives(px, py, pz, h->n_src, h->geom, h->cell2leaf.p, h->rec.p, pc, nullptr, 1, ec, h->partials.p,
+    launch_derivatives(px, py, pz, h->n_src, h->geom, h->cell2leaf.p, h->rec.p, h->cent.p, pc, nullptr, 1, ec, h->partials.p,
                        h->counters.p, d_out, s, spin ? h->flag.d + (size_t)buf * 2 * EV_WORDS : nullptr, seq, nullptr,
                        xinfo, xround);
     HIP_TRY(h, hipGetLastError());
@@ -840,7 +860,7 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
     }
     h->pre_on2 = in_flight_resident ? (h->cur_on2 ^ 1) : h->cur_on2;
     if (in_flight_resident) h->n_prelaunch_overlapped++;
-    launch_derivatives(px, py, pz, h->n_src, h->geom, h->cell2leaf.p, h->rec.p, pc, nullptr, 1, ec, h->partials.p,
+    launch_derivatives(px, py, pz, h->n_src, h->geom, h->cell2leaf.p, h->rec.p, h->cent.p, pc, nullptr, 1, ec, h->partials.p,
                        h->counters.p, d_out, h->pre_on2 ? h->stream2 : s, h->flag.d + (size_t)h->pre_buf * 2 * EV_WORDS,
                        h->pre_seq, h->mbox, xinfo, h->pre_round, h->arrive_ctr.p + h->pre_buf, h->arrived.d + h->pre_buf);
     HIP_TRY(h, hipGetLastError());
@@ -1041,7 +1061,7 @@ int ndt_destroy(ndt_handle* h) {
   h->tx.release(); h->ty.release(); h->tz.release();
   h->keys.release(); h->vals.release(); h->keys2.release(); h->vals2.release();
   h->sort_tmp.release(); h->nleaf.release(); h->leaf_start.release(); h->leaf_cnt.release();
-  h->cell2leaf.release(); h->rec.release(); h->stats.release();
+  h->cell2leaf.release(); h->rec.release(); h->cent.release(); h->stats.release();
   h->run_counts.release(); h->run_offsets.release(); h->fin_counts.release(); h->bucket_off.release(); h->upl_tmp.release(); h->sort_tags.release(); h->run_tags.release(); h->xyz4.release(); h->leaf_sums.release();
   h->brows.release(); h->tickets.release(); h->gd.release(); h->gdh.release();
   for (auto& kv : h->keyframes) { kv.second.x.release(); kv.second.y.release(); kv.second.z.release(); }
@@ -1325,6 +1345,17 @@ int ndt_multigrid_create_kdtree(ndt_handle* h) {
   h->grid_dirty_slots = 0;
   HIP_TRY(h, h->rec.ensure(total));
   HIP_TRY(h, hipMemcpyAsync(h->rec.p, rec.data(), total * sizeof(VoxelRecord), hipMemcpyHostToDevice, s));
+  // f32 centroids + the chain link of every leaf (the slot of the next leaf in the same cell, -1: none), as bits
+  std::vector<float> cent(4 * total);
+  for (size_t k = 0; k < total; ++k) {
+    cent[4 * k + 0] = (float)rec[k].mean[0];
+    cent[4 * k + 1] = (float)rec[k].mean[1];
+    cent[4 * k + 2] = (float)rec[k].mean[2];
+    const int link = (int)rec[k].pad;
+    std::memcpy(&cent[4 * k + 3], &link, sizeof(int));
+  }
+  HIP_TRY(h, h->cent.ensure(4 * total));
+  HIP_TRY(h, hipMemcpyAsync(h->cent.p, cent.data(), cent.size() * sizeof(float), hipMemcpyHostToDevice, s));
   DevBuf<int> dc, ds;
   HIP_TRY(h, dc.ensure(head_cells.size()));
   HIP_TRY(h, ds.ensure(head_cells.size()));
@@ -1534,7 +1565,7 @@ static int eval_batch(ndt_handle* h, const double* poses6, const float* transfor
   const unsigned long long seq = g_launch_seq.fetch_add(1, std::memory_order_relaxed);
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, s));
   launch_derivatives(h->src_sorted ? h->ox.p : h->vx, h->src_sorted ? h->oy.p : h->vy,
-                     h->src_sorted ? h->oz.p : h->vz, h->n_src, h->geom, h->cell2leaf.p, h->rec.p,
+                     h->src_sorted ? h->oz.p : h->vz, h->n_src, h->geom, h->cell2leaf.p, h->rec.p, h->cent.p,
                      h->hposes.h[0], fast ? h->bposes : h->dposes.p, K, ec, h->partials.p, h->counters.p, h->dres.p, s,
                      fast ? h->flag.d : nullptr, seq);
   HIP_TRY(h, hipGetLastError());

@@ -333,8 +333,9 @@ constexpr int KD_CELLS = 27;
 template <int MODE, bool RADIUS, bool CHAIN>
 __device__ __forceinline__ void point_pairs_kd(PairAcc& a, float x, float y, float z, const GridGeom& g,
                                                const int* __restrict__ cell2leaf,
-                                               const VoxelRecord* __restrict__ rec, const RigidRT& P,
-                                               const EvalConsts& ec, int* __restrict__ lds_list, bool active) {
+                                               const VoxelRecord* __restrict__ rec, const float4* __restrict__ cent,
+                                               const RigidRT& P, const EvalConsts& ec, int* __restrict__ lds_list,
+                                               bool active) {
   a.w[0] = a.w[1] = a.w[2] = 0.0;
 #pragma unroll
   for (int k = 0; k < 6; ++k) a.S[k] = 0.0;
@@ -348,12 +349,25 @@ __device__ __forceinline__ void point_pairs_kd(PairAcc& a, float x, float y, flo
   const int i0 = finite ? (int)(floorf(xt * g.inv_leaf) - (float)g.min_b[0]) : -4;
   const int i1 = finite ? (int)(floorf(yt * g.inv_leaf) - (float)g.min_b[1]) : -4;
   const int i2 = finite ? (int)(floorf(zt * g.inv_leaf) - (float)g.min_b[2]) : -4;
+  // The 27 cells are nine rows of three x-adjacent cells: ONE 12-byte load per row (nine loads in flight instead of
+  // 27; round 3).  At the ends of the grid a row starts one or two ints outside it -- the index grid is readable four
+  // ints beyond either end (IndexGrid, ndt_api.hip) and those lanes are masked.  Cell n = (dx+1) + 3 (dy+1) + 9 (dz+1),
+  // as before: the listing order, hence the summation order, is unchanged.
   int slot[KD_CELLS];
+  {
+    const bool xin0 = i0 - 1 >= 0 && i0 - 1 < g.div_b[0], xin1 = i0 >= 0 && i0 < g.div_b[0], xin2 = i0 + 1 >= 0 && i0 + 1 < g.div_b[0];
+    const bool xany = xin0 || xin1 || xin2;
+    struct alignas(4) Int3 { int a, b, c; };
 #pragma unroll
-  for (int n = 0; n < KD_CELLS; ++n) {  // all 27 index loads in flight
-    const int c0 = i0 + (n % 3) - 1, c1 = i1 + ((n / 3) % 3) - 1, c2 = i2 + (n / 9) - 1;
-    const bool ok = c0 >= 0 && c0 < g.div_b[0] && c1 >= 0 && c1 < g.div_b[1] && c2 >= 0 && c2 < g.div_b[2];
-    slot[n] = ok ? cell2leaf[c0 + c1 * g.mul1 + c2 * g.mul2] : -1;
+    for (int r = 0; r < 9; ++r) {
+      const int c1 = i1 + (r % 3) - 1, c2 = i2 + (r / 3) - 1;
+      const bool rowok = xany && c1 >= 0 && c1 < g.div_b[1] && c2 >= 0 && c2 < g.div_b[2];
+      const int base = rowok ? (i0 - 1) + c1 * g.mul1 + c2 * g.mul2 : 0;
+      const Int3 v = *reinterpret_cast<const Int3*>(cell2leaf + base);
+      slot[3 * r + 0] = (rowok && xin0) ? v.a : -1;
+      slot[3 * r + 1] = (rowok && xin1) ? v.b : -1;
+      slot[3 * r + 2] = (rowok && xin2) ? v.c : -1;
+    }
   }
   // column `threadIdx.x` of lds_list[KD_CELLS][blockDim.x]: conflict-free for a wave
   const int stride = (int)blockDim.x;
@@ -367,19 +381,16 @@ __device__ __forceinline__ void point_pairs_kd(PairAcc& a, float x, float y, flo
     bool overflow = false;
 #pragma unroll
     for (int n0 = 0; n0 < KD_CELLS; n0 += 9) {
-      double m[9][3], nxt[9];
+      float4 m[9];   // f32 centroid + chain link: 16 bytes per leaf instead of 32 of its 80-byte record
 #pragma unroll
-      for (int q = 0; q < 9; ++q) {
-        const VoxelRecord* rp = rec + (slot[n0 + q] >= 0 ? slot[n0 + q] : 0);
-        m[q][0] = rp->mean[0]; m[q][1] = rp->mean[1]; m[q][2] = rp->mean[2]; nxt[q] = rp->pad;
-      }
+      for (int q = 0; q < 9; ++q) m[q] = cent[slot[n0 + q] >= 0 ? slot[n0 + q] : 0];
 #pragma unroll
       for (int q = 0; q < 9; ++q) {
         if (slot[n0 + q] < 0) continue;
         int sl = slot[n0 + q];
-        double m0 = m[q][0], m1 = m[q][1], m2 = m[q][2], nx = nxt[q];
+        float4 c = m[q];
         for (;;) {
-          const float ex = xt - (float)m0, ey = yt - (float)m1, ez = zt - (float)m2;
+          const float ex = xt - c.x, ey = yt - c.y, ez = zt - c.z;
           float d = ex * ex;
           d = d + ey * ey;
           d = d + ez * ez;
@@ -387,10 +398,9 @@ __device__ __forceinline__ void point_pairs_kd(PairAcc& a, float x, float y, flo
             if (count < KD_CELLS) { lds_list[count * stride + (int)threadIdx.x] = sl; ++count; }
             else overflow = true;
           }
-          sl = (int)nx;
+          sl = __float_as_int(c.w);
           if (sl < 0) break;
-          const VoxelRecord* rp = rec + sl;
-          m0 = rp->mean[0]; m1 = rp->mean[1]; m2 = rp->mean[2]; nx = rp->pad;
+          c = cent[sl];
         }
       }
     }
@@ -406,15 +416,12 @@ __device__ __forceinline__ void point_pairs_kd(PairAcc& a, float x, float y, flo
     // 7 instead of 15 on C3.  Same f32 test on the same operands, same (cell) order: the same pairs.
 #pragma unroll
     for (int n0 = 0; n0 < KD_CELLS; n0 += 9) {
-      double m[9][3];
+      float4 m[9];   // the f32 centroids (one 16-byte load per cell; two loads of the record's f64 mean before round 3)
+#pragma unroll
+      for (int q = 0; q < 9; ++q) m[q] = cent[slot[n0 + q] >= 0 ? slot[n0 + q] : 0];
 #pragma unroll
       for (int q = 0; q < 9; ++q) {
-        const VoxelRecord* rp = rec + (slot[n0 + q] >= 0 ? slot[n0 + q] : 0);
-        m[q][0] = rp->mean[0]; m[q][1] = rp->mean[1]; m[q][2] = rp->mean[2];
-      }
-#pragma unroll
-      for (int q = 0; q < 9; ++q) {
-        const float ex = xt - (float)m[q][0], ey = yt - (float)m[q][1], ez = zt - (float)m[q][2];
+        const float ex = xt - m[q].x, ey = yt - m[q].y, ez = zt - m[q].z;
         float d = ex * ex;
         d = d + ey * ey;
         d = d + ez * ez;
@@ -779,6 +786,7 @@ struct DerivKernArgs {
   GridGeom g;
   const int* cell2leaf;
   const VoxelRecord* rec;
+  const float4* cent;
   PoseConsts pose;
   const PoseConsts* poses;
   EvalConsts ec;
@@ -804,7 +812,7 @@ template <bool BATCH, int MODE, int NB, bool MBOX>
 __global__ void __launch_bounds__(MAX_BLOCK)
 k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, int n,
               GridGeom g, const int* __restrict__ cell2leaf, const VoxelRecord* __restrict__ rec,
-              PoseConsts pose_arg, const PoseConsts* __restrict__ poses, EvalConsts ec,
+              const float4* __restrict__ cent, PoseConsts pose_arg, const PoseConsts* __restrict__ poses, EvalConsts ec,
               double* __restrict__ partials, unsigned int* __restrict__ counters, double* __restrict__ out,
               unsigned long long* flag, unsigned long long seq, const PoseMailbox* mbox,
               const XchgInfo* __restrict__ xinfo, unsigned long long xround,
@@ -957,7 +965,7 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
     extern __shared__ int lds_kd_list[];  // KD_CELLS x blockDim.x leaf indices
     if (!(MBOX && ec.mbox_preload) && i < n) { x = sx[i]; y = sy[i]; z = sz[i]; }
     NDT_STAMP(1);
-    point_pairs_kd<MODE, NB == 2 || NB == 4, NB == 4>(a, x, y, z, g, cell2leaf, rec, rt, ec, lds_kd_list, i < n);
+    point_pairs_kd<MODE, NB == 2 || NB == 4, NB == 4>(a, x, y, z, g, cell2leaf, rec, cent, rt, ec, lds_kd_list, i < n);
   } else if (i < n) {
     if (!(MBOX && ec.mbox_preload)) { x = sx[i]; y = sy[i]; z = sz[i]; }
     NDT_STAMP(1);
@@ -1090,7 +1098,7 @@ static int derivs_dedicated_summer(size_t n_src, int K) {
 int derivs_grid_blocks(size_t n_src, int K) { return derivs_point_blocks(n_src, K) + derivs_dedicated_summer(n_src, K); }
 
 void launch_derivatives(const float* sx, const float* sy, const float* sz, size_t n_src,
-                        const GridGeom& g, const int* cell2leaf, const VoxelRecord* rec,
+                        const GridGeom& g, const int* cell2leaf, const VoxelRecord* rec, const float* cent4,
                         const PoseConsts& pose, const PoseConsts* d_poses, int K,
                         const EvalConsts& ec, double* d_partials, unsigned int* d_counters,
                         double* d_out, hipStream_t s, unsigned long long* d_flag,
@@ -1107,7 +1115,7 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
   const size_t dyn_lds = nb >= 2 ? (size_t)KD_CELLS * threads * sizeof(int) : 0;
 #define NDT_LAUNCH2(B, M, NBH, MB, GY, FLAG, SEQ)                                                            \
   hipLaunchKernelGGL((k_derivatives<B, M, NBH, MB>), dim3(blocks, GY), dim3(threads), dyn_lds, s, sx, sy, sz,  \
-                     (int)n_src, g, cell2leaf, rec, pose, d_poses, ecl, d_partials, d_counters, d_out,         \
+                     (int)n_src, g, cell2leaf, rec, reinterpret_cast<const float4*>(cent4), pose, d_poses, ecl, d_partials, d_counters, d_out,         \
                      FLAG, SEQ, d_mbox, d_xinfo, xround, d_arrive_ctr, d_arrived_host)
 #define NDT_LAUNCH(B, M, NBH, GY, FLAG, SEQ)                                  \
   do {                                                                         \

@@ -64,8 +64,8 @@ hipError_t launch_bucket_build(const float* x, const float* y, const float* z, s
                                long long cell_capacity, int min_pts, FinalizeParams fp, BuildGeom* gd, BuildGeom* gd_host,
                                uint32_t* table, uint32_t* seq, const LeafStats* old_stats, int dirty_slots, int* cell2leaf,
                                size_t c2l_cap, int* rows, int* bucket_off, int* d_nleaf, unsigned int* ticket, float* pts4,
-                               double* sums, VoxelRecord* rec, LeafStats* stats, int max_leaves, int* nleaf_host,
-                               int done_tag, hipStream_t s);
+                               double* sums, VoxelRecord* rec, float* cent4 /* 4 floats per leaf slot: f32 centroid + chain link */,
+                               LeafStats* stats, int max_leaves, int* nleaf_host, int done_tag, hipStream_t s);
 
 // runs of equal cell key with >= min_pts points get a leaf slot (ascending cell order);
 // block_counts / block_offsets: runs_blocks(n) ints each; d_nleaf[0] receives the total
@@ -87,8 +87,9 @@ int build_read_stamps(unsigned long long* out /* 4 x 512 x 8 */);  // -DNDT_STAM
 // per-leaf sums, then per-leaf statistics; sums: 9 doubles per leaf slot (scratch)
 void launch_finalize_leaves(const float* xyz4, const uint32_t* keys_sorted, const uint32_t* vals_sorted,
                             int* d_nleaf /* [0]=slots, [1]=valid */, const int* leaf_start, const int* leaf_cnt,
-                            int max_leaves, FinalizeParams fp, double* sums, VoxelRecord* rec, LeafStats* stats,
-                            int* cell2leaf, int* block_ok /* finalize_blocks(max_leaves) ints, scratch */,
+                            int max_leaves, FinalizeParams fp, double* sums, VoxelRecord* rec,
+                            float* cent4 /* 4 floats per leaf slot: the f32 centroid the radius search tests + chain link */,
+                            LeafStats* stats, int* cell2leaf, int* block_ok /* finalize_blocks(max_leaves) ints, scratch */,
                             unsigned int* ticket /* zero, left at zero */,
                             int* nleaf_host /* pinned, 16-byte aligned: receives {d_nleaf[0], d_nleaf[1], done_tag, 0} in one store */,
                             int done_tag, hipStream_t s);
@@ -129,7 +130,8 @@ int derivs_read_stamps(unsigned long long* out, int nblocks);  // diagnostic bui
 // d_mbox != nullptr (single-pose only): a PRE-LAUNCHED evaluation -- `pose` is ignored, the kernel
 // waits for the pose to appear in *d_mbox under its sequence number (PoseMailbox in ndt_device.h).
 void launch_derivatives(const float* sx, const float* sy, const float* sz, size_t n_src,
-                        const GridGeom& g, const int* cell2leaf, const VoxelRecord* rec,
+                        const GridGeom& g, const int* cell2leaf /* readable 4 ints beyond either end */,
+                        const VoxelRecord* rec, const float* cent4 /* per-leaf f32 centroid + chain link (KDTREE, multi-grid) */,
                         const PoseConsts& pose, const PoseConsts* d_poses, int K,
                         const EvalConsts& ec, double* d_partials, unsigned int* d_counters,
                         double* d_out, hipStream_t s, unsigned long long* d_host_slots,

@@ -1020,11 +1020,11 @@ __device__ __forceinline__ void moments_xor_tree(Moments& m) {
 __device__ __forceinline__ bool finalize_one(int slot, const uint32_t* __restrict__ keys,
                                              const int* __restrict__ leaf_start, const int* __restrict__ leaf_cnt,
                                              const double* __restrict__ sums, FinalizeParams fp,
-                                             VoxelRecord* __restrict__ rec, LeafStats* __restrict__ stats,
-                                             int* __restrict__ cell2leaf);
+                                             VoxelRecord* __restrict__ rec, float4* __restrict__ cent,
+                                             LeafStats* __restrict__ stats, int* __restrict__ cell2leaf);
 __device__ __forceinline__ bool finalize_leaf(int slot, int cell, int cnt, const double* __restrict__ in, FinalizeParams fp,
-                                              VoxelRecord* __restrict__ rec, LeafStats* __restrict__ stats,
-                                              int* __restrict__ cell2leaf);
+                                              VoxelRecord* __restrict__ rec, float4* __restrict__ cent,
+                                              LeafStats* __restrict__ stats, int* __restrict__ cell2leaf);
 
 // ref: voxel_grid_covariance_impl.hpp:265-343 -- one thread per leaf: mean, covariance,
 // eigen-decomposition, eigenvalue inflation, inverse, validity checks.  (Fusing this into the
@@ -1041,7 +1041,7 @@ __global__ void __launch_bounds__(THREADS) k_leaf_finalize(const uint32_t* __res
                                                            const int* __restrict__ leaf_start,
                                                            const int* __restrict__ leaf_cnt,
                                                            const double* __restrict__ sums, FinalizeParams fp,
-                                                           VoxelRecord* __restrict__ rec,
+                                                           VoxelRecord* __restrict__ rec, float4* __restrict__ cent,
                                                            LeafStats* __restrict__ stats,
                                                            int* __restrict__ cell2leaf, int* __restrict__ block_ok,
                                                            unsigned int* __restrict__ ticket,
@@ -1056,7 +1056,7 @@ __global__ void __launch_bounds__(THREADS) k_leaf_finalize(const uint32_t* __res
   const int live_blocks = max(1, (nl + THREADS - 1) / THREADS);
   if ((int)blockIdx.x >= live_blocks) return;
   bool ok = false;
-  if (slot < nl) ok = finalize_one(slot, keys, leaf_start, leaf_cnt, sums, fp, rec, stats, cell2leaf);
+  if (slot < nl) ok = finalize_one(slot, keys, leaf_start, leaf_cnt, sums, fp, rec, cent, stats, cell2leaf);
   const int wave_ok = __popcll(__ballot(ok));
   if ((threadIdx.x & 63) == 0) s_ok[threadIdx.x >> 6] = wave_ok;
   __syncthreads();
@@ -1090,16 +1090,16 @@ __global__ void __launch_bounds__(THREADS) k_leaf_finalize(const uint32_t* __res
 __device__ __forceinline__ bool finalize_one(int slot, const uint32_t* __restrict__ keys,
                                              const int* __restrict__ leaf_start, const int* __restrict__ leaf_cnt,
                                              const double* __restrict__ sums, FinalizeParams fp,
-                                             VoxelRecord* __restrict__ rec, LeafStats* __restrict__ stats,
-                                             int* __restrict__ cell2leaf) {
+                                             VoxelRecord* __restrict__ rec, float4* __restrict__ cent,
+                                             LeafStats* __restrict__ stats, int* __restrict__ cell2leaf) {
   const int start = leaf_start[slot], cnt = leaf_cnt[slot];
-  return finalize_leaf(slot, (int)keys[start], cnt, sums + (size_t)slot * 9, fp, rec, stats, cell2leaf);
+  return finalize_leaf(slot, (int)keys[start], cnt, sums + (size_t)slot * 9, fp, rec, cent, stats, cell2leaf);
 }
 
 // one leaf: count, cell, and its nine moment sums -> statistics, record, dense index entry
 __device__ __forceinline__ bool finalize_leaf(int slot, int cell, int cnt, const double* __restrict__ in, FinalizeParams fp,
-                                              VoxelRecord* __restrict__ rec, LeafStats* __restrict__ stats,
-                                              int* __restrict__ cell2leaf) {
+                                              VoxelRecord* __restrict__ rec, float4* __restrict__ cent,
+                                              LeafStats* __restrict__ stats, int* __restrict__ cell2leaf) {
   const double s[3] = {in[0], in[1], in[2]};
   const double ss[6] = {in[3], in[4], in[5], in[6], in[7], in[8]};
   const double n = (double)cnt;
@@ -1202,6 +1202,10 @@ __device__ __forceinline__ bool finalize_leaf(int slot, int cell, int cnt, const
   r.icov[3] = ok ? I[4] : 0.0; r.icov[4] = ok ? I[5] : 0.0; r.icov[5] = ok ? I[8] : 0.0;
   r.pad = (double)cnt;
   rec[slot] = r;
+  // the centroid as the radius search sees it (f32-rounded leaf mean, ref: voxel_grid_covariance_impl.hpp:420-422),
+  // 16 bytes per leaf: the KDTREE / multi-grid neighbourhoods test 27 cells per point against it; w = "no further leaf
+  // in this cell" (the multi-grid union chains leaves through it)
+  cent[slot] = make_float4((float)r.mean[0], (float)r.mean[1], (float)r.mean[2], __int_as_float(-1));
   if (ok) cell2leaf[cell] = slot;
   return ok;
 }
@@ -1637,7 +1641,8 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __re
                                                              FinalizeParams fp, BuildGeom* __restrict__ gd,
                                                              BuildGeom* __restrict__ gd_host, int* __restrict__ d_nleaf,
                                                              unsigned int* __restrict__ ticket, double* __restrict__ sums,
-                                                             VoxelRecord* __restrict__ rec, LeafStats* __restrict__ stats,
+                                                             VoxelRecord* __restrict__ rec, float4* __restrict__ cent,
+                                                             LeafStats* __restrict__ stats,
                                                              int* __restrict__ cell2leaf, int max_leaves,
                                                              int* __restrict__ nleaf_host, int done_tag) {
   __shared__ float px[BK_MAXP], py[BK_MAXP], pz[BK_MAXP];
@@ -2028,7 +2033,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __re
   int ok_here = 0;
   for (int li = threadIdx.x; li < nl; li += BK_THREADS) {
     const int slot = slot0 + li;
-    if (slot < max_leaves && finalize_leaf(slot, leaves[li].cell, (int)leaves[li].cnt, sums + (size_t)slot * 9, fp, rec, stats, cell2leaf))
+    if (slot < max_leaves && finalize_leaf(slot, leaves[li].cell, (int)leaves[li].cnt, sums + (size_t)slot * 9, fp, rec, cent, stats, cell2leaf))
       ++ok_here;
   }
   const int wave_ok = __popcll(__ballot(ok_here == 1)) + 2 * __popcll(__ballot(ok_here == 2)) + 3 * __popcll(__ballot(ok_here >= 3));
@@ -2463,7 +2468,7 @@ hipError_t launch_bucket_build(const float* x, const float* y, const float* z, s
                                long long cell_capacity, int min_pts, FinalizeParams fp, BuildGeom* gd, BuildGeom* gd_host,
                                uint32_t* table, uint32_t* seq, const LeafStats* old_stats, int dirty_slots, int* cell2leaf,
                                size_t c2l_cap, int* rows, int* bucket_off, int* d_nleaf, unsigned int* ticket, float* pts4,
-                               double* sums, VoxelRecord* rec, LeafStats* stats, int max_leaves, int* nleaf_host,
+                               double* sums, VoxelRecord* rec, float* cent4, LeafStats* stats, int max_leaves, int* nleaf_host,
                                int done_tag, hipStream_t s) {
   if (n == 0) return hipErrorInvalidValue;
   uint32_t tag = (*seq + 1u) & 0xffffu;
@@ -2484,7 +2489,7 @@ hipError_t launch_bucket_build(const float* x, const float* y, const float* z, s
                      reinterpret_cast<float4*>(pts4));
   hipLaunchKernelGGL(k_bucket_leaves, dim3(BK_BUCKETS), dim3(BK_THREADS), 0, s, reinterpret_cast<const float4*>(pts4),
                      bucket_off, rows, ntiles, leaf, inv_leaf, cell_capacity, min_pts, fp, gd, gd_host, d_nleaf, ticket, sums,
-                     rec, stats, cell2leaf, max_leaves, nleaf_host, done_tag);
+                     rec, reinterpret_cast<float4*>(cent4), stats, cell2leaf, max_leaves, nleaf_host, done_tag);
   return hipGetLastError();
 }
 
@@ -2544,7 +2549,7 @@ int finalize_blocks(int max_leaves) { return (max_leaves + 63) / 64; }
 
 void launch_finalize_leaves(const float* xyz4, const uint32_t* keys_sorted, const uint32_t* vals_sorted,
                             int* d_nleaf, const int* leaf_start, const int* leaf_cnt, int max_leaves,
-                            FinalizeParams fp, double* sums, VoxelRecord* rec, LeafStats* stats, int* cell2leaf,
+                            FinalizeParams fp, double* sums, VoxelRecord* rec, float* cent4, LeafStats* stats, int* cell2leaf,
                             int* block_ok, unsigned int* ticket, int* nleaf_host, int done_tag, hipStream_t s) {
   if (max_leaves <= 0) return;
   size_t blocks = ((size_t)max_leaves * LANES_PER_LEAF + 255) / 256;
@@ -2553,10 +2558,10 @@ void launch_finalize_leaves(const float* xyz4, const uint32_t* keys_sorted, cons
                      vals_sorted, d_nleaf, leaf_start, leaf_cnt, sums);
   if (build_tuning().finalize_threads == 256)
     hipLaunchKernelGGL(k_leaf_finalize<256>, dim3((unsigned)((max_leaves + 255) / 256)), dim3(256), 0, s, keys_sorted,
-                       d_nleaf, leaf_start, leaf_cnt, sums, fp, rec, stats, cell2leaf, block_ok, ticket, nleaf_host, done_tag);
+                       d_nleaf, leaf_start, leaf_cnt, sums, fp, rec, reinterpret_cast<float4*>(cent4), stats, cell2leaf, block_ok, ticket, nleaf_host, done_tag);
   else
     hipLaunchKernelGGL(k_leaf_finalize<64>, dim3((unsigned)((max_leaves + 63) / 64)), dim3(64), 0, s, keys_sorted,
-                       d_nleaf, leaf_start, leaf_cnt, sums, fp, rec, stats, cell2leaf, block_ok, ticket, nleaf_host, done_tag);
+                       d_nleaf, leaf_start, leaf_cnt, sums, fp, rec, reinterpret_cast<float4*>(cent4), stats, cell2leaf, block_ok, ticket, nleaf_host, done_tag);
 }
 
 }  // namespace ndt
