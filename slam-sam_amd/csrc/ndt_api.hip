@@ -121,6 +121,7 @@ struct ndt_handle {
   uint32_t run_seq = 0;
   long long n_fused_sort_fallbacks = 0;
   DevBuf<int> bucket_off;             // first point of every bucket (two-launch bucketed build)
+  DevBuf<int> bnd;                    // its 8 bounds words {min xyz, max xyz, #finite, largest bucket}; neutral between builds
   long long n_bucket_builds = 0, n_bucket_fallbacks = 0;
   const float* vx = nullptr;          // the source as evaluated: the engine's own copy (sx/sy/sz) or,
   const float* vy = nullptr;          // after ndt_set_source_device_view, the caller's arrays
@@ -370,6 +371,16 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
   HIP_TRY(h, h->small.ensure(16));
   HIP_TRY(h, h->brows.ensure(8 * (size_t)std::max(nrows, bucket_build_tiles(n))));
   HIP_TRY(h, h->bucket_off.ensure(260));
+  auto neutral_bounds = [&]() -> hipError_t {   // (re)initialise the bounds words of the two-launch build
+    int w[8];
+    bucket_bounds_neutral(w);
+    hipError_t e = hipMemcpyAsync(h->bnd.p, w, sizeof(w), hipMemcpyHostToDevice, s);
+    return e == hipSuccess ? hipStreamSynchronize(s) : e;   // (w lives on this frame)
+  };
+  if (!h->bnd.p) {
+    HIP_TRY(h, h->bnd.ensure(8));
+    HIP_TRY(h, neutral_bounds());
+  }
   HIP_TRY(h, h->gd.ensure(1));
   HIP_TRY(h, h->gdh.ensure(1));
   if (!h->tickets.p) {
@@ -432,7 +443,7 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
       // bounds, partition, sort, sums and statistics in two launches (k_bucket_pass, k_bucket_leaves)
       FinalizeParams fpb{h->prm.eig_inflation_ratio, h->prm.cov_mode};
       HIP_TRY(h, launch_bucket_build(x, y, z, n, leaf, inv_leaf, cap_cells, min_pts, fpb, h->gd.p, h->gdh.d, h->sort_tags.p,
-                                     &h->sort_seq, h->stats.p, dirty_slots, h->cell2leaf.p, h->cell2leaf.cap, h->brows.p,
+                                     &h->sort_seq, h->stats.p, dirty_slots, h->cell2leaf.p, h->cell2leaf.cap, h->bnd.p,
                                      h->bucket_off.p, h->nleaf.p, h->tickets.p + 2, h->xyz4.p, h->leaf_sums.p, h->rec.p,
                                      h->cent.p, h->stats.p, max_leaves, h->small.d + 8, done_tag, s));
     } else {
@@ -506,6 +517,7 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
       dirty_slots = 0;
       if (bg.status == BG_BUCKET) clean_cap = 0;
       ++h->n_bucket_fallbacks;
+      HIP_TRY(h, neutral_bounds());   // (the launch pair resets them itself on every path; belt and braces)
       continue;
     }
     if (bucketed && bg.status == BG_OK) ++h->n_bucket_builds;
@@ -1062,7 +1074,7 @@ int ndt_destroy(ndt_handle* h) {
   h->keys.release(); h->vals.release(); h->keys2.release(); h->vals2.release();
   h->sort_tmp.release(); h->nleaf.release(); h->leaf_start.release(); h->leaf_cnt.release();
   h->cell2leaf.release(); h->rec.release(); h->cent.release(); h->stats.release();
-  h->run_counts.release(); h->run_offsets.release(); h->fin_counts.release(); h->bucket_off.release(); h->upl_tmp.release(); h->sort_tags.release(); h->run_tags.release(); h->xyz4.release(); h->leaf_sums.release();
+  h->run_counts.release(); h->run_offsets.release(); h->fin_counts.release(); h->bucket_off.release(); h->bnd.release(); h->upl_tmp.release(); h->sort_tags.release(); h->run_tags.release(); h->xyz4.release(); h->leaf_sums.release();
   h->brows.release(); h->tickets.release(); h->gd.release(); h->gdh.release();
   for (auto& kv : h->keyframes) { kv.second.x.release(); kv.second.y.release(); kv.second.z.release(); }
   h->keyframes.clear();

@@ -58,12 +58,16 @@ hipError_t sort_cloud_fused(const float* x, const float* y, const float* z, size
 // 8192 points; bucket_off: 257 ints; pts4: n float4 (the cloud partitioned by bucket); sums: 9 doubles per
 // leaf slot.  Refusals leave BG_BUCKET / BG_SPIN / BG_CAPACITY / ... in *gd_host with nothing written.
 bool bucket_build_enabled();                            // NDT_BUCKET_BUILD != 0 (default on)
+// the 8 bounds words {min xyz, max xyz, #finite, largest bucket} between two builds (host copy for (re)initialisation;
+// the launch pair leaves them neutral again whenever it runs to its end)
+void bucket_bounds_neutral(int out[8]);
 bool bucket_build_fits(size_t n, int compute_units);
 int bucket_build_tiles(size_t n);
 hipError_t launch_bucket_build(const float* x, const float* y, const float* z, size_t n, float leaf, float inv_leaf,
                                long long cell_capacity, int min_pts, FinalizeParams fp, BuildGeom* gd, BuildGeom* gd_host,
                                uint32_t* table, uint32_t* seq, const LeafStats* old_stats, int dirty_slots, int* cell2leaf,
-                               size_t c2l_cap, int* rows, int* bucket_off, int* d_nleaf, unsigned int* ticket, float* pts4,
+                               size_t c2l_cap, int* bnd /* 8 ints, see bucket_bounds_neutral */, int* bucket_off, int* d_nleaf,
+                               unsigned int* ticket, float* pts4,
                                double* sums, VoxelRecord* rec, float* cent4 /* 4 floats per leaf slot: f32 centroid + chain link */,
                                LeafStats* stats, int max_leaves, int* nleaf_host, int done_tag, hipStream_t s);
 

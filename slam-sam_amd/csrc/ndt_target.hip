@@ -1328,7 +1328,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_pass(const float* __restr
                                                            BuildGeom* __restrict__ gd, BuildGeom* __restrict__ gd_host,
                                                            const LeafStats* __restrict__ old_stats, int dirty_slots,
                                                            int* __restrict__ cell2leaf, size_t c2l_cap,
-                                                           int* __restrict__ rows, int* __restrict__ bucket_off,
+                                                           int* __restrict__ bnd, int* __restrict__ bucket_off,
                                                            int* __restrict__ d_nleaf, float4* __restrict__ pts_out) {
   constexpr int ROUNDS = BK_ROUNDS;
   constexpr int TILE = BK_THREADS * ROUNDS;
@@ -1341,7 +1341,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_pass(const float* __restr
   __shared__ int lbase[SORT_BINS];
   __shared__ int wsum[2 * SORT_BINS / 64];
   __shared__ int wrow[BK_WAVES][8];
-  __shared__ int s_fail;
+  __shared__ int s_fail, s_bmax;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tile = blockIdx.x;
   // the cells the PREVIOUS build published (the dense grid is filled with -1 once per allocation)
@@ -1374,8 +1374,8 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_pass(const float* __restr
     }
   }
   for (int d = threadIdx.x; d < BK_WAVES * SORT_BINS; d += BK_THREADS) (&cnt[0][0])[d] = 0;
-  if (threadIdx.x == 0) s_fail = 0;
-  // ref: pcl::getMinMax3D at voxel_grid_covariance_impl.hpp:103 -- this tile's row of the bounds
+  if (threadIdx.x == 0) { s_fail = 0; s_bmax = 0; }
+  // ref: pcl::getMinMax3D at voxel_grid_covariance_impl.hpp:103 -- this tile's share of the bounds
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
@@ -1398,7 +1398,13 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_pass(const float* __restr
       const int o = wrow[w][t];
       v = t < 3 ? min(v, o) : (t < 6 ? max(v, o) : v + o);
     }
-    rows[tile * 8 + t] = v;   // read by the NEXT launch
+    // Seven words for the whole cloud {min xyz, max xyz, #finite} (order-encoded ints), folded by integer atomics
+    // -- 7 per tile, spread over the launch: the next launch reads them with scalar loads and every wave derives the
+    // grid geometry in registers, where round 3's first version had every block fold 123 rows through LDS (5 us).
+    // Exact and order-free (min / max / integer add).  k_bucket_leaves' last block puts them back to neutral.
+    if (t < 3) atomicMin(&bnd[t], v);
+    else if (t < 6) atomicMax(&bnd[t], v);
+    else atomicAdd(&bnd[6], v);
   }
   NDT_BSTAMP(4, 1);  // points loaded, bounds row written
   // stable rank among the equal buckets before it in the wave's 512 points (8 ballots per round)
@@ -1491,6 +1497,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_pass(const float* __restr
     g_excl = incl - t + bsum;
     l_excl = lincl - my_count;
     b_total = incl - t;
+    if (tile == 0) atomicMax(&s_bmax, t);   // the largest bucket of the cloud (it must fit one block of the next launch)
   }
   __syncthreads();  // part_total / part_before are dead from here on: `stage` becomes the staging tile
   if (threadIdx.x < SORT_BINS) {
@@ -1501,6 +1508,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_pass(const float* __restr
     if (tile == 0) {  // first point of every bucket in the partitioned cloud, for the next launch
       bucket_off[threadIdx.x] = before + b_total;
       if (threadIdx.x == SORT_BINS - 1) bucket_off[SORT_BINS] = n;
+      if (threadIdx.x == 0) bnd[7] = s_bmax;
     }
   }
   __syncthreads();
@@ -1635,8 +1643,16 @@ __device__ __forceinline__ void moments_tree_dpp(Moments& m) {
 #undef NDT_TREE_STEP
 }
 
+// the bounds words between two builds: neutral elements of min / max / add
+__device__ __forceinline__ void reset_bounds_words(int* __restrict__ bnd) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { bnd[k] = INT_MAX; bnd[3 + k] = INT_MIN; }
+  bnd[6] = 0;
+  bnd[7] = 0;
+}
+
 __global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __restrict__ pts, const int* __restrict__ bucket_off,
-                                                             const int* __restrict__ rows, int ntiles, float leaf,
+                                                             int* __restrict__ bnd, float leaf,
                                                              float inv_leaf, long long cell_capacity, int min_pts,
                                                              FinalizeParams fp, BuildGeom* __restrict__ gd,
                                                              BuildGeom* __restrict__ gd_host, int* __restrict__ d_nleaf,
@@ -1660,9 +1676,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __re
   __shared__ int dbase[SORT_BINS];
   __shared__ int wsum[BK_WAVES];
   __shared__ int wave_head[BK_WAVES], wave_total[BK_WAVES];
-  __shared__ int fold[BK_WAVES][8];
-  __shared__ BuildGeom sg;
-  __shared__ int s_maxb, s_base, s_ok, s_last, s_decline;
+  __shared__ int s_base, s_ok, s_last, s_decline;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int bucket = blockIdx.x;
   NDT_BSTAMP(5, 0);
@@ -1670,17 +1684,14 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __re
   // (the launch starts on cold caches: every dependent round trip is ~2 us, so the verdict of the partition
   // launch travels with the bucket's range instead of in front of it)
   const int prior_status = gd->status;
+  int bw[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) bw[k] = bnd[k];   // uniform: scalar loads
   const int base = bucket_off[bucket], m = bucket_off[bucket + 1] - base;
-  if (prior_status == BG_SPIN) return;  // the partition launch gave up waiting (uniform over the grid)
-  int fm[6] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN};
-  int fc = 0;
-  for (int r = threadIdx.x; r < ntiles; r += BK_THREADS) {
-    const int4 lo4 = *reinterpret_cast<const int4*>(rows + r * 8), hi4 = *reinterpret_cast<const int4*>(rows + r * 8 + 4);
-    fm[0] = min(fm[0], lo4.x); fm[1] = min(fm[1], lo4.y); fm[2] = min(fm[2], lo4.z);
-    fm[3] = max(fm[3], lo4.w); fm[4] = max(fm[4], hi4.x); fm[5] = max(fm[5], hi4.y);
-    fc += hi4.z;
+  if (prior_status == BG_SPIN) {  // the partition launch gave up waiting (uniform over the grid)
+    if (bucket == 0 && threadIdx.x == 0) reset_bounds_words(bnd);
+    return;
   }
-  const int my_bucket_size = threadIdx.x < SORT_BINS ? bucket_off[threadIdx.x + 1] - bucket_off[threadIdx.x] : 0;
   // Position p = wave * C + round * 64 + lane: a wave owns C consecutive positions, so "tile order" is (wave, round,
   // lane) as in the sort passes above; C is the smallest multiple of 64 that spreads the bucket over all 16 waves
   // (a bucket of 3906 points: 4 rounds on every wave instead of 8 rounds on half of them).
@@ -1692,60 +1703,39 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __re
     q[r] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (r < R && p < m) q[r] = pts[base + p];
   }
-  // ---- geometry: every block folds the bounds rows and derives the same BuildGeom -------------------
+  // ---- geometry: every wave derives the same BuildGeom from the seven bounds words, in registers ---------------
+  // (same f32 arithmetic as voxel_grid_covariance_impl.hpp:108-140; no LDS, no barrier)
+  // (only the grid geometry stays live through the kernel; the block that ends the launch derives the whole
+  // BuildGeom once more from the eight words for the host -- kept in registers it cost 100 bytes of scratch)
+  auto derive = [&](BuildGeom* out) {
+    derive_geometry_lean(bw, bw[6], leaf, inv_leaf, cell_capacity, out);
+    if (out->status == BG_OK) {
+      // exactness of floor(p / leaf) - min_b in f32 (one voxel, one bucket), and a bucket must fit a block
+      bool big = false;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) big = big || !(fabsf(floorf(decode_ordered_dev(bw[k]) * inv_leaf)) < BK_COORD_LIMIT);
+      if (big || bw[7] > BK_MAXP) out->status = BG_BUCKET;
+    }
+  };
+  GridGeom g;
+  int status;
   {
-    const int nw = min(BK_WAVES, (ntiles + 63) / 64);   // waves that hold any row
-    if (wave < nw) {
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          fm[k] = min(fm[k], __shfl_xor(fm[k], off));
-          fm[3 + k] = max(fm[3 + k], __shfl_xor(fm[3 + k], off));
-        }
-        fc += __shfl_xor(fc, off);
-      }
-      if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) fold[wave][k] = fm[k];
-        fold[wave][6] = fc;
-      }
-    }
-    if (threadIdx.x == 0) { s_maxb = 0; s_ok = 0; s_decline = 0; }
-    for (int t = threadIdx.x; t < BK_TAB; t += BK_THREADS) tab[t] = BK_EMPTY;
-    __syncthreads();
-    if (threadIdx.x < SORT_BINS) {
-      int mb = my_bucket_size;
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) mb = max(mb, __shfl_xor(mb, off));
-      if (lane == 0) atomicMax(&s_maxb, mb);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int out[6], total = 0;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        int v = fold[0][k];
-        for (int w = 1; w < nw; ++w) v = k < 3 ? min(v, fold[w][k]) : max(v, fold[w][k]);
-        out[k] = v;
-      }
-      for (int w = 0; w < nw; ++w) total += fold[w][6];
-      derive_geometry_lean(out, total, leaf, inv_leaf, cell_capacity, &sg);
-      if (sg.status == BG_OK) {
-        // exactness of floor(p / leaf) - min_b in f32 (one voxel, one bucket), and a bucket must fit a block
-        bool big = false;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) big = big || !(fabsf(floorf(decode_ordered_dev(out[k]) * inv_leaf)) < BK_COORD_LIMIT);
-        if (big || s_maxb > BK_MAXP) sg.status = BG_BUCKET;
-      }
-    }
-    __syncthreads();
+    BuildGeom lg;
+    derive(&lg);
+    g = lg.g;
+    status = lg.status;
   }
-  if (sg.status != BG_OK) {
+  if (threadIdx.x == 0) { s_ok = 0; s_decline = 0; }
+  for (int t = threadIdx.x; t < BK_TAB; t += BK_THREADS) tab[t] = BK_EMPTY;
+  __syncthreads();
+  if (status != BG_OK) {
     // refused (the host repeats the build another way, or reports the error): nothing was written
     if (bucket == 0 && threadIdx.x == 0) {
-      *gd = sg;
-      *gd_host = sg;
+      BuildGeom lg;
+      derive(&lg);
+      *gd = lg;
+      *gd_host = lg;
+      reset_bounds_words(bnd);
       nleaf_host[0] = 0;
       nleaf_host[1] = 0;
       // the verdict first, the tag the host polls for last (gd_host and nleaf_host are __restrict__: without
@@ -1755,15 +1745,16 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __re
     return;
   }
   NDT_BSTAMP(5, 1);  // geometry derived
-  const GridGeom g = sg.g;
   // ---- LDS copy of the points; cell key (ref: voxel_grid_covariance_impl.hpp:222-225); the distinct cells of the
   // bucket go into an LDS hash table (a few hundred of them): sorting by the table's DENSE ids takes one or two
   // narrow digit passes instead of three 8-bit passes over the 24-bit cell index -------------------------------
   unsigned short tslot[BK_ROUNDS];
+  uint32_t ckey[BK_ROUNDS], cold[BK_ROUNDS];
 #pragma unroll
   for (int r = 0; r < BK_ROUNDS; ++r) {
     const int p = wave * C + r * 64 + lane;
     tslot[r] = 0;
+    ckey[r] = BK_EMPTY;   // "no point here"
     if (r < R && p < m) {
       px[p] = q[r].x; py[p] = q[r].y; pz[p] = q[r].z;
       uint32_t key = (uint32_t)g.ncells;  // sentinel: never a leaf
@@ -1771,11 +1762,25 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __re
         const int c = cell_of(q[r].x, q[r].y, q[r].z, g);
         if (c >= 0 && c < g.ncells) key = (uint32_t)c;
       }
-      uint32_t hsl = (key * 0x9E3779B1u) >> (32 - 12);
-      for (int probe = 0; probe < BK_TAB; ++probe) {
-        const uint32_t old = atomicCAS(&tab[hsl], BK_EMPTY, key);
-        if (old == BK_EMPTY || old == key) break;
+      ckey[r] = key;
+      tslot[r] = (unsigned short)((key * 0x9E3779B1u) >> (32 - 12));
+    }
+  }
+  // first probe of every round in flight together (an LDS atomic with return is ~120 cycles; one after the other
+  // they were a chain of R of them), collisions resolved afterwards
+#pragma unroll
+  for (int r = 0; r < BK_ROUNDS; ++r) {
+    cold[r] = BK_EMPTY;
+    if (r < R && ckey[r] != BK_EMPTY) cold[r] = atomicCAS(&tab[tslot[r]], BK_EMPTY, ckey[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < BK_ROUNDS; ++r) {
+    if (r < R && ckey[r] != BK_EMPTY && cold[r] != BK_EMPTY && cold[r] != ckey[r]) {
+      uint32_t hsl = tslot[r];
+      for (int probe = 1; probe < BK_TAB; ++probe) {
         hsl = (hsl + 1) & (BK_TAB - 1);
+        const uint32_t old = atomicCAS(&tab[hsl], BK_EMPTY, ckey[r]);
+        if (old == BK_EMPTY || old == ckey[r]) break;
         if (probe == BK_TAB - 1) s_decline = 1;  // table full
       }
       tslot[r] = (unsigned short)hsl;
@@ -2054,9 +2059,12 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __re
       const int valid = __hip_atomic_load(&d_nleaf[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // a bucket with more distinct cells than its table holds declined AFTER other blocks had published leaves:
       // the host repeats the build sort-based on a cleared grid
-      if (__hip_atomic_load(&d_nleaf[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) sg.status = BG_BUCKET;
-      *gd = sg;
-      *gd_host = sg;
+      BuildGeom lg;
+      derive(&lg);
+      if (__hip_atomic_load(&d_nleaf[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) lg.status = BG_BUCKET;
+      *gd = lg;
+      *gd_host = lg;
+      reset_bounds_words(bnd);   // every block read them at its entry, long ago: neutral again for the next build
       nleaf_host[0] = slots;
       nleaf_host[1] = valid;
       // geometry and counts first, the tag the host polls for last (see above)
@@ -2455,6 +2463,11 @@ bool bucket_build_enabled() {
   return on;
 }
 int bucket_build_tiles(size_t n) { return (int)((n + BK_MAXP - 1) / BK_MAXP); }
+void bucket_bounds_neutral(int out[8]) {
+  for (int k = 0; k < 3; ++k) { out[k] = INT_MAX; out[3 + k] = INT_MIN; }
+  out[6] = 0;
+  out[7] = 0;
+}
 // The hash spreads voxels, not points: the largest bucket of a lidar map is ~1.6x the mean (crowded voxels
 // near the sensor), and a bucket must fit BK_MAXP points -- so clouds up to 256 * BK_MAXP / 1.6 points are
 // worth trying (a bucket that overflows anyway costs one refused launch pair, BG_BUCKET).  Every block of
@@ -2467,7 +2480,7 @@ bool bucket_build_fits(size_t n, int compute_units) {
 hipError_t launch_bucket_build(const float* x, const float* y, const float* z, size_t n, float leaf, float inv_leaf,
                                long long cell_capacity, int min_pts, FinalizeParams fp, BuildGeom* gd, BuildGeom* gd_host,
                                uint32_t* table, uint32_t* seq, const LeafStats* old_stats, int dirty_slots, int* cell2leaf,
-                               size_t c2l_cap, int* rows, int* bucket_off, int* d_nleaf, unsigned int* ticket, float* pts4,
+                               size_t c2l_cap, int* bnd, int* bucket_off, int* d_nleaf, unsigned int* ticket, float* pts4,
                                double* sums, VoxelRecord* rec, float* cent4, LeafStats* stats, int max_leaves, int* nleaf_host,
                                int done_tag, hipStream_t s) {
   if (n == 0) return hipErrorInvalidValue;
@@ -2485,10 +2498,10 @@ hipError_t launch_bucket_build(const float* x, const float* y, const float* z, s
 #endif
   const int ntiles = bucket_build_tiles(n);
   hipLaunchKernelGGL(k_bucket_pass, dim3((unsigned)ntiles), dim3(BK_THREADS), 0, s, x, y, z, (int)n, inv_leaf, ntiles, table,
-                     tag, mute_tile, gd, gd_host, old_stats, dirty_slots, cell2leaf, c2l_cap, rows, bucket_off, d_nleaf,
+                     tag, mute_tile, gd, gd_host, old_stats, dirty_slots, cell2leaf, c2l_cap, bnd, bucket_off, d_nleaf,
                      reinterpret_cast<float4*>(pts4));
   hipLaunchKernelGGL(k_bucket_leaves, dim3(BK_BUCKETS), dim3(BK_THREADS), 0, s, reinterpret_cast<const float4*>(pts4),
-                     bucket_off, rows, ntiles, leaf, inv_leaf, cell_capacity, min_pts, fp, gd, gd_host, d_nleaf, ticket, sums,
+                     bucket_off, bnd, leaf, inv_leaf, cell_capacity, min_pts, fp, gd, gd_host, d_nleaf, ticket, sums,
                      rec, reinterpret_cast<float4*>(cent4), stats, cell2leaf, max_leaves, nleaf_host, done_tag);
   return hipGetLastError();
 }
