@@ -184,6 +184,14 @@ def main():
     rehearsal = os.environ.get("NDT_BENCH_SINGLE_DEVICE", "0") == "1"
     if rehearsal:
         local_rank = 0
+        if world > 2:
+            # The build's fast paths wait INSIDE a kernel for sibling blocks (every tile of k_bucket_pass / k_sort_pass for
+            # every other one) and need all of them resident: three or more ranks' builds on ONE device do not fit its 256
+            # compute units together, each waits out its 50 ms time-out and falls back (0.2-0.6 s per step with four
+            # ranks, profiles/r03_4on1_rehearsal.txt).  A rehearsal of that shape takes the launch-per-phase passes, which
+            # never wait inside a kernel.  One rank per device -- the deployment -- is not affected.
+            os.environ.setdefault("NDT_BUCKET_BUILD", "0")
+            os.environ.setdefault("NDT_FUSED_SORT", "0")
     # stdout carries ONE JSON line and nothing else: native libraries write there too (librccl prints
     # "RCCL version : ..." on its first communicator), so file descriptor 1 is pointed at stderr for the
     # life of the rank and the line goes out through a private copy of the original descriptor

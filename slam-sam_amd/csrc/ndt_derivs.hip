@@ -560,7 +560,10 @@ constexpr int ROW_WORDS = 2 * EV_WORDS;   // 32 x {tag, value}
 constexpr int AUX_AGENT = 16;             // sc1
 constexpr int AUX_SYSTEM = 17;            // sc0 sc1
 constexpr int SUM_BATCH = 16;             // rows per thread and memory round trip (64 VGPRs in flight; 20 spilled once the retry mask joined them)
-constexpr unsigned long long SUM_TIMEOUT_TICKS = 10000000ull;  // 100 ms of the 100 MHz clock: no launch of this kernel runs that long
+// 2 s of the 100 MHz clock.  The summing block waits for blocks of its OWN launch that may not have been dispatched
+// yet: on a device shared with other processes (whose waiting kernels hold compute units for up to 20 ms each) that
+// took longer than the 100 ms this limit stood at for a while -- four ranks rehearsing on one device lost rows.
+constexpr unsigned long long SUM_TIMEOUT_TICKS = 200000000ull;
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t slots_rsrc(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xFFFFFFFFu, 0x00020000);
