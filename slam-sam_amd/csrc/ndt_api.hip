@@ -123,6 +123,7 @@ struct ndt_handle {
   DevBuf<int> bucket_off;             // first point of every bucket (two-launch bucketed build)
   DevBuf<int> bnd;                    // its 8 bounds words {min xyz, max xyz, #finite, largest bucket}; neutral between builds
   long long n_bucket_builds = 0, n_bucket_fallbacks = 0;
+  int bucket_skip = 0, bucket_backoff = 0;  // builds to go before the two-launch build is tried again after a decline
   const float* vx = nullptr;          // the source as evaluated: the engine's own copy (sx/sy/sz) or,
   const float* vy = nullptr;          // after ndt_set_source_device_view, the caller's arrays
   const float* vz = nullptr;
@@ -409,6 +410,14 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
   const bool fused_sort = fused && fused_sort_fits(n, h->n_cus);
   // the two-launch build: steady state only (decided per attempt below), and it shares the tag table
   bool bucketed_ok = bucket_build_enabled() && bucket_build_fits(n, h->n_cus);
+  // A cloud the two-launch build declined (BG_BUCKET: a bucket beyond a block's LDS or hash table, far-away coordinates)
+  // is usually followed by more of its kind (the same map, the next keyframe): the attempt costs two launches and, for a
+  // late decline, a full clear of the index grid, so after a decline the next 8 builds go sort-based straight away, 16 after
+  // the next decline, ... at most 64.
+  if (bucketed_ok && h->bucket_skip > 0) {
+    --h->bucket_skip;
+    bucketed_ok = false;
+  }
   if ((fused_sort || bucketed_ok) && !h->sort_tags.p) {
     HIP_TRY(h, h->sort_tags.ensure(fused_table_words()));
     HIP_TRY(h, hipMemsetAsync(h->sort_tags.p, 0, h->sort_tags.cap * sizeof(uint32_t), s));
@@ -515,12 +524,19 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
       // leaves): that retry does not trust the grid -- full clear, geometry awaited.
       bucketed_ok = false;
       dirty_slots = 0;
-      if (bg.status == BG_BUCKET) clean_cap = 0;
+      if (bg.status == BG_BUCKET) {
+        clean_cap = 0;
+        h->bucket_backoff = std::min(64, std::max(8, 2 * h->bucket_backoff));
+        h->bucket_skip = h->bucket_backoff;
+      }
       ++h->n_bucket_fallbacks;
       HIP_TRY(h, neutral_bounds());   // (the launch pair resets them itself on every path; belt and braces)
       continue;
     }
-    if (bucketed && bg.status == BG_OK) ++h->n_bucket_builds;
+    if (bucketed && bg.status == BG_OK) {
+      ++h->n_bucket_builds;
+      h->bucket_backoff = 0;
+    }
     if (optimistic && (bg.status == BG_CAPACITY || bg.status == BG_PASSES)) {
       // the cloud outgrew the dense grid (or the enqueued sort passes): nothing after the bounds
       // kernel ran; the old cells were reset by it.  Once more, waiting for the geometry.

@@ -712,3 +712,46 @@ def test_one_engine_many_targets_in_turn(pkg, S):
     bc = ndt.buildCounters()
     # fresh engines build sort-based (first build), this one mostly in two launches: bit-identical leaves
     assert bc[0] == 0 and bc[2] >= 8, bc
+
+
+def test_two_launch_build_declines_and_the_sort_based_build_repeats_it(pkg, O):
+    """The steady-state build in two launches declines what it cannot hold, and the sort-based pipeline repeats the
+    build with the same leaves as a first (sort-based) build of that cloud, bit for bit:
+      * a cloud of isolated points -- more distinct cells in a bucket than its LDS hash table takes: the bucket notices
+        AFTER other buckets have published leaves (BG_BUCKET from the last block; the host clears the whole grid);
+      * coordinates beyond 2^23 voxels -- floor(p / leaf) - min_b stops being exact in f32 there, one voxel could
+        straddle two buckets: declined before anything is written."""
+    rng = np.random.default_rng(31)
+    kw = dict(resolution=0.5, step_size=0.1, trans_epsilon=1e-4, max_iterations=5, min_points_per_voxel=6)
+    # (a) 1.1 M points, almost every one alone in its voxel, plus a few hundred real leaves
+    sparse = rng.uniform(-150.0, 150.0, (1100000, 3)) * np.array([1.0, 1.0, 0.2])
+    dense = np.concatenate([c + rng.uniform(-0.2, 0.2, (40, 3)) for c in rng.uniform(-100.0, 100.0, (300, 3))])
+    tgt = np.concatenate([sparse, dense])[rng.permutation(1100000 + 300 * 40)].astype(np.float32)
+    grid = O.Grid(tgt, O.default_params(num_threads=8, **kw))
+    OL = grid.export()
+    ndt = pkg.NormalDistributionsTransform(device_id=0, **kw)
+    first = None
+    for rep in range(3):
+        ndt.setInputTarget(tgt)
+        L = ndt.getLeaves()
+        assert np.array_equal(L["cell"], OL["cell"]) and np.array_equal(L["count"], OL["count"]) and len(L["cell"]) >= 250
+        np.testing.assert_allclose(L["mean"], OL["mean"], rtol=1e-12, atol=0)
+        if first is None:
+            first = L
+        for f in ("mean", "cov", "icov", "evals"):
+            assert np.array_equal(L[f], first[f]), (rep, f)
+    assert ndt.buildCounters()[1:] == (1, 0)   # declined once, then not tried again for the next 8 builds; never built in two launches
+    # (b) the same engine, an ordinary cloud 6 000 km from the origin
+    far = (rng.normal(0, 1, (60000, 3)) * np.array([8.0, 6.0, 1.0]) + np.array([6.0e6, 0.0, 0.0])).astype(np.float32)
+    fresh = pkg.NormalDistributionsTransform(device_id=0, **kw)
+    fresh.setInputTarget(far)
+    want = fresh.getLeaves()
+    assert len(want["cell"]) > 10
+    ndt2 = pkg.NormalDistributionsTransform(device_id=0, **kw)
+    for rep in range(3):
+        ndt2.setInputTarget(far)
+        L = ndt2.getLeaves()
+        for f in ("cell", "count", "mean", "cov", "icov", "evals"):
+            assert np.array_equal(L[f], want[f]), (rep, f)
+    bc = ndt2.buildCounters()
+    assert bc[1] == 1 and bc[2] == 0, bc       # the first steady-state build declined, the next went sort-based straight away
