@@ -34,6 +34,8 @@ import os
 # right before a timed region cost it 2.4x).  The synthetic workloads need no threaded BLAS.
 for _v in ("OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "BLIS_NUM_THREADS"):
     os.environ.setdefault(_v, "1")
+# A rank that stops answering inside an all-reduce is a failed reduce variant here, not something to sit out
+os.environ.setdefault("NDT_COMM_TIMEOUT_S", "20")
 import sys
 import threading
 import time
@@ -226,7 +228,14 @@ def main():
     n_tgt = len(cfg["target"])
     guess_cm = pkg.ColMajor4f(cfg["guess"])
 
+    current = {"mode": "none", "steps": 0}
+    inject = os.environ.get("NDT_BENCH_INJECT_FAILURE")   # tests only: "<variant>" -> the last rank errors in its 3rd step
+
     def step():
+        if inject is not None and inject == current["mode"] and rank == world - 1:
+            current["steps"] += 1
+            if current["steps"] == 3:
+                raise pkg.NdtError(-7, "injected failure (NDT_BENCH_INJECT_FAILURE)")
         t0 = time.perf_counter()
         ndt.setInputTargetDevice(tptr[0], tptr[1], tptr[2], n_tgt)
         t1 = time.perf_counter()
@@ -241,28 +250,48 @@ def main():
         hip.synchronize()
 
     def timed_region():
-        """W warm-up steps, then exactly K steps between two fences; max wall time over ranks."""
-        for _ in range(args.warmup):
-            step()
+        """W warm-up steps, then exactly K steps between two fences; max wall time over ranks.
+        With several ranks an engine error (a reducer that stops answering) does not leave the other
+        ranks stranded in a fence: the failing rank still walks through the same board calls and
+        reports an infinite time, so every rank sees the variant as failed and moves on."""
+        failed = None
+        try:
+            for _ in range(args.warmup):
+                step()
+        except pkg.NdtError as e:
+            if not multi:
+                raise
+            failed = e
         fence()
         pre0 = ndt.prelaunchCounters()
         t0 = time.perf_counter()
         iters = evals = reused = 0
         t_build = t_align = 0.0
-        for _ in range(args.steps):
-            e, tb, ta = step()
-            iters += e.getFinalNumIteration()
-            evals += e.getNumEvaluations()
-            reused += e._raw.n_evaluations_reused
-            t_build += tb
-            t_align += ta
+        try:
+            for _ in range(args.steps if failed is None else 0):
+                e, tb, ta = step()
+                iters += e.getFinalNumIteration()
+                evals += e.getNumEvaluations()
+                reused += e._raw.n_evaluations_reused
+                t_build += tb
+                t_align += ta
+        except pkg.NdtError as e:
+            if not multi:
+                raise
+            failed = e
         fence()
         elapsed = time.perf_counter() - t0
+        if failed is not None:
+            print("rank %d: engine error inside the timed region (%s)" % (rank, failed), file=sys.stderr, flush=True)
+            elapsed = float("inf")
         if multi:
             elapsed = board.allmax(elapsed)
+        if elapsed == float("inf"):
+            return None
         pre1 = ndt.prelaunchCounters()
+        err_t, err_r = S.pose_error(ndt.getResult()["T"], cfg["gt"])
         return dict(elapsed=elapsed, iters=iters, evals=evals, reused=reused, t_build=t_build, t_align=t_align,
-                    prelaunched=pre1[0] - pre0[0], prelaunch_timeouts=pre1[2] - pre0[2])
+                    prelaunched=pre1[0] - pre0[0], prelaunch_timeouts=pre1[2] - pre0[2], err_m=err_t, err_rad=err_r)
 
     def init_reducer(mode):
         """Creates the engine's cross-rank reducer on every rank; False if any rank failed."""
@@ -543,23 +572,35 @@ def main():
                     out.setdefault("reduce_failed", mode)
             else:
                 n_comm = ndt.commRankCount()
+                current["mode"], current["steps"] = mode, 0
                 res = timed_region()
-                variants[mode] = {"value": res["iters"] / res["elapsed"], "ms_per_step": 1e3 * res["elapsed"] / args.steps,
-                                  "ranks": n_comm, "evaluations_prelaunched_per_align": res["prelaunched"] / args.steps}
-                if mode == "rccl":
-                    variants[mode]["ncclCommCount"] = n_comm
-                if out is None:
-                    out = instrumented(res, mode, variants)
-                    if rank != 0:
-                        out = {"config": {"reduce_variants": variants}}  # placeholder: only rank 0 prints
-                    probe = scaling_probe()
-                    if probe is not None:
-                        probe["reduce"] = mode
-                        out["scaling_probe"] = probe
-                if best is None or res["elapsed"] < best["elapsed"]:
-                    best = res
-                    headline(out, res, mode)
-                ndt.commDestroy()
+                if res is None:      # an engine error on some rank: the variant is reported as failed, the others stand
+                    variants[mode] = "failed"
+                    if out is not None:
+                        out.setdefault("reduce_failed", mode)
+                    ndt.commDestroy()
+                else:
+                    # a transport that sums wrongly shows up in the answer: the same scan must land on the same pose
+                    sane = bool(board.allmax(0.0 if res["err_m"] < 0.05 else 1.0) == 0.0)
+                    variants[mode] = {"value": res["iters"] / res["elapsed"], "ms_per_step": 1e3 * res["elapsed"] / args.steps,
+                                      "ranks": n_comm, "evaluations_prelaunched_per_align": res["prelaunched"] / args.steps,
+                                      "iterations_per_align": res["iters"] / args.steps, "final_error_m": res["err_m"]}
+                    if not sane:
+                        variants[mode]["suspect"] = "final pose more than 5 cm from ground truth: not eligible as the headline"
+                    if mode == "rccl":
+                        variants[mode]["ncclCommCount"] = n_comm
+                    if out is None and sane:
+                        out = instrumented(res, mode, variants)
+                        if rank != 0:
+                            out = {"config": {"reduce_variants": variants}}  # placeholder: only rank 0 prints
+                        probe = scaling_probe()
+                        if probe is not None:
+                            probe["reduce"] = mode
+                            out["scaling_probe"] = probe
+                    if sane and (best is None or res["elapsed"] < best["elapsed"]):
+                        best = res
+                        headline(out, res, mode)
+                    ndt.commDestroy()
             if rank == 0:
                 state["out"] = out
             if dog is not None:

@@ -11,8 +11,22 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
+
+namespace {
+// How long a rank waits for the others inside one all-reduce before it reports NDT_ERR_COMM
+// (NDT_COMM_TIMEOUT_S, default 120 s: a peer that is paged out or being debugged is not an error).
+std::chrono::seconds wait_limit() {
+  static const long s = [] {
+    const char* e = std::getenv("NDT_COMM_TIMEOUT_S");
+    const long v = e ? std::atol(e) : 0;
+    return v > 0 ? v : 120L;
+  }();
+  return std::chrono::seconds(s);
+}
+}  // namespace
 
 namespace ndt {
 
@@ -298,7 +312,7 @@ int Reducer::p2p_finish_on_host(uint64_t round, double* words, int n, std::strin
     for (int r = 0; r < nranks_ && ok; ++r)
       for (int v = 0; v < NDT_EVAL_WORDS && ok; ++v) ok = rows[r][2 * v] == round;
     if (ok) break;
-    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
+    if (std::chrono::steady_clock::now() - t0 > wait_limit()) {
       if (err) *err = "peer-write all-reduce timed out waiting for a rank";
       return NDT_ERR_COMM;
     }
@@ -398,7 +412,7 @@ int Reducer::allreduce_host(double* words, int n, std::string* err) {
     while (seg->seq[r].v.load(std::memory_order_acquire) < round) {
       if (++spins > 4096) {
         spins = 0;
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
+        if (std::chrono::steady_clock::now() - t0 > wait_limit()) {
           if (err) *err = "shared-memory all-reduce timed out";
           return NDT_ERR_COMM;
         }

@@ -77,3 +77,21 @@ def test_bench_forced_distributed_one_rank_runs_rccl():
     v = d["config"]["reduce_variants"]
     assert v["rccl"]["ncclCommCount"] == 1 and v["rccl"]["value"] > 0 and v["shm"]["value"] > 0 and v["p2p"]["value"] > 0
     assert "/opt/rocm" in d["config"]["rccl"]["library"] and "torch" not in d["config"]["rccl"]["library"]
+
+
+def test_bench_survives_a_reduce_variant_that_fails_mid_run():
+    """One rank errors inside the peer-write variant's timed region (NDT_BENCH_INJECT_FAILURE): the other rank's
+    all-reduce times out (NDT_COMM_TIMEOUT_S), both walk through the same fences, the variant is reported as
+    failed and the shared-memory measurement taken before it stands -- one JSON line, rc 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NDT_RANKS_BOARD")}
+    env.update(NDT_BENCH_PROBE="0", NDT_BENCH_SINGLE_DEVICE="1", NDT_BENCH_INJECT_FAILURE="p2p", NDT_COMM_TIMEOUT_S="3")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    v = d["config"]["reduce_variants"]
+    assert v["p2p"] == "failed" and d["reduce_failed"] == "p2p" and v["shm"]["value"] > 0 and d["config"]["reduce"] == "shm"
+    assert v["shm"]["final_error_m"] < 0.05 and "suspect" not in v["shm"]
+    assert "injected failure" in r.stderr and "timed out" in r.stderr
