@@ -27,4 +27,9 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS
 python3 $R/scripts/pmc_summary.py $P > $OUT/pmc_summary.txt 2>&1
 rm -rf $OUT/prof/*/*trace* 2>/dev/null
 find $P -name "*kernel_trace.csv" -delete; find $P -name "*agent_info.csv" -delete
+cd $R
+make -C $R/slam-sam_amd/csrc VARIANT=stamps -j8 > /dev/null 2>&1
+NDT_HIP_LIB=$R/slam-sam_amd/libndt_hip_stamps.so timeout -k 10 200 python tests/gpu_stamps_prelaunch.py 2>&1 | grep -v amdgpu.ids | tail -9 > $OUT/stamps_prelaunch.txt
+NDT_HIP_LIB=$R/slam-sam_amd/libndt_hip_stamps.so timeout -k 10 200 python tests/gpu_build_stamps.py 2>&1 | grep -v amdgpu.ids | tail -18 > $OUT/build_stamps.txt
+rm -f $R/slam-sam_amd/libndt_hip_stamps.so
 echo done; head -c 700 $OUT/bench.json; echo; cat $OUT/replay.txt; cat $OUT/modes.txt | tail -8
