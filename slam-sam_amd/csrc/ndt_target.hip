@@ -51,8 +51,16 @@ __device__ unsigned long long g_bstamps[6 * 512 * 8];  // slots 4 / 5: k_bucket_
     if (threadIdx.x == 0 && blockIdx.x < 512)                                                \
       g_bstamps[((slot) * 512 + blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memrealtime();   \
   } while (0)
+// per-WAVE stamps of k_bucket_leaves' blocks 0..31 (16 waves each), in the rows of slot 0 (the sort passes' slot:
+// they do not run in a bucketed build)
+#define NDT_WSTAMP(k)                                                                                   \
+  do {                                                                                                  \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 32)                                                     \
+      g_bstamps[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memrealtime();   \
+  } while (0)
 #else
 #define NDT_BSTAMP(slot, k) do { } while (0)
+#define NDT_WSTAMP(k) do { } while (0)
 #endif
 
 __device__ __forceinline__ float decode_ordered_dev(int enc) {
@@ -989,7 +997,10 @@ constexpr int SUMS_BLOCKS_MAX = 2048;
 // crowded leaf holds beyond that is gathered by all 64 lanes of the wave, leaf after leaf, and
 // added by a fixed 6-step tree -- otherwise the most crowded voxel of the map (1000+ points on 8
 // lanes) sets the kernel's duration.  Every association is fixed: the sums are reproducible.
-constexpr int LEAF_HEAD = 64;
+#ifndef NDT_LEAF_HEAD
+#define NDT_LEAF_HEAD 64   // (128 measured in round 3: no difference, profiles/r03_build_stamps_waves.txt)
+#endif
+constexpr int LEAF_HEAD = NDT_LEAF_HEAD;
 #ifndef NDT_SUMS_UNROLL
 #define NDT_SUMS_UNROLL 4
 #endif
@@ -1968,6 +1979,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __re
   }
   __syncthreads();   // leaf list complete (s_base is read behind the next barrier only)
   NDT_BSTAMP(5, 4);  // runs found
+  NDT_WSTAMP(0);
   // ---- per-voxel sums (ref :236-239), from LDS, in input order: 8 lanes per leaf, crowded leaves by the wave ----
   int slot0 = 0;
   {
@@ -1993,6 +2005,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __re
         for (int u = 0; u < SUMS_UNROLL; ++u) moments_add(mo, pp[u], live[u]);
       }
       moments_tree_dpp<LANES_PER_LEAF>(mo);
+      NDT_WSTAMP(1);
       unsigned long long crowded = __ballot(c > LEAF_HEAD);
       while (crowded) {
         const int src = __ffsll((long long)crowded) - 1;
@@ -2020,6 +2033,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __re
           for (int a = 0; a < 6; ++a) mo.ss[a] += t.ss[a];
         }
       }
+      NDT_WSTAMP(2);
       if (l0 == 0) {   // uniform: the slot base has arrived by now
         __syncthreads();
         slot0 = s_base;
@@ -2032,7 +2046,9 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __re
       if (sub == 0) o[8] = mo.ss[5];
     }
   }
+  NDT_WSTAMP(3);
   __syncthreads();   // the sums of this block's leaves are visible to the whole block
+  NDT_WSTAMP(4);
   NDT_BSTAMP(5, 5);  // sums written
   // ---- ref :265-343: one thread per leaf ---------------------------------------------------------------
   int ok_here = 0;
@@ -2041,6 +2057,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __re
     if (slot < max_leaves && finalize_leaf(slot, leaves[li].cell, (int)leaves[li].cnt, sums + (size_t)slot * 9, fp, rec, cent, stats, cell2leaf))
       ++ok_here;
   }
+  NDT_WSTAMP(5);  // this wave's leaves finalised, stores issued
   const int wave_ok = __popcll(__ballot(ok_here == 1)) + 2 * __popcll(__ballot(ok_here == 2)) + 3 * __popcll(__ballot(ok_here >= 3));
   if (lane == 0 && wave_ok) atomicAdd(&s_ok, wave_ok);
   __syncthreads();

@@ -30,3 +30,14 @@ for slot, nb, label in ((0, (n + 8191) // 8192, "sort pass 0 (from points)"), (1
     print("%s: %d blocks (us since the first block's entry)" % (label, nb))
     for k, name in enumerate(nm):
         print("  %-13s min %6.2f  median %6.2f  max %6.2f" % (name, rel[:, k].min(), np.median(rel[:, k]), rel[:, k].max()))
+# per-wave stamps of k_bucket_leaves' blocks 0..31 (rows of slot 0): sums / statistics phases
+w = t[0].reshape(32, 16, 8)
+if w[:, :, 0].max() > 0:
+    ent = t[5, :32, 0][:, None, None]   # the block's entry
+    relw = (w - ent) * 0.01
+    wn = ["sums start", "head+tree", "crowded done", "sums written", "barrier", "finalised"]
+    print("k_bucket_leaves per wave, median over blocks 0..31 (us since the block's entry):")
+    print("  wave          " + "".join("%15s" % x for x in wn))
+    for wv in (0, 1, 2, 4, 8, 10, 12, 15):
+        print("  wave %2d       " % wv + "".join("%15.2f" % np.median(relw[:, wv, k]) for k in range(len(wn))))
+    print("  max over waves" + "".join("%15.2f" % np.median(relw[:, :, k].max(axis=1)) for k in range(len(wn))))
