@@ -180,6 +180,26 @@ struct RigidRT {
   float t[3];
 };
 
+// Record fetch of the DIRECT7 pair loop.  Two timing-only ablations (wrong results; `make VARIANT=ab EXTRA=-DNDT_ABL=..`):
+// 4: every lane reads record 0 (35 coalesced instead of 35 divergent 16-byte loads per lane) -- what divergence costs;
+// 5: 48 of the 80 bytes (three 16-byte loads instead of five) -- what a packed 48-byte record could save.
+#if defined(NDT_ABL) && NDT_ABL == 4
+#define NDT_LOAD_REC(s) rec[0]
+#elif defined(NDT_ABL) && NDT_ABL == 5
+__device__ __forceinline__ VoxelRecord load_rec48(const VoxelRecord* __restrict__ rec, int i) {
+  const double2* p = reinterpret_cast<const double2*>(rec + i);
+  const double2 a = p[0], b = p[1], c = p[2];
+  VoxelRecord r;
+  r.mean[0] = a.x; r.mean[1] = a.y; r.mean[2] = b.x;
+  r.icov[0] = b.y; r.icov[1] = c.x; r.icov[2] = c.y; r.icov[3] = b.y; r.icov[4] = c.x; r.icov[5] = c.y;
+  r.pad = 0.0;
+  return r;
+}
+#define NDT_LOAD_REC(s) load_rec48(rec, (s) >= 0 ? (s) : 0)
+#else
+#define NDT_LOAD_REC(s) rec[(s) >= 0 ? (s) : 0]
+#endif
+
 // Phase 1 of a point: transform, neighbour lookup, pair sums.  Needs only R|t.
 // D7: DIRECT7 (centre + 6 face neighbours); otherwise DIRECT1 (the point's own voxel only).
 template <int MODE, bool D7>
@@ -263,21 +283,21 @@ __device__ __forceinline__ void point_pairs(PairAcc& a, float x, float y, float 
   // ordinary launch by HIP events).  The scheduling fences keep the compiler from sinking the loads
   // back to their first use (it otherwise serialises seven L2 round trips per point).
 #ifndef NDT_PAIR_DEPTH4
-  const VoxelRecord r0 = rec[slot[0] >= 0 ? slot[0] : 0];
-  const VoxelRecord r1 = rec[slot[1] >= 0 ? slot[1] : 0];
-  const VoxelRecord r2 = rec[slot[2] >= 0 ? slot[2] : 0];
+  const VoxelRecord r0 = NDT_LOAD_REC(slot[0]);
+  const VoxelRecord r1 = NDT_LOAD_REC(slot[1]);
+  const VoxelRecord r2 = NDT_LOAD_REC(slot[2]);
   __builtin_amdgcn_sched_barrier(0);
   pair_update<MODE>(a, r0, xt, yt, zt, ec, slot[0] >= 0);
-  const VoxelRecord r3 = rec[slot[3] >= 0 ? slot[3] : 0];
+  const VoxelRecord r3 = NDT_LOAD_REC(slot[3]);
   __builtin_amdgcn_sched_barrier(0);
   pair_update<MODE>(a, r1, xt, yt, zt, ec, slot[1] >= 0);
-  const VoxelRecord r4 = rec[slot[4] >= 0 ? slot[4] : 0];
+  const VoxelRecord r4 = NDT_LOAD_REC(slot[4]);
   __builtin_amdgcn_sched_barrier(0);
   pair_update<MODE>(a, r2, xt, yt, zt, ec, slot[2] >= 0);
-  const VoxelRecord r5 = rec[slot[5] >= 0 ? slot[5] : 0];
+  const VoxelRecord r5 = NDT_LOAD_REC(slot[5]);
   __builtin_amdgcn_sched_barrier(0);
   pair_update<MODE>(a, r3, xt, yt, zt, ec, slot[3] >= 0);
-  const VoxelRecord r6 = rec[slot[6] >= 0 ? slot[6] : 0];
+  const VoxelRecord r6 = NDT_LOAD_REC(slot[6]);
   __builtin_amdgcn_sched_barrier(0);
   pair_update<MODE>(a, r4, xt, yt, zt, ec, slot[4] >= 0);
   pair_update<MODE>(a, r5, xt, yt, zt, ec, slot[5] >= 0);
@@ -972,7 +992,7 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
   } else if (i < n) {
     if (!(MBOX && ec.mbox_preload)) { x = sx[i]; y = sy[i]; z = sz[i]; }
     NDT_STAMP(1);
-#if !(defined(NDT_ABL) && NDT_ABL >= 3)
+#if !(defined(NDT_ABL) && NDT_ABL == 3)
     point_pairs<MODE, NB == 1>(a, x, y, z, g, cell2leaf, rec, rt, ec);
 #endif
   }
@@ -982,7 +1002,7 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
     __syncthreads();  // angle tables visible
   }
   double acc[EV_WORDS];
-#if defined(NDT_ABL) && NDT_ABL >= 3  // ablation: launch + reduction only
+#if defined(NDT_ABL) && NDT_ABL == 3  // ablation: launch + reduction only
 #pragma unroll
   for (int v = 0; v < EV_WORDS; ++v) acc[v] = 0.0;
   acc[0] = (double)(x + rt.R[0] + tab.jang[3]);
