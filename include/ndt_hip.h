@@ -233,6 +233,18 @@ int ndt_set_source_device_view(ndt_handle* h, const float* dx, const float* dy, 
  * Freeing the arrays while they are the source is the caller's error, as with the shared_ptr. */
 int ndt_source_changed(ndt_handle* h);
 
+/* Voxel-record format of the derivative kernel (SURVEY 7 "packed 48-B record").  NDT_RECORDS_F64: 80 bytes per
+ * voxel, mean and inverse covariance in f64 (default; what the 1e-9 parity tests run on).  NDT_RECORDS_PACKED48:
+ * 48 bytes, the mean stays f64 and the inverse covariance is rounded to f32 -- what the reference's own per-pair
+ * gradient / Hessian arithmetic does with it (c_inv4, svn_ndt_impl.hpp:449-456); only the score's Mahalanobis term
+ * sees an f32 matrix where the reference keeps f64.  Derivatives move by ~1e-7 of their norm, the aligned transform
+ * by micrometres (tests/test_gpu_features.py); an evaluation fetches three 16-byte pieces per neighbour instead of
+ * five.  Not applied to a multi-grid union (its leaves are chained through the 80-byte record).  Takes effect at
+ * the next evaluation; exported leaf statistics are the f64 ones either way. */
+typedef enum ndt_record_format { NDT_RECORDS_F64 = 0, NDT_RECORDS_PACKED48 = 1 } ndt_record_format;
+int ndt_set_record_format(ndt_handle* h, int format);
+int ndt_get_record_format(const ndt_handle* h);
+
 /* Multi-grid target [RECALLED: tier4 ndt_omp's MultiGridNormalDistributionsTransform -- addTarget /
  * removeTarget / createVoxelKdtree -- named by the reference's build (CMakeLists.txt:41-42); its
  * sources are in the absent extern/ndt_omp submodule and no driver instantiates it].  Every cloud is

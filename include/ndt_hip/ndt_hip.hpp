@@ -408,6 +408,12 @@ class NormalDistributionsTransform
     if (status_ == NDT_OK) n_src_ = 0;  // align()'s output cloud is not filled on this path
   }
 
+  // engine-specific: 48-byte voxel records (f64 mean, f32 inverse covariance) instead of 80-byte f64 ones
+  // (ndt_set_record_format in ndt_hip.h: what it costs in accuracy and what it saves per evaluation)
+  void setPackedVoxelRecords(bool on) {
+    status_ = h_ ? ndt_set_record_format(h_, on ? NDT_RECORDS_PACKED48 : NDT_RECORDS_F64) : NDT_ERR_NO_DEVICE;
+  }
+
   // ---- multi-grid target [RECALLED: tier4 ndt_omp multigrid_ndt_omp.h -- addTarget / removeTarget /
   // createVoxelKdtree with string ids; the reference names the class only in its build,
   // CMakeLists.txt:41-42, and no driver instantiates it] ----

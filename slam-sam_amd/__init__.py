@@ -31,6 +31,7 @@ COV_SVN, COV_PCL_RECALLED = 0, 1
 WAIT_SPIN, WAIT_BLOCK = 0, 1
 SOURCE_ORDER_AUTO, SOURCE_ORDER_KEEP, SOURCE_ORDER_SORT = 0, 1, 2
 PRELAUNCH_AUTO, PRELAUNCH_OFF, PRELAUNCH_ONE_STREAM = 0, 1, 2
+RECORDS_F64, RECORDS_PACKED48 = 0, 1
 PRESET_DEFAULT, PRESET_PCLOMP_RECALLED, PRESET_SVN = 0, 1, 2
 
 STATUS = {0: "NDT_OK", -1: "NDT_ERR_INVALID_ARG", -2: "NDT_ERR_NO_DEVICE", -3: "NDT_ERR_HIP",
@@ -134,6 +135,7 @@ ABI_SYMBOLS = [
     "ndt_params_preset", "ndt_score_transform", "ndt_comm_info", "ndt_score_transforms",
     "ndt_xy_covariance_laplace", "ndt_propose_poses_to_search", "ndt_xy_covariance_multi_ndt",
     "ndt_xy_covariance_multi_ndt_score", "ndt_source_changed", "ndt_comm_rank_count", "ndt_comm_p2p_handle", "ndt_comm_init_p2p",
+    "ndt_set_record_format", "ndt_get_record_format",
 ]
 
 _lib = None
@@ -165,6 +167,8 @@ def lib():
         L.ndt_set_source_device.argtypes = [vp, vp, vp, vp, C.c_size_t]
         L.ndt_set_source_device_view.argtypes = [vp, vp, vp, vp, C.c_size_t]
         L.ndt_source_changed.argtypes = [vp]
+        L.ndt_set_record_format.argtypes = [vp, C.c_int]
+        L.ndt_get_record_format.argtypes = [vp]
         L.ndt_set_regularization_pose.argtypes = [vp, fp]
         L.ndt_clear_regularization_pose.argtypes = [vp]
         L.ndt_align.argtypes = [vp, fp, C.POINTER(Result)]
@@ -405,6 +409,14 @@ class NormalDistributionsTransform:
     def sourceChanged(self):
         """The arrays of a viewed source were rewritten in place: drop whatever the engine cached of them."""
         self._check(lib().ndt_source_changed(self._h))
+
+    def setRecordFormat(self, fmt):
+        """RECORDS_F64 (80-byte voxel records, default) or RECORDS_PACKED48 (f64 mean + f32 inverse covariance,
+        three 16-byte loads per neighbour instead of five; ndt_hip.h)."""
+        self._check(lib().ndt_set_record_format(self._h, int(fmt)))
+
+    def getRecordFormat(self):
+        return int(lib().ndt_get_record_format(self._h))
 
     # --- multi-grid target [RECALLED: tier4 MultiGridNormalDistributionsTransform] ---
     def addTarget(self, cloud, target_id):

@@ -137,6 +137,11 @@ struct ndt_handle {
   DevBuf<float> xyz4;                // packed float4 copy of the target for the gather
   IndexGrid cell2leaf;
   DevBuf<VoxelRecord> rec;
+  // the same table as 48-byte PackedRecords (ndt_set_record_format): written behind every build while the packed
+  // format is selected, or on demand when it is selected afterwards
+  DevBuf<PackedRecord> prec;
+  bool prec_valid = false;
+  int record_format = NDT_RECORDS_F64;
   DevBuf<float> cent;                // 4 floats per leaf slot: f32 centroid (what the radius search tests) + chain link
   DevBuf<LeafStats> stats;
   int n_slots = 0, n_valid = 0;
@@ -351,6 +356,32 @@ int upload_soa(ndt_handle* h, const float* xyz, const float* x, const float* y, 
 // capacities the host assumed; ONE synchronisation at the end.  First build, or a cloud that
 // outgrew the buffers: the host waits for the geometry once, allocates, and goes on (as
 // before).  A refused optimistic build (BG_CAPACITY / BG_PASSES) is repeated that way.
+// (re)writes the packed copy of the record table; `wait`: the caller is about to launch on another stream
+int pack_records(ndt_handle* h, bool wait) {
+  if (h->n_slots <= 0) return NDT_OK;
+  HIP_TRY(h, h->prec.ensure((size_t)h->n_slots));
+  launch_pack_records(h->rec.p, h->prec.p, (size_t)h->n_slots, h->stream);
+  HIP_TRY(h, hipGetLastError());
+  if (wait) HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->prec_valid = true;
+  return NDT_OK;
+}
+
+// The record table an evaluation reads: the 48-byte packed copy when that format is selected (not for a multi-grid
+// union: its leaves are chained through VoxelRecord::pad), the 80-byte f64 records otherwise.
+int records_for_eval(ndt_handle* h, EvalConsts* ec, const VoxelRecord** rec) {
+  ec->packed = 0;
+  *rec = h->rec.p;
+  if (h->record_format != NDT_RECORDS_PACKED48 || h->multi_active) return NDT_OK;
+  if (!h->prec_valid) {
+    int rc = pack_records(h, true);  // (the format was selected after the build, or the table came from another path)
+    if (rc) return rc;
+  }
+  ec->packed = 1;
+  *rec = reinterpret_cast<const VoxelRecord*>(h->prec.p);
+  return NDT_OK;
+}
+
 int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, size_t n) {
   h->have_grid = false;
   h->multi_active = false;
@@ -580,6 +611,12 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
   h->grid_dirty_slots = h->n_slots;
   h->n_valid = h->small.h[9];
   h->have_grid = true;
+  h->prec_valid = false;
+  if (h->record_format == NDT_RECORDS_PACKED48) {
+    // behind the build on its stream; the first evaluation of an align is an ordinary launch on the same stream
+    int rc = pack_records(h, false);
+    if (rc) return rc;
+  }
   return NDT_OK;
 }
 
@@ -776,8 +813,11 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
   fill_pose_consts(p, T, &pc);
   EvalConsts ec = make_eval_consts(h, need_h);
   ec.score_only = score_only ? 1 : 0;
+  const VoxelRecord* records = nullptr;
   {
-    int rc = ensure_partials(h, derivs_partials_words(h->n_src, 1));
+    int rc = records_for_eval(h, &ec, &records);
+    if (rc) return rc;
+    rc = ensure_partials(h, derivs_partials_words(h->n_src, 1));
     if (rc) return rc;
   }
   HIP_TRY(h, h->result.ensure(EV_WORDS));
@@ -847,7 +887,7 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
     buf = (h->flag_toggle ^= 1);
     h->cur_on2 = 0;
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, s));
-    launch_derivatives(px, py, pz, h->n_src, h->geom, h->cell2leaf.p, h->rec.p, h->cent.p, pc, nullptr, 1, ec, h->partials.p,
+    launch_derivatives(px, py, pz, h->n_src, h->geom, h->cell2leaf.p, records, h->cent.p, pc, nullptr, 1, ec, h->partials.p,
                        h->counters.p, d_out, s, spin ? h->flag.d + (size_t)buf * 2 * EV_WORDS : nullptr, seq, nullptr,
                        xinfo, xround);
     HIP_TRY(h, hipGetLastError());
@@ -888,7 +928,7 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
     }
     h->pre_on2 = in_flight_resident ? (h->cur_on2 ^ 1) : h->cur_on2;
     if (in_flight_resident) h->n_prelaunch_overlapped++;
-    launch_derivatives(px, py, pz, h->n_src, h->geom, h->cell2leaf.p, h->rec.p, h->cent.p, pc, nullptr, 1, ec, h->partials.p,
+    launch_derivatives(px, py, pz, h->n_src, h->geom, h->cell2leaf.p, records, h->cent.p, pc, nullptr, 1, ec, h->partials.p,
                        h->counters.p, d_out, h->pre_on2 ? h->stream2 : s, h->flag.d + (size_t)h->pre_buf * 2 * EV_WORDS,
                        h->pre_seq, h->mbox, xinfo, h->pre_round, h->arrive_ctr.p + h->pre_buf, h->arrived.d + h->pre_buf);
     HIP_TRY(h, hipGetLastError());
@@ -1089,7 +1129,7 @@ int ndt_destroy(ndt_handle* h) {
   h->tx.release(); h->ty.release(); h->tz.release();
   h->keys.release(); h->vals.release(); h->keys2.release(); h->vals2.release();
   h->sort_tmp.release(); h->nleaf.release(); h->leaf_start.release(); h->leaf_cnt.release();
-  h->cell2leaf.release(); h->rec.release(); h->cent.release(); h->stats.release();
+  h->cell2leaf.release(); h->rec.release(); h->prec.release(); h->prec_valid = false; h->cent.release(); h->stats.release();
   h->run_counts.release(); h->run_offsets.release(); h->fin_counts.release(); h->bucket_off.release(); h->bnd.release(); h->upl_tmp.release(); h->sort_tags.release(); h->run_tags.release(); h->xyz4.release(); h->leaf_sums.release();
   h->brows.release(); h->tickets.release(); h->gd.release(); h->gdh.release();
   for (auto& kv : h->keyframes) { kv.second.x.release(); kv.second.y.release(); kv.second.z.release(); }
@@ -1244,6 +1284,18 @@ int ndt_source_changed(ndt_handle* h) {
   h->src_sorted = false;
   return NDT_OK;
 }
+
+// 48-byte packed voxel records (f64 mean, f32 inverse covariance) instead of the 80-byte f64 ones: three 16-byte
+// loads per neighbour instead of five.  Takes effect at the next evaluation; the statistics the engine exports
+// (ndt_get_leaves) are the f64 ones either way.
+int ndt_set_record_format(ndt_handle* h, int format) {
+  if (!h) return NDT_ERR_INVALID_ARG;
+  if (format != NDT_RECORDS_F64 && format != NDT_RECORDS_PACKED48) return fail(h, NDT_ERR_INVALID_ARG, "unknown record format");
+  h->record_format = format;
+  return NDT_OK;
+}
+
+int ndt_get_record_format(const ndt_handle* h) { return h ? h->record_format : NDT_ERR_INVALID_ARG; }
 
 // ---- multi-grid target [RECALLED: tier4 ndt_omp multigrid_ndt_omp.h / multi_voxel_grid_covariance_omp.h,
 // named by the reference's build (CMakeLists.txt:41-42), sources in the absent submodule] ----------
@@ -1401,6 +1453,7 @@ int ndt_multigrid_create_kdtree(ndt_handle* h) {
   h->tm.ms_last_build = h->ms_build;
   h->have_grid = true;
   h->multi_active = true;
+  h->prec_valid = false;
   return NDT_OK;
 }
 
@@ -1578,6 +1631,9 @@ static int eval_batch(ndt_handle* h, const double* poses6, const float* transfor
   if (fast) _mm_sfence();  // the write-combined BAR stores are on their way before the doorbell rings
   EvalConsts ec = make_eval_consts(h, compute_hessian != 0);
   ec.score_only = score_only ? 1 : 0;
+  const VoxelRecord* records = nullptr;
+  rc = records_for_eval(h, &ec, &records);
+  if (rc) return rc;
   rc = ensure_partials(h, derivs_partials_words(h->n_src, K));
   if (rc) return rc;
   HIP_TRY(h, h->result.ensure((size_t)K * EV_WORDS));
@@ -1593,7 +1649,7 @@ static int eval_batch(ndt_handle* h, const double* poses6, const float* transfor
   const unsigned long long seq = g_launch_seq.fetch_add(1, std::memory_order_relaxed);
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, s));
   launch_derivatives(h->src_sorted ? h->ox.p : h->vx, h->src_sorted ? h->oy.p : h->vy,
-                     h->src_sorted ? h->oz.p : h->vz, h->n_src, h->geom, h->cell2leaf.p, h->rec.p, h->cent.p,
+                     h->src_sorted ? h->oz.p : h->vz, h->n_src, h->geom, h->cell2leaf.p, records, h->cent.p,
                      h->hposes.h[0], fast ? h->bposes : h->dposes.p, K, ec, h->partials.p, h->counters.p, h->dres.p, s,
                      fast ? h->flag.d : nullptr, seq);
   HIP_TRY(h, hipGetLastError());

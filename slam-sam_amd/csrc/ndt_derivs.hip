@@ -180,6 +180,21 @@ struct RigidRT {
   float t[3];
 };
 
+// One voxel record into registers, from the 80-byte f64 table or the 48-byte packed one (`packed` is uniform over
+// the launch: a scalar branch).  The pair arithmetic is the same f64 code either way.
+__device__ __forceinline__ VoxelRecord fetch_record(const VoxelRecord* __restrict__ rec, int i, bool packed) {
+  if (packed) {
+    const PackedRecord p = reinterpret_cast<const PackedRecord*>(rec)[i];
+    VoxelRecord r;
+    r.mean[0] = p.mean[0]; r.mean[1] = p.mean[1]; r.mean[2] = p.mean[2];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) r.icov[k] = (double)p.icov[k];
+    r.pad = -1.0;
+    return r;
+  }
+  return rec[i];
+}
+
 // Record fetch of the DIRECT7 pair loop.  Two timing-only ablations (wrong results; `make VARIANT=ab EXTRA=-DNDT_ABL=..`):
 // 4: every lane reads record 0 (35 coalesced instead of 35 divergent 16-byte loads per lane) -- what divergence costs;
 // 5: 48 of the 80 bytes (three 16-byte loads instead of five) -- what a packed 48-byte record could save.
@@ -197,12 +212,14 @@ __device__ __forceinline__ VoxelRecord load_rec48(const VoxelRecord* __restrict_
 }
 #define NDT_LOAD_REC(s) load_rec48(rec, (s) >= 0 ? (s) : 0)
 #else
-#define NDT_LOAD_REC(s) rec[(s) >= 0 ? (s) : 0]
+#define NDT_LOAD_REC(s) fetch_record(rec, (s) >= 0 ? (s) : 0, PACKED)
 #endif
 
 // Phase 1 of a point: transform, neighbour lookup, pair sums.  Needs only R|t.
 // D7: DIRECT7 (centre + 6 face neighbours); otherwise DIRECT1 (the point's own voxel only).
-template <int MODE, bool D7>
+// PACKED: the record table is PackedRecord[] (compile time here: as a run-time choice the seven pipelined fetches
+// of DIRECT7 merged both formats' registers and spilled 48-140 bytes per lane)
+template <int MODE, bool D7, bool PACKED>
 __device__ __forceinline__ void point_pairs(PairAcc& a, float x, float y, float z, const GridGeom& g,
                                             const int* __restrict__ cell2leaf,
                                             const VoxelRecord* __restrict__ rec, const RigidRT& P,
@@ -258,7 +275,7 @@ __device__ __forceinline__ void point_pairs(PairAcc& a, float x, float y, float 
   }
   if (!D7) {  // DIRECT1 (ref: getNeighborhoodAtPoint1, voxel_grid_covariance_impl.hpp:604-615)
     const int slot0 = (finite && cell[0] >= 0) ? cell2leaf[cell[0]] : -1;
-    const VoxelRecord r0 = rec[slot0 >= 0 ? slot0 : 0];
+    const VoxelRecord r0 = fetch_record(rec, slot0 >= 0 ? slot0 : 0, PACKED);
     pair_update<MODE>(a, r0, xt, yt, zt, ec, slot0 >= 0);
     return;
   }
@@ -470,17 +487,17 @@ __device__ __forceinline__ void point_pairs_kd(PairAcc& a, float x, float y, flo
     const bool have = j < count;
     if (!CHAIN) {
       const int sl = have ? lds_list[j * stride + (int)threadIdx.x] : 0;
-      const VoxelRecord r = rec[sl];
+      const VoxelRecord r = fetch_record(rec, sl, !CHAIN && ec.packed != 0);
       pair_update<MODE>(a, r, xt, yt, zt, ec, have);  // (KDTREE: only centroids within the radius were listed)
     } else if (RADIUS && filtered) {
       const int sl = have ? lds_list[j * stride + (int)threadIdx.x] : 0;
-      const VoxelRecord r = rec[sl];
+      const VoxelRecord r = fetch_record(rec, sl, !CHAIN && ec.packed != 0);
       pair_update<MODE>(a, r, xt, yt, zt, ec, have);
     } else {
       int sl = have ? lds_list[j * stride + (int)threadIdx.x] : -1;
       while (__ballot(sl >= 0) != 0ull) {  // every lane of the wave leaves together
         const bool live = sl >= 0;
-        const VoxelRecord r = rec[live ? sl : 0];
+        const VoxelRecord r = fetch_record(rec, live ? sl : 0, !CHAIN && ec.packed != 0);
         const bool present = live && (!RADIUS || kd_within(r, xt, yt, zt, ec.kd_radius2));
         pair_update<MODE>(a, r, xt, yt, zt, ec, present);
         sl = live ? (int)r.pad : -1;
@@ -828,7 +845,8 @@ constexpr unsigned int KERNARG_TABLES_OFFSET = offsetof(DerivKernArgs, pose) + o
 static_assert(offsetof(PoseConsts, hang) == offsetof(PoseConsts, jang) + 24 * sizeof(float) &&
               offsetof(AngleTables, hang) == 24 * sizeof(float), "jang / hang must be contiguous");
 
-// NB: neighbourhood -- 0 DIRECT1, 1 DIRECT7, 2 KDTREE, 3 DIRECT26
+// NB: neighbourhood -- 0 DIRECT1, 1 DIRECT7, 2 KDTREE, 3 DIRECT26, 4 multi-grid union; 5 / 6: DIRECT1 / DIRECT7 on the
+// 48-byte packed record table (KDTREE / DIRECT26 take the format as a run-time flag, EvalConsts::packed)
 // MBOX (single-pose only): a pre-launched evaluation -- the pose is not in the kernel arguments
 // (it did not exist yet when the launch was enqueued) but arrives in *mbox, see PoseMailbox.
 template <bool BATCH, int MODE, int NB, bool MBOX>
@@ -983,7 +1001,7 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
 #pragma unroll
   for (int k = 0; k < 6; ++k) a.S[k] = 0.0;
   a.score = 0.0; a.best = 0.0; a.npairs = 0;
-  if (NB >= 2) {
+  if (NB >= 2 && NB <= 4) {
     // every lane takes part (wave-wide trip count): lanes beyond n run with nothing to add
     extern __shared__ int lds_kd_list[];  // KD_CELLS x blockDim.x leaf indices
     if (!(MBOX && ec.mbox_preload) && i < n) { x = sx[i]; y = sy[i]; z = sz[i]; }
@@ -993,7 +1011,7 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
     if (!(MBOX && ec.mbox_preload)) { x = sx[i]; y = sy[i]; z = sz[i]; }
     NDT_STAMP(1);
 #if !(defined(NDT_ABL) && NDT_ABL == 3)
-    point_pairs<MODE, NB == 1>(a, x, y, z, g, cell2leaf, rec, rt, ec);
+    point_pairs<MODE, NB == 1 || NB == 6, NB >= 5>(a, x, y, z, g, cell2leaf, rec, rt, ec);
 #endif
   }
   NDT_STAMP(2);
@@ -1134,8 +1152,9 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
   ecl.single_level_max = deriv_single_level_max();
   ecl.fixed_summer = deriv_fixed_summer();
   ecl.dedicated_summer = derivs_dedicated_summer(n_src, d_poses ? K : 1);
-  const int nb = ec.multigrid ? 4 : (ec.kdtree ? 2 : (ec.direct26 ? 3 : (ec.direct7 ? 1 : 0)));
-  const size_t dyn_lds = nb >= 2 ? (size_t)KD_CELLS * threads * sizeof(int) : 0;
+  if (ec.multigrid) ecl.packed = 0;  // (the union's leaves are chained through VoxelRecord::pad: 80-byte records only)
+  const int nb = ec.multigrid ? 4 : (ec.kdtree ? 2 : (ec.direct26 ? 3 : (ec.direct7 ? (ecl.packed ? 6 : 1) : (ecl.packed ? 5 : 0))));
+  const size_t dyn_lds = nb >= 2 && nb <= 4 ? (size_t)KD_CELLS * threads * sizeof(int) : 0;
 #define NDT_LAUNCH2(B, M, NBH, MB, GY, FLAG, SEQ)                                                            \
   hipLaunchKernelGGL((k_derivatives<B, M, NBH, MB>), dim3(blocks, GY), dim3(threads), dyn_lds, s, sx, sy, sz,  \
                      (int)n_src, g, cell2leaf, rec, reinterpret_cast<const float4*>(cent4), pose, d_poses, ecl, d_partials, d_counters, d_out,         \
@@ -1158,7 +1177,9 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
     else if (nb == 1) NDT_LAUNCH_MODE(B, 1, GY, FLAG, SEQ);     \
     else if (nb == 2) NDT_LAUNCH_MODE(B, 2, GY, FLAG, SEQ);     \
     else if (nb == 3) NDT_LAUNCH_MODE(B, 3, GY, FLAG, SEQ);     \
-    else NDT_LAUNCH_MODE(B, 4, GY, FLAG, SEQ);                  \
+    else if (nb == 4) NDT_LAUNCH_MODE(B, 4, GY, FLAG, SEQ);     \
+    else if (nb == 5) NDT_LAUNCH_MODE(B, 5, GY, FLAG, SEQ);     \
+    else NDT_LAUNCH_MODE(B, 6, GY, FLAG, SEQ);                  \
   } while (0)
   if (d_poses) NDT_LAUNCH_NB(true, K, d_flag, seq);
   else NDT_LAUNCH_NB(false, 1, d_flag, seq);
@@ -1166,6 +1187,24 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
 #undef NDT_LAUNCH_MODE
 #undef NDT_LAUNCH
 #undef NDT_LAUNCH2
+}
+
+namespace {
+__global__ void __launch_bounds__(256) k_pack_records(const VoxelRecord* __restrict__ rec, PackedRecord* __restrict__ out, int n) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= n) return;
+  const VoxelRecord r = rec[i];
+  PackedRecord p;
+  p.mean[0] = r.mean[0]; p.mean[1] = r.mean[1]; p.mean[2] = r.mean[2];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) p.icov[k] = (float)r.icov[k];  // round to nearest even, like the reference's c_inv4 cast
+  out[i] = p;
+}
+}  // namespace
+
+void launch_pack_records(const VoxelRecord* rec, PackedRecord* out, size_t n, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_pack_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rec, out, (int)n);
 }
 
 void launch_transform(const float* sx, const float* sy, const float* sz, size_t n,

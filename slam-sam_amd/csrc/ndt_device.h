@@ -64,6 +64,16 @@ struct LeafStats {
   double evals[3];
 };
 
+// The same record packed into 48 bytes: the mean stays f64 (x' - mu loses nothing), the inverse
+// covariance is rounded to f32 -- what the reference's own per-pair gradient / Hessian arithmetic does with it
+// (c_inv4, svn_ndt_impl.hpp:449-456); only the score's Mahalanobis term sees an f32 matrix where the reference keeps
+// f64 (6e-8 relative).  Three 16-byte loads per neighbour instead of five.  ndt_set_record_format().
+struct alignas(16) PackedRecord {
+  double mean[3];
+  float icov[6];  // xx xy xz yy yz zz
+};
+static_assert(sizeof(PackedRecord) == 48, "three 16-byte loads");
+
 // Pose-dependent constants of one derivative evaluation.  Passed by value as a
 // kernel argument (K = 1) or read from a device array (pose batches).
 struct PoseConsts {
@@ -115,6 +125,7 @@ struct EvalConsts {
   int mbox_tagged;  // pre-launched kernels: 1 = the pose arrives as tagged 8-byte granules, 0 = words then sequence number
   int mbox_preload; // pre-launched kernels: 1 = the point is fetched before the wait for the pose
   int multigrid;   // 1: the table is a union of grids (radius search, leaves of a cell chained through VoxelRecord::pad)
+  int packed;      // 1: the kernel's `rec` argument points at PackedRecord[] (48 bytes per leaf) instead of VoxelRecord[]
 };
 
 // layout of one evaluation (matches NDT_EVAL_WORDS in include/ndt_hip.h)

@@ -147,6 +147,10 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
                         // `seq` once every block of the launch is resident
                         unsigned int* d_arrive_ctr = nullptr, unsigned long long* d_arrived_host = nullptr);
 
+// The 80-byte records of leaf slots [0, n) as 48-byte PackedRecords (f64 mean, f32 inverse covariance); a launch
+// whose EvalConsts::packed is set takes that array in place of `rec`.
+void launch_pack_records(const VoxelRecord* rec, PackedRecord* out, size_t n, hipStream_t s);
+
 void launch_transform(const float* sx, const float* sy, const float* sz, size_t n,
                       const PoseConsts& pose, float* out_xyz, hipStream_t s);
 

@@ -9,6 +9,7 @@ pkg = ge.load_package(); S = pkg.synth
 tag = sys.argv[1] if len(sys.argv) > 1 else ""
 cfg = S.config_c3()
 ndt = pkg.NormalDistributionsTransform(device_id=0, resolution=0.5, step_size=0.1, trans_epsilon=1e-4, max_iterations=35)
+if os.environ.get("NDT_ABL_PACKED") == "1": ndt.setRecordFormat(pkg.RECORDS_PACKED48)
 ndt.setInputTarget(cfg["target"]); ndt.setInputSource(cfg["source"])
 import importlib
 p = np.array(S.matrix_to_pose(cfg["gt"]) if hasattr(S, "matrix_to_pose") else importlib.import_module("oracle.oracle").matrix_to_pose(cfg["gt"]), np.float64)

@@ -504,3 +504,64 @@ def test_viewed_source_rewritten_in_place(pkg, S, hipmem):
         hipmem.write(ptr[a], src_a[:, a])
     ndt.setInputSourceDeviceView(ptr[0], ptr[1], ptr[2], len(src_a))
     assert np.array_equal(ndt.align(cfg["guess"]), Ta)
+
+
+def test_packed_voxel_records(pkg, O, S):
+    """ndt_set_record_format(NDT_RECORDS_PACKED48): 48-byte records (f64 mean, inverse covariance rounded to f32 --
+    the reference's own c_inv4 for the per-pair gradient / Hessian products).  Same pairs (counts exact); score,
+    gradient and Hessian within 1e-6 of the f64 records' (measured ~1e-7: the f32 rounding of the matrix) and of the
+    oracle; align ends on the same pose within the convergence threshold and within 1 mm of the oracle's, iterations within one; batched ==
+    single launches bit for bit; selecting the format before or after the build gives the same bits; the exported
+    leaf statistics stay the f64 ones."""
+    for cfg, res in ((S.config_c1(), 1.0), (S.config_c2(), 1.0)):
+        kw = dict(KW, resolution=res)
+        p0, pg = O.matrix_to_pose(cfg["guess"]), O.matrix_to_pose(cfg["gt"])
+        poses = np.stack([p0, pg])
+        for method, omethod in ((pkg.DIRECT7, O.DIRECT7), (pkg.DIRECT1, O.DIRECT1), (pkg.KDTREE, O.KDTREE), (pkg.DIRECT26, O.DIRECT26)):
+            grid = O.Grid(cfg["target"], O.default_params(search_method=omethod, num_threads=8, **kw))
+            a = _ndt(pkg, search_method=method, resolution=res)
+            b = _ndt(pkg, search_method=method, resolution=res)
+            b.setRecordFormat(pkg.RECORDS_PACKED48)           # before the build: packed behind it
+            assert b.getRecordFormat() == pkg.RECORDS_PACKED48 and a.getRecordFormat() == pkg.RECORDS_F64
+            for n in (a, b):
+                n.setInputTarget(cfg["target"])
+                n.setInputSource(cfg["source"])
+            la, lb = a.getLeaves(), b.getLeaves()
+            for f in ("cell", "count", "mean", "cov", "icov"):
+                assert np.array_equal(la[f], lb[f]), f
+            ea, eb = a.evalDerivatives(poses), b.evalDerivatives(poses)
+            for p, x, y in zip(poses, ea, eb):
+                assert x["n_pairs"] == y["n_pairs"] and x["n_with_neighbors"] == y["n_with_neighbors"]
+                assert y["score"] == pytest.approx(x["score"], rel=1e-6)
+                assert y["score"] != x["score"]              # (the packed table is what was read)
+                gn, hn = np.linalg.norm(x["gradient"]), np.linalg.norm(x["hessian"])
+                assert np.linalg.norm(y["gradient"] - x["gradient"]) <= 1e-6 * gn + 1e-9
+                assert np.linalg.norm(y["hessian"] - x["hessian"]) <= 1e-6 * hn + 1e-9
+                d = grid.derivatives(cfg["source"], p)
+                assert y["n_pairs"] == d["n_pairs"] and y["score"] == pytest.approx(d["score"], rel=1e-6)
+                assert np.linalg.norm(y["gradient"] - d["gradient"]) <= 2e-6 * np.linalg.norm(d["gradient"]) + 1e-9
+            # batched launch == single launches, bit for bit, on the packed table too
+            for p, y in zip(poses, eb):
+                one = b.evalDerivatives(p)[0]
+                assert one["score"] == y["score"] and np.array_equal(one["hessian"], y["hessian"])
+            # format selected AFTER the build: packed on demand, same bits
+            a.setRecordFormat(pkg.RECORDS_PACKED48)
+            for x, y in zip(a.evalDerivatives(poses), eb):
+                assert x["score"] == y["score"] and np.array_equal(x["gradient"], y["gradient"]) and np.array_equal(x["hessian"], y["hessian"])
+            a.setRecordFormat(pkg.RECORDS_F64)
+            for x, y in zip(a.evalDerivatives(poses), ea):
+                assert x["score"] == y["score"] and np.array_equal(x["hessian"], y["hessian"])
+            Ta = a.align(cfg["guess"]); ra = a.getResult()
+            Tb = b.align(cfg["guess"]); rb = b.getResult()
+            dt, dr = S.pose_error(Ta, Tb)
+            # (both stop once a step is shorter than trans_epsilon = 1e-4 m: the end poses agree to that, not better)
+            assert dt < 2e-4 and dr < 1e-5 and abs(ra["iterations"] - rb["iterations"]) <= 1, (method, dt, dr)
+            ref = grid.align(cfg["source"], cfg["guess"])
+            dt, dr = S.pose_error(Tb, ref["T"])
+            assert dt < 1e-3 and dr < 1e-4, (method, dt, dr)
+            # a second target through the same engine: the packed copy follows the rebuild
+            b.setInputTarget(cfg["target"][::2])
+            a.setInputTarget(cfg["target"][::2])
+            x, y = a.evalDerivatives(pg)[0], b.evalDerivatives(pg)[0]
+            assert x["n_pairs"] == y["n_pairs"] and y["score"] == pytest.approx(x["score"], rel=1e-6) and y["score"] != x["score"]
+            a.close(); b.close()

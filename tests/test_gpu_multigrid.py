@@ -58,6 +58,12 @@ def test_union_is_the_sum_of_the_grids(pkg, O, S):
             rg, rh = np.linalg.norm(d["gradient"] - x["gradient"]), np.linalg.norm(d["hessian"] - x["hessian"])
             assert np.linalg.norm(e["gradient"] - d["gradient"]) <= 1.01 * rg + 1e-9 * gn + 1e-9
             assert np.linalg.norm(e["hessian"] - d["hessian"]) <= 1.01 * rh + 1e-9 * hn + 1e-9
+        # the packed 48-byte record format does not apply to a union (its leaves are chained through the 80-byte
+        # record): selecting it changes no bit
+        ndt.setRecordFormat(pkg.RECORDS_PACKED48)
+        for e, e48 in zip(got, ndt.evalDerivatives(poses)):
+            assert e48["score"] == e["score"] and np.array_equal(e48["hessian"], e["hessian"])
+        ndt.setRecordFormat(pkg.RECORDS_F64)
         sc = ndt.scoreTransform(O.pose_to_matrix(poses[0]))
         assert sc["score"] == got[0]["score"] and sc["n_pairs"] == got[0]["n_pairs"]
     # align on the union converges to the ground truth like the single-grid target does
