@@ -131,7 +131,7 @@ struct ndt_handle {
   int n_cus = 0;                      // compute units of the device (a fused sort pass needs one per tile)
   DevBuf<double> leaf_sums;
   DevBuf<int> brows;                 // per-block bounds rows
-  DevBuf<unsigned int> tickets;      // [0] bounds, [1] run-count, [2] finalize kernel; zero between launches
+  DevBuf<unsigned int> tickets;      // [0] bounds, [1] run-count, [2] finalize kernel, [4..5] the two-launch build's 64-bit tail word; zero between launches
   DevBuf<BuildGeom> gd;              // geometry + sort plan of the build, derived on the device
   PinBuf<BuildGeom> gdh;             // ... and its host-visible copy
   DevBuf<float> xyz4;                // packed float4 copy of the target for the gather
@@ -416,7 +416,7 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
   HIP_TRY(h, h->gd.ensure(1));
   HIP_TRY(h, h->gdh.ensure(1));
   if (!h->tickets.p) {
-    HIP_TRY(h, h->tickets.ensure(3));
+    HIP_TRY(h, h->tickets.ensure(6));
     HIP_TRY(h, hipMemsetAsync(h->tickets.p, 0, h->tickets.cap * sizeof(unsigned int), s));
   }
   HIP_TRY(h, h->nleaf.ensure(4));  // [0] slots, [1] valid, [2] buckets that declined (two-launch build)
@@ -484,7 +484,7 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
       FinalizeParams fpb{h->prm.eig_inflation_ratio, h->prm.cov_mode};
       HIP_TRY(h, launch_bucket_build(x, y, z, n, leaf, inv_leaf, cap_cells, min_pts, fpb, h->gd.p, h->gdh.d, h->sort_tags.p,
                                      &h->sort_seq, h->stats.p, dirty_slots, h->cell2leaf.p, h->cell2leaf.cap, h->bnd.p,
-                                     h->bucket_off.p, h->nleaf.p, h->tickets.p + 2, h->xyz4.p, h->leaf_sums.p, h->rec.p,
+                                     h->bucket_off.p, h->nleaf.p, h->tickets.p + 4, h->xyz4.p, h->leaf_sums.p, h->rec.p,
                                      h->cent.p, h->stats.p, max_leaves, h->small.d + 8, done_tag, s));
     } else {
     launch_bounds_geometry(x, y, z, n, leaf, inv_leaf, cap_cells, passes, h->brows.p, h->tickets.p, h->gd.p, h->gdh.d,

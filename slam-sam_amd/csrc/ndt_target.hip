@@ -1667,7 +1667,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __re
                                                              float inv_leaf, long long cell_capacity, int min_pts,
                                                              FinalizeParams fp, BuildGeom* __restrict__ gd,
                                                              BuildGeom* __restrict__ gd_host, int* __restrict__ d_nleaf,
-                                                             unsigned int* __restrict__ ticket, double* __restrict__ sums,
+                                                             unsigned long long* __restrict__ tail, double* __restrict__ sums,
                                                              VoxelRecord* __restrict__ rec, float4* __restrict__ cent,
                                                              LeafStats* __restrict__ stats,
                                                              int* __restrict__ cell2leaf, int max_leaves,
@@ -1687,7 +1687,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __re
   __shared__ int dbase[SORT_BINS];
   __shared__ int wsum[BK_WAVES];
   __shared__ int wave_head[BK_WAVES], wave_total[BK_WAVES];
-  __shared__ int s_base, s_ok, s_last, s_decline;
+  __shared__ int s_base, s_ok, s_decline;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int bucket = blockIdx.x;
   NDT_BSTAMP(5, 0);
@@ -1973,10 +1973,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __re
       leaves[li0++] = L;
     }
   // this block's leaf slots: the atomic's round trip runs under the first batch of sums
-  if (threadIdx.x == 0) {
-    s_base = nl > 0 ? atomicAdd(&d_nleaf[0], nl) : 0;
-    if (decline) atomicAdd(&d_nleaf[2], 1);
-  }
+  if (threadIdx.x == 0) s_base = nl > 0 ? atomicAdd(&d_nleaf[0], nl) : 0;
   __syncthreads();   // leaf list complete (s_base is read behind the next barrier only)
   NDT_BSTAMP(5, 4);  // runs found
   NDT_WSTAMP(0);
@@ -2063,30 +2060,30 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __re
   __syncthreads();
   NDT_BSTAMP(5, 6);  // statistics written
   if (threadIdx.x == 0) {
-    // every add of this block has RETURNED before the ticket is drawn: the block that draws the last one reads
-    // totals that include every block's
-    int seen = 0;
-    if (s_ok) seen = atomicAdd(&d_nleaf[1], s_ok);
-    asm volatile("" ::"v"(seen), "v"(slot0));
-    __builtin_amdgcn_s_waitcnt(0);
-    const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = t == gridDim.x - 1u ? 1 : 0;
-    if (s_last) {
-      const int slots = __hip_atomic_load(&d_nleaf[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int valid = __hip_atomic_load(&d_nleaf[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ONE 64-bit atomic ends the block: its ticket and its contributions to the launch's totals travel together, so
+    // the block that draws the last ticket holds every block's counts in the returned value -- {ticket : 11 | buckets
+    // that declined : 9 | accepted leaves : 22 | leaf slots : 22}.  (Until round 3: an add for the accepted leaves,
+    // wait, the ticket, wait, three loads of the totals -- three round trips at the very end of the build.)
+    const unsigned long long add = (1ull << 53) | ((unsigned long long)(decline ? 1u : 0u) << 44) |
+                                   ((unsigned long long)(unsigned int)s_ok << 22) | (unsigned long long)(unsigned int)nl;
+    const unsigned long long prev = __hip_atomic_fetch_add(tail, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((prev >> 53) == (unsigned long long)gridDim.x - 1ull) {
+      const unsigned long long total = prev + add;
+      const int slots = (int)(total & 0x3fffffull), valid = (int)((total >> 22) & 0x3fffffull);
       // a bucket with more distinct cells than its table holds declined AFTER other blocks had published leaves:
       // the host repeats the build sort-based on a cleared grid
       BuildGeom lg;
       derive(&lg);
-      if (__hip_atomic_load(&d_nleaf[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) lg.status = BG_BUCKET;
+      if (((total >> 44) & 0x1ffull) != 0ull) lg.status = BG_BUCKET;
       *gd = lg;
       *gd_host = lg;
       reset_bounds_words(bnd);   // every block read them at its entry, long ago: neutral again for the next build
+      d_nleaf[1] = valid;
       nleaf_host[0] = slots;
       nleaf_host[1] = valid;
       // geometry and counts first, the tag the host polls for last (see above)
       __hip_atomic_store(nleaf_host + 2, done_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(tail, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -2518,7 +2515,8 @@ hipError_t launch_bucket_build(const float* x, const float* y, const float* z, s
                      tag, mute_tile, gd, gd_host, old_stats, dirty_slots, cell2leaf, c2l_cap, bnd, bucket_off, d_nleaf,
                      reinterpret_cast<float4*>(pts4));
   hipLaunchKernelGGL(k_bucket_leaves, dim3(BK_BUCKETS), dim3(BK_THREADS), 0, s, reinterpret_cast<const float4*>(pts4),
-                     bucket_off, bnd, leaf, inv_leaf, cell_capacity, min_pts, fp, gd, gd_host, d_nleaf, ticket, sums,
+                     bucket_off, bnd, leaf, inv_leaf, cell_capacity, min_pts, fp, gd, gd_host, d_nleaf,
+                     reinterpret_cast<unsigned long long*>(ticket) /* 8-byte aligned, zero between builds */, sums,
                      rec, reinterpret_cast<float4*>(cent4), stats, cell2leaf, max_leaves, nleaf_host, done_tag);
   return hipGetLastError();
 }
