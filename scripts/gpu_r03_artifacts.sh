@@ -28,6 +28,11 @@ python3 $R/scripts/pmc_summary.py $P > $OUT/pmc_summary.txt 2>&1
 rm -rf $OUT/prof/*/*trace* 2>/dev/null
 find $P -name "*kernel_trace.csv" -delete; find $P -name "*agent_info.csv" -delete
 cd $R
+timeout -k 10 300 python tests/gpu_soak.py 2>&1 | grep -v amdgpu.ids | tail -8 > $OUT/soak.txt
+timeout -k 10 200 python tests/gpu_mbox_stress.py 3000 2>&1 | grep -v amdgpu.ids | tail -3 > $OUT/mbox_stress.txt
+timeout -k 10 300 python tests/gpu_build_stress.py 150 2>&1 | grep -v amdgpu.ids | tail -3 > $OUT/build_stress.txt
+timeout -k 10 120 python tests/gpu_abl_bench.py "f64 records" 2>&1 | grep -v amdgpu.ids > $OUT/packed.txt
+NDT_ABL_PACKED=1 timeout -k 10 120 python tests/gpu_abl_bench.py "packed 48-byte records" 2>&1 | grep -v amdgpu.ids >> $OUT/packed.txt
 make -C $R/slam-sam_amd/csrc VARIANT=stamps -j8 > /dev/null 2>&1
 NDT_HIP_LIB=$R/slam-sam_amd/libndt_hip_stamps.so timeout -k 10 200 python tests/gpu_stamps_prelaunch.py 2>&1 | grep -v amdgpu.ids | tail -9 > $OUT/stamps_prelaunch.txt
 NDT_HIP_LIB=$R/slam-sam_amd/libndt_hip_stamps.so timeout -k 10 200 python tests/gpu_build_stamps.py 2>&1 | grep -v amdgpu.ids | tail -18 > $OUT/build_stamps.txt
