@@ -534,8 +534,8 @@ def main():
                     "iterations_per_align": pk["iters"] / args.steps, "evaluations_per_align": pk["evals"] / args.steps,
                     # compare THIS with the headline's ms_align / evaluations_per_align: the rounded table can move a
                     # line-search decision, and a step with fewer evaluations says nothing about the format
-                    "us_per_evaluation": 1e3 * pk["t_align"] / max(pk["evals"], 1),
-                    "us_per_evaluation_f64_records": 1e3 * res["t_align"] / max(res["evals"], 1),
+                    "us_per_evaluation": 1e6 * pk["t_align"] / max(pk["evals"], 1),
+                    "us_per_evaluation_f64_records": 1e6 * res["t_align"] / max(res["evals"], 1),
                     "final_error_vs_ground_truth": {"m": pk["err_m"], "rad": pk["err_rad"]}}
         hc = host_cloud()
         if out is not None and hc is not None:

@@ -372,7 +372,7 @@ int pack_records(ndt_handle* h, bool wait) {
 int records_for_eval(ndt_handle* h, EvalConsts* ec, const VoxelRecord** rec) {
   ec->packed = 0;
   *rec = h->rec.p;
-  if (h->record_format != NDT_RECORDS_PACKED48 || h->multi_active) return NDT_OK;
+  if (h->record_format != NDT_RECORDS_PACKED48 || h->multi_active || h->n_slots <= 0) return NDT_OK;  // (an empty table: slot 0 of the f64 one is what absent neighbours read)
   if (!h->prec_valid) {
     int rc = pack_records(h, true);  // (the format was selected after the build, or the table came from another path)
     if (rc) return rc;
