@@ -280,8 +280,34 @@ __device__ __forceinline__ void point_pairs(PairAcc& a, float x, float y, float 
     return;
   }
   int slot[7];
+#ifdef NDT_XROW
+  // The centre cell and its two x-neighbours are adjacent ints of the index grid: ONE 12-byte load instead of three
+  // 4-byte ones (five vector-memory instructions per point instead of seven; the grid is readable four ints beyond
+  // either end, IndexGrid in ndt_api.hip).  The +-x probes are classified on their own (same f32 arithmetic as ever),
+  // so a probe whose cell is not the one next to the centre's -- rounding at a voxel face, or a centre outside the
+  // box -- still takes its own load.
+  {
+    struct alignas(4) Int3 { int a, b, c; };
+    const bool row = finite && cell[0] >= 0;
+    Int3 v;
+    v.a = v.b = v.c = -1;
+    if (row) v = *reinterpret_cast<const Int3*>(cell2leaf + (cell[0] - 1));
+    slot[0] = row ? v.b : -1;
+#pragma unroll
+    for (int k = 1; k < 3; ++k) {
+      const int off = cell[k] - (cell[0] - 1);
+      const bool have = finite && cell[k] >= 0;
+      const bool in_row = row && have && off >= 0 && off <= 2;
+      slot[k] = in_row ? (off == 0 ? v.a : (off == 1 ? v.b : v.c)) : -1;
+      if (have && !in_row) slot[k] = cell2leaf[cell[k]];
+    }
+#pragma unroll
+    for (int k = 3; k < 7; ++k) slot[k] = (finite && cell[k] >= 0) ? cell2leaf[cell[k]] : -1;
+  }
+#else
 #pragma unroll
   for (int k = 0; k < 7; ++k) slot[k] = (finite && cell[k] >= 0) ? cell2leaf[cell[k]] : -1;
+#endif
 #if defined(NDT_ABL) && NDT_ABL == 1  // ablation: grid loads kept, no records / pair math
 #pragma unroll
   for (int k = 0; k < 7; ++k) slot[k] = slot[k] == 0x7fffffff ? 0 : -1;
