@@ -239,7 +239,8 @@ int ndt_source_changed(ndt_handle* h);
  * gradient / Hessian arithmetic does with it (c_inv4, svn_ndt_impl.hpp:449-456); only the score's Mahalanobis term
  * sees an f32 matrix where the reference keeps f64.  Derivatives move by ~1e-7 of their norm, the aligned transform
  * by micrometres (tests/test_gpu_features.py); an evaluation fetches three 16-byte pieces per neighbour instead of
- * five.  Not applied to a multi-grid union (its leaves are chained through the 80-byte record).  Takes effect at
+ * five.  Applies to the DIRECT7 / DIRECT1 neighbourhoods; KDTREE, DIRECT26 and a multi-grid union keep reading the
+ * 80-byte records (measured: no gain there; the union chains its leaves through them).  Takes effect at
  * the next evaluation; exported leaf statistics are the f64 ones either way. */
 typedef enum ndt_record_format { NDT_RECORDS_F64 = 0, NDT_RECORDS_PACKED48 = 1 } ndt_record_format;
 int ndt_set_record_format(ndt_handle* h, int format);

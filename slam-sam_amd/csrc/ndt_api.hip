@@ -367,12 +367,15 @@ int pack_records(ndt_handle* h, bool wait) {
   return NDT_OK;
 }
 
-// The record table an evaluation reads: the 48-byte packed copy when that format is selected (not for a multi-grid
-// union: its leaves are chained through VoxelRecord::pad), the 80-byte f64 records otherwise.
+// The record table an evaluation reads: the 48-byte packed copy when that format is selected and the neighbourhood is
+// DIRECT7 / DIRECT1 (a multi-grid union chains its leaves through VoxelRecord::pad; the 27-cell neighbourhoods gained
+// nothing from it), the 80-byte f64 records otherwise.
 int records_for_eval(ndt_handle* h, EvalConsts* ec, const VoxelRecord** rec) {
   ec->packed = 0;
   *rec = h->rec.p;
-  if (h->record_format != NDT_RECORDS_PACKED48 || h->multi_active || h->n_slots <= 0) return NDT_OK;  // (an empty table: slot 0 of the f64 one is what absent neighbours read)
+  if (h->record_format != NDT_RECORDS_PACKED48 || h->multi_active || h->n_slots <= 0 ||
+      (h->prm.search_method != NDT_DIRECT7 && h->prm.search_method != NDT_DIRECT1))
+    return NDT_OK;  // (an empty table: slot 0 of the f64 one is what absent neighbours read)
   if (!h->prec_valid) {
     int rc = pack_records(h, true);  // (the format was selected after the build, or the table came from another path)
     if (rc) return rc;

@@ -180,8 +180,8 @@ struct RigidRT {
   float t[3];
 };
 
-// One voxel record into registers, from the 80-byte f64 table or the 48-byte packed one (`packed` is uniform over
-// the launch: a scalar branch).  The pair arithmetic is the same f64 code either way.
+// One voxel record into registers, from the 80-byte f64 table or the 48-byte packed one (`packed` is a compile-time
+// constant at every call site).  The pair arithmetic is the same f64 code either way.
 __device__ __forceinline__ VoxelRecord fetch_record(const VoxelRecord* __restrict__ rec, int i, bool packed) {
   if (packed) {
     const PackedRecord p = reinterpret_cast<const PackedRecord*>(rec)[i];
@@ -513,17 +513,17 @@ __device__ __forceinline__ void point_pairs_kd(PairAcc& a, float x, float y, flo
     const bool have = j < count;
     if (!CHAIN) {
       const int sl = have ? lds_list[j * stride + (int)threadIdx.x] : 0;
-      const VoxelRecord r = fetch_record(rec, sl, !CHAIN && ec.packed != 0);
+      const VoxelRecord r = rec[sl];
       pair_update<MODE>(a, r, xt, yt, zt, ec, have);  // (KDTREE: only centroids within the radius were listed)
     } else if (RADIUS && filtered) {
       const int sl = have ? lds_list[j * stride + (int)threadIdx.x] : 0;
-      const VoxelRecord r = fetch_record(rec, sl, !CHAIN && ec.packed != 0);
+      const VoxelRecord r = rec[sl];
       pair_update<MODE>(a, r, xt, yt, zt, ec, have);
     } else {
       int sl = have ? lds_list[j * stride + (int)threadIdx.x] : -1;
       while (__ballot(sl >= 0) != 0ull) {  // every lane of the wave leaves together
         const bool live = sl >= 0;
-        const VoxelRecord r = fetch_record(rec, live ? sl : 0, !CHAIN && ec.packed != 0);
+        const VoxelRecord r = rec[live ? sl : 0];
         const bool present = live && (!RADIUS || kd_within(r, xt, yt, zt, ec.kd_radius2));
         pair_update<MODE>(a, r, xt, yt, zt, ec, present);
         sl = live ? (int)r.pad : -1;
@@ -872,7 +872,7 @@ static_assert(offsetof(PoseConsts, hang) == offsetof(PoseConsts, jang) + 24 * si
               offsetof(AngleTables, hang) == 24 * sizeof(float), "jang / hang must be contiguous");
 
 // NB: neighbourhood -- 0 DIRECT1, 1 DIRECT7, 2 KDTREE, 3 DIRECT26, 4 multi-grid union; 5 / 6: DIRECT1 / DIRECT7 on the
-// 48-byte packed record table (KDTREE / DIRECT26 take the format as a run-time flag, EvalConsts::packed)
+// 48-byte packed record table (the 27-cell neighbourhoods always read the 80-byte records)
 // MBOX (single-pose only): a pre-launched evaluation -- the pose is not in the kernel arguments
 // (it did not exist yet when the launch was enqueued) but arrives in *mbox, see PoseMailbox.
 template <bool BATCH, int MODE, int NB, bool MBOX>
@@ -1178,7 +1178,9 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
   ecl.single_level_max = deriv_single_level_max();
   ecl.fixed_summer = deriv_fixed_summer();
   ecl.dedicated_summer = derivs_dedicated_summer(n_src, d_poses ? K : 1);
-  if (ec.multigrid) ecl.packed = 0;  // (the union's leaves are chained through VoxelRecord::pad: 80-byte records only)
+  // DIRECT7 / DIRECT1 only: the union's leaves are chained through VoxelRecord::pad, and in the 27-cell neighbourhoods
+  // the format (as a run-time flag) cost more than the shorter fetch gave back (KDTREE 21.9 -> 22.5 us, DIRECT26 29.1 -> 29.7)
+  if (ec.multigrid || ec.kdtree || ec.direct26) ecl.packed = 0;
   const int nb = ec.multigrid ? 4 : (ec.kdtree ? 2 : (ec.direct26 ? 3 : (ec.direct7 ? (ecl.packed ? 6 : 1) : (ecl.packed ? 5 : 0))));
   const size_t dyn_lds = nb >= 2 && nb <= 4 ? (size_t)KD_CELLS * threads * sizeof(int) : 0;
 #define NDT_LAUNCH2(B, M, NBH, MB, GY, FLAG, SEQ)                                                            \

@@ -8,6 +8,7 @@ for cname, cfg in (("C2", S.config_c2()), ("C3", S.config_c3())):
     for mode in ("DIRECT7", "DIRECT1", "KDTREE", "DIRECT26", "MULTIGRID"):
         ndt = pkg.NormalDistributionsTransform(device_id=0, resolution=float(cfg["resolution"]), step_size=0.1,
                                                trans_epsilon=1e-4, max_iterations=35)
+        if os.environ.get("NDT_MODES_PACKED") == "1": ndt.setRecordFormat(pkg.RECORDS_PACKED48)   # (not applied to MULTIGRID)
         if mode == "MULTIGRID":   # the map as 2 x 2 tiles that overlap by 2 m, united by createVoxelKdtree
             t = cfg["target"]; mx, my = np.median(t[:, 0]), np.median(t[:, 1])
             t0 = time.perf_counter()
