@@ -371,7 +371,9 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_source,
                          "hbm_achieved_from_traffic": (traffic / (ms_kernel * 1e-3) / 1e9) if (traffic and ms_kernel > 0) else None,
-                         "note": "achieved = algorithmic bytes / HIP-event launch duration (SURVEY 8d), measured in an "
+                         "note": "achieved = algorithmic bytes / launch duration (SURVEY 8d) by HIP events ATTACHED TO THE DISPATCH "
+                                 "(hipExtLaunchKernel: the kernel's own begin / end timestamps, the figure rocprofv3 reports; events "
+                                 "recorded around the launch call, as until round 3, add ~2.4 us of dispatch), measured in an "
                                  "instrumented repeat that uses ordinary launches (k_derivatives<..., false>): the "
                                  "pre-launched variant (<..., true>) of the timed steps starts early and its duration "
                                  "includes waiting for the pose.  The table is cache-resident at this size, so real HBM "

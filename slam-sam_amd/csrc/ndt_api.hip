@@ -356,6 +356,14 @@ int upload_soa(ndt_handle* h, const float* xyz, const float* x, const float* y, 
 // capacities the host assumed; ONE synchronisation at the end.  First build, or a cloud that
 // outgrew the buffers: the host waits for the geometry once, allocates, and goes on (as
 // before).  A refused optimistic build (BG_CAPACITY / BG_PASSES) is repeated that way.
+// Kernel timing (ndt_enable_kernel_timing): the two events are attached to the derivative kernel's dispatch, so their
+// difference is the kernel's own duration -- the figure rocprofv3 reports.  NDT_TIMING_BRACKET=1 records them around
+// the launch call instead, as rounds 1-2 did (adds the dispatch, ~2.4 us: the tuning scripts' older numbers).
+bool timing_brackets_launch() {
+  static const bool on = [] { const char* e = getenv("NDT_TIMING_BRACKET"); return e && atoi(e) != 0; }();
+  return on;
+}
+
 // (re)writes the packed copy of the record table; `wait`: the caller is about to launch on another stream
 int pack_records(ndt_handle* h, bool wait) {
   if (h->n_slots <= 0) return NDT_OK;
@@ -889,12 +897,14 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
     seq = g_launch_seq.fetch_add(1, std::memory_order_relaxed);
     buf = (h->flag_toggle ^= 1);
     h->cur_on2 = 0;
-    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, s));
+    const bool bracket = h->timing && timing_brackets_launch();
+    if (bracket) HIP_TRY(h, hipEventRecord(h->ev0, s));
     launch_derivatives(px, py, pz, h->n_src, h->geom, h->cell2leaf.p, records, h->cent.p, pc, nullptr, 1, ec, h->partials.p,
                        h->counters.p, d_out, s, spin ? h->flag.d + (size_t)buf * 2 * EV_WORDS : nullptr, seq, nullptr,
-                       xinfo, xround);
+                       xinfo, xround, nullptr, nullptr, h->timing && !bracket ? h->ev0 : nullptr,
+                       h->timing && !bracket ? h->ev1 : nullptr);
     HIP_TRY(h, hipGetLastError());
-    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, s));
+    if (bracket) HIP_TRY(h, hipEventRecord(h->ev1, s));
   }
   if (p2p) h->red.p2p_set_round(xround);  // this evaluation's tag is spent (a fallback below gives it back)
   if (prelaunch) {
@@ -1650,13 +1660,15 @@ static int eval_batch(ndt_handle* h, const double* poses6, const float* transfor
     HIP_TRY(h, hipMemcpyAsync(h->dposes.p, h->hposes.h, (size_t)K * sizeof(PoseConsts), hipMemcpyHostToDevice, s));
   }
   const unsigned long long seq = g_launch_seq.fetch_add(1, std::memory_order_relaxed);
-  if (h->timing) HIP_TRY(h, hipEventRecord(h->ev0, s));
+  const bool bracket = h->timing && timing_brackets_launch();
+  if (bracket) HIP_TRY(h, hipEventRecord(h->ev0, s));
   launch_derivatives(h->src_sorted ? h->ox.p : h->vx, h->src_sorted ? h->oy.p : h->vy,
                      h->src_sorted ? h->oz.p : h->vz, h->n_src, h->geom, h->cell2leaf.p, records, h->cent.p,
                      h->hposes.h[0], fast ? h->bposes : h->dposes.p, K, ec, h->partials.p, h->counters.p, h->dres.p, s,
-                     fast ? h->flag.d : nullptr, seq);
+                     fast ? h->flag.d : nullptr, seq, nullptr, nullptr, 0ull, nullptr, nullptr,
+                     h->timing && !bracket ? h->ev0 : nullptr, h->timing && !bracket ? h->ev1 : nullptr);
   HIP_TRY(h, hipGetLastError());
-  if (h->timing) HIP_TRY(h, hipEventRecord(h->ev1, s));
+  if (bracket) HIP_TRY(h, hipEventRecord(h->ev1, s));
   if (overlap) overlap(overlap_ctx);
   if (fast) {
     rc = wait_slots(h, seq, K);

@@ -21,6 +21,8 @@
 // round exactly as written to classify points into the same voxels as the ref.
 #include "ndt_kernels.h"
 
+#include <hip/hip_ext.h>
+
 #include <cstddef>
 #include <algorithm>
 #include <cstdlib>
@@ -1170,7 +1172,8 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
                         const EvalConsts& ec, double* d_partials, unsigned int* d_counters,
                         double* d_out, hipStream_t s, unsigned long long* d_flag,
                         unsigned long long seq, const PoseMailbox* d_mbox, const XchgInfo* d_xinfo,
-                        unsigned long long xround, unsigned int* d_arrive_ctr, unsigned long long* d_arrived_host) {
+                        unsigned long long xround, unsigned int* d_arrive_ctr, unsigned long long* d_arrived_host,
+                        hipEvent_t ev_start, hipEvent_t ev_stop) {
   const int blocks = derivs_grid_blocks(n_src, d_poses ? K : 1);
   const int threads = derivs_block_threads(n_src, d_poses ? K : 1);
   const int mode = ec.score_only ? 3 : (!ec.need_hessian ? 0 : (ec.gauss_newton ? 2 : 1));
@@ -1183,10 +1186,19 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
   if (ec.multigrid || ec.kdtree || ec.direct26) ecl.packed = 0;
   const int nb = ec.multigrid ? 4 : (ec.kdtree ? 2 : (ec.direct26 ? 3 : (ec.direct7 ? (ecl.packed ? 6 : 1) : (ecl.packed ? 5 : 0))));
   const size_t dyn_lds = nb >= 2 && nb <= 4 ? (size_t)KD_CELLS * threads * sizeof(int) : 0;
+  // ev_start / ev_stop: events attached to THIS dispatch (hipExtLaunchKernel): they carry the kernel's own begin and
+  // end timestamps, what rocprofv3 reports -- events recorded around the launch include ~2.4 us of dispatch
 #define NDT_LAUNCH2(B, M, NBH, MB, GY, FLAG, SEQ)                                                            \
-  hipLaunchKernelGGL((k_derivatives<B, M, NBH, MB>), dim3(blocks, GY), dim3(threads), dyn_lds, s, sx, sy, sz,  \
-                     (int)n_src, g, cell2leaf, rec, reinterpret_cast<const float4*>(cent4), pose, d_poses, ecl, d_partials, d_counters, d_out,         \
-                     FLAG, SEQ, d_mbox, d_xinfo, xround, d_arrive_ctr, d_arrived_host)
+  do {                                                                                                       \
+    if (ev_start != nullptr)                                                                                 \
+      hipExtLaunchKernelGGL((k_derivatives<B, M, NBH, MB>), dim3(blocks, GY), dim3(threads), (std::uint32_t)dyn_lds, s, ev_start, ev_stop, 0u, sx, sy, sz,  \
+                            (int)n_src, g, cell2leaf, rec, reinterpret_cast<const float4*>(cent4), pose, d_poses, ecl, d_partials, d_counters, d_out,         \
+                            FLAG, SEQ, d_mbox, d_xinfo, xround, d_arrive_ctr, d_arrived_host);                \
+    else                                                                                                     \
+      hipLaunchKernelGGL((k_derivatives<B, M, NBH, MB>), dim3(blocks, GY), dim3(threads), dyn_lds, s, sx, sy, sz,  \
+                         (int)n_src, g, cell2leaf, rec, reinterpret_cast<const float4*>(cent4), pose, d_poses, ecl, d_partials, d_counters, d_out,         \
+                         FLAG, SEQ, d_mbox, d_xinfo, xround, d_arrive_ctr, d_arrived_host);                   \
+  } while (0)
 #define NDT_LAUNCH(B, M, NBH, GY, FLAG, SEQ)                                  \
   do {                                                                         \
     if (!B && d_mbox != nullptr) NDT_LAUNCH2(false, M, NBH, true, GY, FLAG, SEQ);  \

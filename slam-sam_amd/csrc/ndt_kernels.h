@@ -145,7 +145,10 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
                         const XchgInfo* d_xinfo = nullptr, unsigned long long xround = 0ull,
                         // pre-launched launches: a zeroed device counter and a pinned host word that receives
                         // `seq` once every block of the launch is resident
-                        unsigned int* d_arrive_ctr = nullptr, unsigned long long* d_arrived_host = nullptr);
+                        unsigned int* d_arrive_ctr = nullptr, unsigned long long* d_arrived_host = nullptr,
+                        // kernel timing: events attached to the dispatch itself (begin / end of the kernel, as rocprofv3
+                        // reports it); both or neither
+                        hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
 // The 80-byte records of leaf slots [0, n) as 48-byte PackedRecords (f64 mean, f32 inverse covariance); a launch
 // whose EvalConsts::packed is set takes that array in place of `rec`.
