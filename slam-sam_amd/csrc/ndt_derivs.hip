@@ -873,6 +873,17 @@ constexpr unsigned int KERNARG_TABLES_OFFSET = offsetof(DerivKernArgs, pose) + o
 static_assert(offsetof(PoseConsts, hang) == offsetof(PoseConsts, jang) + 24 * sizeof(float) &&
               offsetof(AngleTables, hang) == 24 * sizeof(float), "jang / hang must be contiguous");
 
+// Which chunk of the source a block works on.  The hardware hands workgroup g to XCD g mod 8, and every XCD has its
+// own 4 MB L2 that is cold at the start of a launch: with chunk = g each L2 sees every eighth stretch of the scan,
+// i.e. the whole map, and fetches the whole record table and index grid once per XCD.  With the blocks of one XCD on
+// CONSECUTIVE chunks an L2 serves one eighth of the scan's extent.  A bijection of [0, G) for any G; block 0 keeps
+// chunk 0 (the dedicated summing block); rows are numbered by chunk, so the final sum -- fixed order over the rows --
+// does not change by a bit.
+__device__ __forceinline__ int xcd_chunk(int g, int G) {
+  const int x = g & 7, j = g >> 3, q = G >> 3, r = G & 7;
+  return x * q + min(x, r) + j;
+}
+
 // NB: neighbourhood -- 0 DIRECT1, 1 DIRECT7, 2 KDTREE, 3 DIRECT26, 4 multi-grid union; 5 / 6: DIRECT1 / DIRECT7 on the
 // 48-byte packed record table (the 27-cell neighbourhoods always read the 80-byte records)
 // MBOX (single-pose only): a pre-launched evaluation -- the pose is not in the kernel arguments
@@ -907,7 +918,8 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
   // per-point expansion to the block reduction, not across the pair loop
   // (with a dedicated summing block the points start at block 1; block 0's threads own none)
   const bool summing_block = ec.dedicated_summer != 0 && blockIdx.x == 0;
-  const int i = summing_block ? n : ((int)blockIdx.x - ec.dedicated_summer) * (int)blockDim.x + threadIdx.x;
+  const int chunk = (!BATCH && ec.xcd_chunks ? xcd_chunk((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x) - ec.dedicated_summer;
+  const int i = summing_block ? n : chunk * (int)blockDim.x + threadIdx.x;
   float x = 0.0f, y = 0.0f, z = 0.0f;
   if (MBOX) {
     // a pre-launched kernel has nothing to do until its pose arrives: its point does not depend
@@ -1062,7 +1074,7 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
                       out + (size_t)blockIdx.y * EV_WORDS,
                       flag ? flag + (size_t)blockIdx.y * ROW_WORDS : nullptr,  // pose y's 32 host slots
                       seq, ec.single_level_max,
-                      ec.fixed_summer != 0, BATCH ? nullptr : xinfo, xround, (int)blockIdx.x - ec.dedicated_summer,
+                      ec.fixed_summer != 0, BATCH ? nullptr : xinfo, xround, chunk,
                       (int)gridDim.x - ec.dedicated_summer, ec.dedicated_summer != 0);
 }
 
@@ -1181,6 +1193,11 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
   ecl.single_level_max = deriv_single_level_max();
   ecl.fixed_summer = deriv_fixed_summer();
   ecl.dedicated_summer = derivs_dedicated_summer(n_src, d_poses ? K : 1);
+  static const bool xcd_on = [] { const char* e = getenv("NDT_DERIV_XCD"); return !(e && atoi(e) == 0); }();  // A/B knob
+  // Only while the whole grid is resident at once (at most one block per compute unit): on larger grids an XCD that
+  // drew an expensive eighth of the source finishes late, round after round (C3, 400 k / 800 k points: 26.9 / 44.6 us
+  // against 23.7 / 37.6 with chunk = block id; profiles/r03_xcd_chunks.txt)
+  ecl.xcd_chunks = (!d_poses && xcd_on && blocks >= 16 && blocks <= g_compute_units + 1) ? 1 : 0;
   // DIRECT7 / DIRECT1 only: the union's leaves are chained through VoxelRecord::pad, and in the 27-cell neighbourhoods
   // the format (as a run-time flag) cost more than the shorter fetch gave back (KDTREE 21.9 -> 22.5 us, DIRECT26 29.1 -> 29.7)
   if (ec.multigrid || ec.kdtree || ec.direct26) ecl.packed = 0;

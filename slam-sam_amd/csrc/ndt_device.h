@@ -126,6 +126,7 @@ struct EvalConsts {
   int mbox_preload; // pre-launched kernels: 1 = the point is fetched before the wait for the pose
   int multigrid;   // 1: the table is a union of grids (radius search, leaves of a cell chained through VoxelRecord::pad)
   int packed;      // 1: the kernel's `rec` argument points at PackedRecord[] (48 bytes per leaf) instead of VoxelRecord[]
+  int xcd_chunks;  // 1: the blocks an XCD receives (workgroup id mod 8) take CONSECUTIVE chunks of the source (single-pose launches)
 };
 
 // layout of one evaluation (matches NDT_EVAL_WORDS in include/ndt_hip.h)
