@@ -1160,6 +1160,16 @@ int derivs_block_threads(size_t n_src, int K) {
     const size_t per_cu = (n_src + kCUs - 1) / kCUs;
     return (int)(((per_cu + 63) / 64) * 64);
   }
+  // Small sources -- a rank's share of the scan in a multi-GPU job, a sparse scan -- spread over more compute units in
+  // smaller blocks: about 196 blocks of 256 .. 512 threads (25 k points: 98 blocks of 256 = 8.2 us per launch against
+  // 9.9 with 49 of 512; 50 k: 9.2 against 10.1; 100 k stays at 196 x 512, where 256-thread blocks would put two on
+  // a compute unit: 13.8 against 10.4; profiles/r03_small_source_blocks.txt).  For every K, so that a batched launch
+  // keeps the partition -- hence the sums, bit for bit -- of the single-pose one.
+  if (n_src <= (size_t)196 * 512) {
+    const size_t per = (n_src + 195) / 196;
+    const size_t bt = ((per + 63) / 64) * 64;
+    return (int)std::min<size_t>(512, std::max<size_t>(256, bt));
+  }
   return 512;
 }
 

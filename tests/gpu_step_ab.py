@@ -10,6 +10,8 @@ pkg = ge.load_package(); S = pkg.synth
 tag = sys.argv[1] if len(sys.argv) > 1 else ""
 hip = pkg.ranks.Hip(0)
 cfg = S.config_c3()
+if os.environ.get("NDT_STEP_AB_NSRC"):   # a rank's share of the scan in a multi-GPU job (first points of the scan)
+    cfg["source"] = cfg["source"][:int(os.environ["NDT_STEP_AB_NSRC"])]
 ndt = pkg.NormalDistributionsTransform(device_id=0, resolution=0.5, step_size=0.1, trans_epsilon=1e-4, max_iterations=35)
 tp = [hip.upload(cfg["target"][:, a]) for a in range(3)]; sp = [hip.upload(cfg["source"][:, a]) for a in range(3)]
 hip.synchronize()
