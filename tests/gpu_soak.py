@@ -13,7 +13,8 @@ ndt.setInputTarget(cfg["target"])
 gt_inv = np.linalg.inv(cfg["gt"])
 big = (cfg["target"].astype(np.float64) @ gt_inv[:3, :3].T + gt_inv[:3, 3]).astype(np.float32)
 shapes = [("200k (241 blocks of 832)", cfg["source"], reps),
-          ("1k (2 blocks)", cfg["source"][:1000], reps),
+          ("1k (4 blocks of 256)", cfg["source"][:1000], reps),
+          ("25k (98 blocks of 256)", cfg["source"][:25000], reps),
           ("130k (254 blocks of 512)", cfg["source"][:130000], reps),
           ("1M (1954 rows)", big, max(50, reps // 20)),
           ("1.2M (two-level sum)", np.concatenate([big, big[:200000] + np.float32(0.01)]), max(50, reps // 20))]
