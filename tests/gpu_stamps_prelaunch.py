@@ -7,13 +7,16 @@ import numpy as np
 import __graft_entry__ as ge
 pkg = ge.load_package(); S = pkg.synth
 cfg = S.config_c3()
+if os.environ.get("NDT_STAMPS_NSRC"):   # a rank's share of the scan
+    cfg["source"] = cfg["source"][:int(os.environ["NDT_STAMPS_NSRC"])]
 ndt = pkg.NormalDistributionsTransform(device_id=0, resolution=0.5, step_size=0.1, trans_epsilon=1e-4, max_iterations=35)
 ndt.setInputTarget(cfg["target"])
 ndt.setInputSource(cfg["source"])
 L = pkg.lib()
 L.ndt_debug_read_stamps.argtypes = [C.c_void_p, C.c_int]
 n = len(cfg["source"])
-bt = int(os.environ.get("NDT_DERIV_BLOCK", "0")) or ((((n + 255) // 256 + 63) // 64) * 64 if 131072 < n <= 262144 else 512)
+bt = int(os.environ.get("NDT_DERIV_BLOCK", "0")) or ((((n + 255) // 256 + 63) // 64) * 64 if 131072 < n <= 262144 else
+                                                    (min(512, max(256, (((n + 195) // 196 + 63) // 64) * 64)) if n <= 196 * 512 else 512))
 ded = 0 if os.environ.get("NDT_DERIV_DEDICATED") == "0" else 1   # block 0 owns no points: it only adds the rows
 if not int(os.environ.get("NDT_DERIV_BLOCK", "0")) and 131072 < n <= 262144:
     bt = (((n + 254) // 255 + 63) // 64) * 64                      # one compute unit is left to the summing block
