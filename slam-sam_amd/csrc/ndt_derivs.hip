@@ -327,6 +327,60 @@ __device__ __forceinline__ void point_pairs(PairAcc& a, float x, float y, float 
   // profiles/r03_step_ab_summer_depth.txt: no difference in wall time per evaluation, 0.7 us less per
   // ordinary launch by HIP events).  The scheduling fences keep the compiler from sinking the loads
   // back to their first use (it otherwise serialises seven L2 round trips per point).
+#if defined(NDT_LDS_STAGE)
+  // EXPERIMENT (north_star's "LDS staging of neighbour-voxel covariances", per wave): the 64 points of a wave are
+  // neighbours along the scan, so for a given probe k their 64 leaf slots take only a handful of distinct values.
+  // The wave lists the distinct ones (up to 12 per probe), fetches each record ONCE -- one global_load_lds_dwordx4
+  // per probe, lane 5 j + c carrying the c-th 16-byte piece of the j-th listed record straight into the wave's LDS
+  // stage -- and every lane then reads its neighbours' records from LDS: 7 vector-memory instructions per wave on
+  // 7 x ~6 distinct lines instead of 35 on 35 x ~6.  Same records, same order of pair updates: the same bits.
+  if (!PACKED) {
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    constexpr int CAPR = 12;
+    __shared__ __align__(16) unsigned char lds_stage[(MAX_BLOCK / 64) * 7 * CAPR * 80];
+    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+    unsigned char* wbase = lds_stage + (size_t)wave * (7 * CAPR * 80);
+    int idx[7], nk[7];
+    const int jrec = lane / 5, piece = lane - 5 * jrec;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      const int my = slot[k];
+      int id = -1, n = 0, vlist = 0;
+      unsigned long long todo = __ballot(my >= 0);
+      while (todo != 0ull && n < CAPR) {   // wave-uniform
+        const int leader = __ffsll((long long)todo) - 1;
+        const int val = __builtin_amdgcn_readlane(my, leader);
+        const bool mine = my == val;
+        id = mine ? n : id;
+        vlist = lane == n ? val : vlist;
+        todo &= ~__ballot(mine);
+        ++n;
+      }
+      idx[k] = id;
+      nk[k] = n;
+      const int rj = __shfl(vlist, jrec);
+      if (lane < 5 * n) {
+        const char* g = reinterpret_cast<const char*>(rec + rj) + 16 * piece;
+        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(wbase + k * (CAPR * 80)), 16, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0);   // every staged record has landed in this wave's LDS
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      if (nk[k] == 0) continue;      // uniform: no lane of the wave has this neighbour
+      const bool present = slot[k] >= 0;
+      VoxelRecord r;
+      if (present && idx[k] < 0) {   // more than CAPR distinct leaves in the wave for this probe: own fetch
+        r = rec[slot[k]];
+      } else {
+        r = *reinterpret_cast<const VoxelRecord*>(wbase + k * (CAPR * 80) + (idx[k] > 0 ? idx[k] : 0) * 80);
+      }
+      pair_update<MODE>(a, r, xt, yt, zt, ec, present);
+    }
+    return;
+  }
+#endif
 #ifndef NDT_PAIR_DEPTH4
   const VoxelRecord r0 = NDT_LOAD_REC(slot[0]);
   const VoxelRecord r1 = NDT_LOAD_REC(slot[1]);
