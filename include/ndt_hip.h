@@ -25,7 +25,11 @@
  *    6x6 double, row-major (symmetric).
  *  - a handle is NOT thread-safe; distinct handles are independent (the
  *    reference uses one engine per thread, ref: run/pipeline.cpp:432,464).
- *  - the engine never keeps caller pointers after a call returns.
+ *  - the engine never keeps caller pointers after a call returns: a cloud handed
+ *    over from host memory has been read completely when ndt_set_target /
+ *    ndt_set_source return (the caller may free or overwrite it at once), even
+ *    though its transfer and the target's voxel-grid build may still be running
+ *    on the device (asynchronous hand-off, below).
  */
 #ifndef NDT_HIP_H_
 #define NDT_HIP_H_
@@ -37,7 +41,7 @@
 extern "C" {
 #endif
 
-#define NDT_HIP_ABI_VERSION 2
+#define NDT_HIP_ABI_VERSION 3
 
 typedef enum ndt_status {
   NDT_OK = 0,
@@ -211,6 +215,25 @@ const char* ndt_last_error(const ndt_handle* h);
 int ndt_backend_info(char* buf, size_t cap);
 
 /* ---- clouds ------------------------------------------------------------- */
+/* Hand-off of HOST clouds (the drivers hold host pcl::PointCloud<PointXYZI>, ref: run/pipeline.cpp:554-561).
+ * NDT_HANDOFF_ASYNC (default): ndt_set_target / ndt_set_source (and their _soa forms) return as soon as the
+ * caller's memory has been repacked into the engine's pinned staging; the PCIe copies, the SoA conversion and the
+ * target's voxel-grid build run behind on the device, the target's under the source's repack, and the first call
+ * that needs them (ndt_align, ndt_eval_derivatives, ndt_get_grid_info, ndt_export_leaves, ...) waits for them.
+ * Consequence: a steady-state build that FAILS (no finite point, index overflow) is reported by that first call
+ * (or by ndt_wait), with the same status code, not by ndt_set_target -- the reference's setInputTarget returns
+ * void, its failures surface in align the same way (ref: svn_ndt_impl.hpp:682-702).  The first build of a handle,
+ * the build that follows a failed one (both wait for the grid geometry inside the call), an empty cloud and
+ * argument errors are still reported at once.
+ * NDT_HANDOFF_SYNC: both calls block until the device has everything (rounds 1-3 behaviour; also NDT_HANDOFF=sync
+ * in the environment). */
+typedef enum ndt_handoff_mode { NDT_HANDOFF_ASYNC = 0, NDT_HANDOFF_SYNC = 1 } ndt_handoff_mode;
+int ndt_set_handoff_mode(ndt_handle* h, int mode);
+int ndt_get_handoff_mode(const ndt_handle* h);
+/* Blocks until every hand-off in flight is complete on the device; returns the status of a deferred build that
+ * failed (and keeps it for the next call that needs the grid), NDT_OK otherwise. */
+int ndt_wait(ndt_handle* h);
+
 /* setInputTarget (ref: run/pipeline.cpp:557): uploads and builds the voxel grid.
  * xyz points to the first x; consecutive points are stride_bytes apart (12 for
  * packed xyz, 32 for pcl::PointXYZI, 16 for pcl::PointXYZ). */
@@ -433,6 +456,27 @@ typedef struct ndt_timing {
 } ndt_timing;
 int ndt_enable_kernel_timing(ndt_handle* h, int on);
 int ndt_get_timing(const ndt_handle* h, ndt_timing* out);
+
+/* Breakdown of the last host hand-off of each cloud (ndt_set_target* / ndt_set_source* from host memory). */
+typedef struct ndt_handoff_lane_timing {
+  int64_t n_points;
+  int64_t bytes_in;     /* bytes of the caller's cloud that were read (n x stride, or 12 n for SoA) */
+  int64_t bytes_dma;    /* bytes that crossed PCIe (12 n) */
+  double ms_repack;     /* host time of the call up to its return in asynchronous mode: wait for the staging buffer,
+                           AoS -> chunk-major repack on `threads` threads, issue of the copies and the SoA kernel */
+  double ms_dma;        /* device time from before the first copy to behind the last, by HIP events; only while kernel
+                           timing is enabled (ndt_enable_kernel_timing) and once the hand-off has completed */
+  double dma_gb_per_s;  /* bytes_dma / ms_dma */
+  int threads;          /* repack threads incl. the caller */
+} ndt_handoff_lane_timing;
+typedef struct ndt_handoff_timing {
+  ndt_handoff_lane_timing target, source;
+  double ms_build_wait; /* time the first call that needed the grid waited for the deferred build's verdict */
+  int mode;             /* ndt_handoff_mode */
+  int cpu_budget;       /* CPUs this process may use (affinity mask cut down to the cgroup quota) */
+  int repack_workers;   /* worker threads of the repack pool (NDT_UPLOAD_THREADS overrides) */
+} ndt_handoff_timing;
+int ndt_get_handoff_timing(const ndt_handle* h, ndt_handoff_timing* out);
 
 #ifdef __cplusplus
 }

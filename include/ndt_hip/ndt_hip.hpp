@@ -408,6 +408,14 @@ class NormalDistributionsTransform
     if (status_ == NDT_OK) n_src_ = 0;  // align()'s output cloud is not filled on this path
   }
 
+  // engine-specific: the hand-off of host clouds.  By default setInputTarget / setInputSource return as soon as the
+  // caller's cloud has been consumed; the transfer and the voxel-grid build finish behind them and align() waits
+  // (ndt_set_handoff_mode in ndt_hip.h).  wait() blocks until they are complete and reports a failed build.
+  void setHandoffMode(int mode /* NDT_HANDOFF_ASYNC | NDT_HANDOFF_SYNC */) {
+    status_ = h_ ? ndt_set_handoff_mode(h_, mode) : NDT_ERR_NO_DEVICE;
+  }
+  int wait() { return status_ = h_ ? ndt_wait(h_) : NDT_ERR_NO_DEVICE; }
+
   // engine-specific: 48-byte voxel records (f64 mean, f32 inverse covariance) instead of 80-byte f64 ones
   // (ndt_set_record_format in ndt_hip.h: what it costs in accuracy and what it saves per evaluation)
   void setPackedVoxelRecords(bool on) {

@@ -32,6 +32,7 @@ WAIT_SPIN, WAIT_BLOCK = 0, 1
 SOURCE_ORDER_AUTO, SOURCE_ORDER_KEEP, SOURCE_ORDER_SORT = 0, 1, 2
 PRELAUNCH_AUTO, PRELAUNCH_OFF, PRELAUNCH_ONE_STREAM = 0, 1, 2
 RECORDS_F64, RECORDS_PACKED48 = 0, 1
+HANDOFF_ASYNC, HANDOFF_SYNC = 0, 1
 PRESET_DEFAULT, PRESET_PCLOMP_RECALLED, PRESET_SVN = 0, 1, 2
 
 STATUS = {0: "NDT_OK", -1: "NDT_ERR_INVALID_ARG", -2: "NDT_ERR_NO_DEVICE", -3: "NDT_ERR_HIP",
@@ -101,6 +102,17 @@ class Timing(C.Structure):
     ]
 
 
+class HandoffLaneTiming(C.Structure):
+    _fields_ = [("n_points", C.c_int64), ("bytes_in", C.c_int64), ("bytes_dma", C.c_int64),
+                ("ms_repack", C.c_double), ("ms_dma", C.c_double), ("dma_gb_per_s", C.c_double),
+                ("threads", C.c_int)]
+
+
+class HandoffTiming(C.Structure):
+    _fields_ = [("target", HandoffLaneTiming), ("source", HandoffLaneTiming), ("ms_build_wait", C.c_double),
+                ("mode", C.c_int), ("cpu_budget", C.c_int), ("repack_workers", C.c_int)]
+
+
 class SvnParams(C.Structure):
     _fields_ = [("particle_count", C.c_int), ("max_iterations", C.c_int),
                 ("kernel_bandwidth", C.c_double), ("step_size", C.c_double),
@@ -136,6 +148,7 @@ ABI_SYMBOLS = [
     "ndt_xy_covariance_laplace", "ndt_propose_poses_to_search", "ndt_xy_covariance_multi_ndt",
     "ndt_xy_covariance_multi_ndt_score", "ndt_source_changed", "ndt_comm_rank_count", "ndt_comm_p2p_handle", "ndt_comm_init_p2p",
     "ndt_set_record_format", "ndt_get_record_format",
+    "ndt_set_handoff_mode", "ndt_get_handoff_mode", "ndt_wait", "ndt_get_handoff_timing",
 ]
 
 _lib = None
@@ -219,6 +232,10 @@ def lib():
         L.ndt_propose_poses_to_search.argtypes = [C.POINTER(Result), dp, dp, C.c_int, fp]
         L.ndt_xy_covariance_multi_ndt.argtypes = [vp, C.POINTER(Result), fp, C.c_int, dp, dp]
         L.ndt_xy_covariance_multi_ndt_score.argtypes = [vp, C.POINTER(Result), fp, C.c_int, C.c_double, dp, dp]
+        L.ndt_set_handoff_mode.argtypes = [vp, C.c_int]
+        L.ndt_get_handoff_mode.argtypes = [vp]
+        L.ndt_wait.argtypes = [vp]
+        L.ndt_get_handoff_timing.argtypes = [vp, C.POINTER(HandoffTiming)]
         L.ndt_debug_prelaunch_counters.argtypes = [vp, C.POINTER(C.c_int64)]  # test seam, not in the header
         L.ndt_debug_build_counters.argtypes = [vp, C.POINTER(C.c_int64)]  # test seam, not in the header
         L.ndt_debug_sort_pairs.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, vp]  # test seam, not in the header
@@ -409,6 +426,26 @@ class NormalDistributionsTransform:
     def sourceChanged(self):
         """The arrays of a viewed source were rewritten in place: drop whatever the engine cached of them."""
         self._check(lib().ndt_source_changed(self._h))
+
+    def setHandoffMode(self, mode):
+        """HANDOFF_ASYNC (default): setInputTarget / setInputSource return once the host cloud has been consumed; the
+        copies and the voxel-grid build finish behind, and a failing steady-state build is reported by the first call
+        that needs the grid (or by wait()).  HANDOFF_SYNC: both block until the device has everything."""
+        self._check(lib().ndt_set_handoff_mode(self._h, int(mode)))
+
+    def getHandoffMode(self):
+        return int(lib().ndt_get_handoff_mode(self._h))
+
+    def wait(self):
+        """Blocks until every hand-off in flight is complete; raises what a deferred build failed with."""
+        self._check(lib().ndt_wait(self._h))
+
+    def getHandoffTiming(self):
+        t = HandoffTiming()
+        self._check(lib().ndt_get_handoff_timing(self._h, C.byref(t)))
+        lane = lambda l: {k: getattr(l, k) for k, _ in HandoffLaneTiming._fields_}  # noqa: E731
+        return dict(target=lane(t.target), source=lane(t.source), ms_build_wait=t.ms_build_wait, mode=t.mode,
+                    cpu_budget=t.cpu_budget, repack_workers=t.repack_workers)
 
     def setRecordFormat(self, fmt):
         """RECORDS_F64 (80-byte voxel records, default) or RECORDS_PACKED48 (f64 mean + f32 inverse covariance,

@@ -113,8 +113,7 @@ struct ndt_handle {
   DevBuf<char> sort_tmp;
   DevBuf<int> nleaf;                 // [0] slots, [1] valid
   DevBuf<int> leaf_start, leaf_cnt, run_counts, run_offsets, fin_counts;
-  DevBuf<float> upl_tmp;              // device twin of the pinned staging buffer (chunk-major cloud)
-  std::unique_ptr<RepackPool> pool;   // repack workers of large uploads, created on first use
+  std::unique_ptr<RepackPool> pool;   // repack workers of the host hand-off, created on first use
   DevBuf<uint32_t> sort_tags;         // tagged tile counts of the fused sort passes
   uint32_t sort_seq = 0;              // ... and their launch tag counter
   DevBuf<uint32_t> run_tags;          // tagged block leaf counts of the fused run search
@@ -164,7 +163,44 @@ struct ndt_handle {
   int64_t n_src_global = -1;
 
   // staging
-  PinBuf<float> stage;               // host->device upload staging
+  // Host hand-off (ndt_set_target / ndt_set_source and their SoA forms): two lanes, each with its own pinned staging
+  // buffer and stream, so that the target's transfer and build run while the source is repacked.
+  struct UploadLane {
+    PinBuf<float> stage;             // pinned, device-mapped staging: the cloud chunk by chunk as [x | y | z]
+    hipEvent_t done = nullptr;       // the last pull kernel out of `stage` has finished
+    hipEvent_t t0 = nullptr, t1 = nullptr;  // kernel timing: before the first copy / behind the last
+    bool busy = false;               // `done` has been recorded and not yet waited for
+    bool timed = false;              // t0 / t1 were recorded for the hand-off in flight
+    ndt_handoff_lane_timing tm{};    // breakdown of the lane's last hand-off
+  };
+  UploadLane lane_t, lane_s;
+  hipStream_t ustream = nullptr;     // the source lane's stream (the target lane shares `stream` with the build)
+  bool src_upload_pending = false;   // the engine's streams have not yet been ordered behind the source hand-off
+  int handoff_mode = NDT_HANDOFF_ASYNC;
+  // The voxel-grid build of an asynchronous hand-off: enqueued by ndt_set_target, its verdict collected by the first
+  // call that needs the grid (settle()).
+  struct BuildRun {
+    const float* x = nullptr;
+    const float* y = nullptr;
+    const float* z = nullptr;
+    size_t n = 0;
+    int dirty_slots = 0;
+    size_t clean_cap = 0;
+    bool fused = false, fused_sort = false, bucketed_ok = false;
+    int min_pts = 0, max_leaves = 0;
+    float leaf = 0, inv_leaf = 0;
+    bool build_events = false, poll_done = false;
+    std::chrono::steady_clock::time_point t0;
+    // the attempt in flight
+    int attempt = 0;
+    bool optimistic = false, bucketed = false;
+    int done_tag = 0;
+  };
+  BuildRun brun;
+  bool build_pending = false;
+  int deferred_rc = 0;               // status of a deferred build that failed, until a call that needs the grid has reported it
+  std::string deferred_msg;
+  double ms_settle_wait = 0;         // time the collecting call waited for the pending build's verdict
   PinBuf<double> result;             // evaluation results (K * EV_WORDS)
   PinBuf<int> small;                 // bounds / counters read-back
   PinBuf<unsigned long long> flag;   // 32 result slots {seq, value} the single-pose kernel writes for the host
@@ -271,80 +307,74 @@ bool params_valid(const ndt_params* p, std::string* why) {
   return true;
 }
 
-// host AoS / SoA -> device SoA through the pinned staging buffer.  Large clouds go in chunks:
-// a few host threads repack chunk after chunk into pinned memory while the calling thread hands
-// every finished chunk to the copy engine, so the PCIe transfer runs under the repack instead of
-// after it (a 1M-point PointXYZI map: repack ~0.6 ms + upload ~0.3 ms serial before).
-int upload_soa(ndt_handle* h, const float* xyz, const float* x, const float* y, const float* z,
-               size_t n, size_t stride, DevBuf<float>& dx, DevBuf<float>& dy, DevBuf<float>& dz) {
+// ---- host hand-off ---------------------------------------------------------------------------------
+// host AoS / SoA -> device SoA through a lane's pinned, device-mapped staging buffer (ref: run/pipeline.cpp:554-561
+// hands host pcl::PointCloud<PointXYZI> clouds).  The cloud is repacked piece by piece by a few persistent host
+// threads AND the calling thread (ndt_repack_pool.h) into pinned memory, chunk-major; every finished chunk is pulled
+// over PCIe at once by a small kernel of its own that writes the three SoA arrays (launch_pull_chunk), so the
+// transfer runs under the repack.  When the function returns the CALLER'S memory has been consumed -- the pull
+// kernels and whatever the caller enqueues behind them on `stream` may still be running (`sync` = false); the
+// lane's `done` event guards the staging buffer's reuse.
+int lane_wait(ndt_handle* h, ndt_handle::UploadLane& lane) {
+  if (!lane.busy) return NDT_OK;
+  HIP_TRY(h, hipEventSynchronize(lane.done));
+  lane.busy = false;
+  if (lane.timed) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, lane.t0, lane.t1) == hipSuccess) {
+      lane.tm.ms_dma = ms;
+      lane.tm.dma_gb_per_s = ms > 0 ? (double)lane.tm.bytes_dma / (ms * 1e-3) / 1e9 : 0.0;
+    }
+    lane.timed = false;
+  }
+  return NDT_OK;
+}
+
+int upload_soa(ndt_handle* h, ndt_handle::UploadLane& lane, hipStream_t stream, const float* xyz, const float* x,
+               const float* y, const float* z, size_t n, size_t stride, DevBuf<float>& dx, DevBuf<float>& dy,
+               DevBuf<float>& dz, bool sync) {
+  const auto t_begin = std::chrono::steady_clock::now();
+  int rc = lane_wait(h, lane);  // the previous hand-off's copies out of this lane's staging buffer
+  if (rc) return rc;
   HIP_TRY(h, dx.ensure(n));
   HIP_TRY(h, dy.ensure(n));
   HIP_TRY(h, dz.ensure(n));
+  lane.tm = ndt_handoff_lane_timing{};
   if (n == 0) return NDT_OK;
-  HIP_TRY(h, h->stage.ensure(3 * n));
-  HIP_TRY(h, h->upl_tmp.ensure(3 * n));
-  float* s = h->stage.h;
-  // Pinned staging and its device twin hold the cloud CHUNK BY CHUNK as [x | y | z] of the chunk's
-  // points, so that a chunk crosses PCIe in ONE copy (three per chunk were 24 copies of 0.5 MB for a
-  // 1M-point map: 0.45 ms where one 12 MB copy takes 0.22, tests/gpu_h2d_probe.py); one small kernel
-  // then writes the three SoA arrays.
-  // chunks of 128 k points: the copy of a chunk runs under the repack of the next (a scan of < 256 k points
-  // goes as one chunk on the calling thread: waking workers for it costs more than it saves)
-  constexpr size_t kChunk = 131072;
-  auto repack = [=](size_t lo, size_t hi) {
-    float* b = s + 3 * lo;
-    const size_t len = hi - lo;
-    if (xyz) {
-      const char* base = reinterpret_cast<const char*>(xyz);
-      for (size_t i = lo; i < hi; ++i) {
-        const float* p = reinterpret_cast<const float*>(base + i * stride);
-        b[i - lo] = p[0];
-        b[len + (i - lo)] = p[1];
-        b[2 * len + (i - lo)] = p[2];
-      }
-    } else {
-      std::memcpy(b, x + lo, len * sizeof(float));
-      std::memcpy(b + len, y + lo, len * sizeof(float));
-      std::memcpy(b + 2 * len, z + lo, len * sizeof(float));
-    }
-  };
-  auto copy_chunk = [&](size_t lo, size_t hi) -> hipError_t {
-    return hipMemcpyAsync(h->upl_tmp.p + 3 * lo, s + 3 * lo, 3 * (hi - lo) * sizeof(float), hipMemcpyHostToDevice, h->stream);
-  };
-  if (n < 2 * kChunk) {
-    // one chunk: [x | y | z] of all n points -- the unchunk kernel is told so through chunk = n
-    repack(0, n);
-    HIP_TRY(h, copy_chunk(0, n));
-    launch_unchunk_soa(h->upl_tmp.p, n, n, dx.p, dy.p, dz.p, h->stream);
-  } else {
-    const size_t nchunks = (n + kChunk - 1) / kChunk;
-    static const int threads_env = [] { const char* e = getenv("NDT_UPLOAD_THREADS"); return e ? atoi(e) : 0; }();
-    const unsigned nthreads = (unsigned)std::min<size_t>(threads_env > 0 ? (size_t)threads_env : (n >= (size_t)1 << 19 ? 6 : 3), nchunks);
-    std::vector<std::atomic<int>> done(nchunks);
-    for (auto& d : done) d.store(0, std::memory_order_relaxed);
-    std::atomic<size_t> next{0};
-    auto worker = [&] {
-      for (;;) {
-        const size_t c = next.fetch_add(1, std::memory_order_relaxed);
-        if (c >= nchunks) return;
-        repack(c * kChunk, std::min(n, (c + 1) * kChunk));
-        done[c].store(1, std::memory_order_release);
-      }
-    };
-    if (!h->pool) h->pool.reset(new RepackPool());
-    h->pool->ensure(nthreads);
-    h->pool->run(worker);   // (workers beyond nthreads, left from a larger upload, just find no chunk)
-    hipError_t err = hipSuccess;
-    for (size_t c = 0; c < nchunks; ++c) {
-      while (!done[c].load(std::memory_order_acquire)) _mm_pause();
-      if (err == hipSuccess) err = copy_chunk(c * kChunk, std::min(n, (c + 1) * kChunk));
-    }
-    h->pool->wait();        // `worker` and its captures live on this frame
-    HIP_TRY(h, err);
-    launch_unchunk_soa(h->upl_tmp.p, n, kChunk, dx.p, dy.p, dz.p, h->stream);
+  HIP_TRY(h, lane.stage.ensure(StageJob::stage_floats(n)));
+  if (!lane.done) {
+    HIP_TRY(h, hipEventCreateWithFlags(&lane.done, hipEventDisableTiming));
+    HIP_TRY(h, hipEventCreate(&lane.t0));
+    HIP_TRY(h, hipEventCreate(&lane.t1));
   }
+  StageJob job;
+  if (xyz) { job.aos = reinterpret_cast<const char*>(xyz); job.stride = stride; }
+  else { job.x = x; job.y = y; job.z = z; }
+  job.n = n;
+  job.stage = lane.stage.h;
+  // a cloud of up to two pieces is not worth a hand-shake with the workers
+  const unsigned workers = n > 2 * job.piece ? repack_workers() : 0u;
+  if (workers && !h->pool) h->pool.reset(new RepackPool());
+  lane.timed = h->timing;
+  if (lane.timed) HIP_TRY(h, hipEventRecord(lane.t0, stream));
+  // every finished chunk is pulled over PCIe by a small kernel of its own, straight into the SoA arrays
+  const float* stage_dev = lane.stage.d;
+  stage_cloud(h->pool.get(), workers, job, [&](size_t c, size_t lo, size_t hi) {
+    launch_pull_chunk(stage_dev + 3 * lo, hi - lo, job.seg(c), dx.p + lo, dy.p + lo, dz.p + lo, stream);
+  });
   HIP_TRY(h, hipGetLastError());
-  HIP_TRY(h, hipStreamSynchronize(h->stream));  // staging buffer is reused
+  if (lane.timed) HIP_TRY(h, hipEventRecord(lane.t1, stream));
+  HIP_TRY(h, hipEventRecord(lane.done, stream));
+  lane.busy = true;
+  lane.tm.n_points = (int64_t)n;
+  lane.tm.bytes_in = (int64_t)(xyz ? n * stride : 3 * n * sizeof(float));
+  lane.tm.bytes_dma = (int64_t)(3 * n * sizeof(float));
+  lane.tm.threads = (int)workers + 1;
+  lane.tm.ms_repack = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  if (sync) {
+    HIP_TRY(h, hipStreamSynchronize(stream));
+    return lane_wait(h, lane);
+  }
   return NDT_OK;
 }
 
@@ -393,36 +423,45 @@ int records_for_eval(ndt_handle* h, EvalConsts* ec, const VoxelRecord** rec) {
   return NDT_OK;
 }
 
-int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, size_t n) {
+// (re)initialise the bounds words of the two-launch build
+int neutral_bounds(ndt_handle* h) {
+  int w[8];
+  bucket_bounds_neutral(w);
+  HIP_TRY(h, hipMemcpyAsync(h->bnd.p, w, sizeof(w), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));   // (w lives on this frame)
+  return NDT_OK;
+}
+
+// everything of a build that does not depend on the attempt: state reset, allocations, constants
+int build_begin(ndt_handle* h, const float* x, const float* y, const float* z, size_t n, ndt_handle::BuildRun& br) {
   h->have_grid = false;
   h->multi_active = false;
   h->src_sorted = false;
   h->n_tgt = n;
   h->n_slots = h->n_valid = 0;
-  int dirty_slots = h->grid_dirty_slots;
-  size_t clean_cap = h->grid_clean_cap;
+  br = ndt_handle::BuildRun{};
+  br.x = x; br.y = y; br.z = z; br.n = n;
+  br.dirty_slots = h->grid_dirty_slots;
+  br.clean_cap = h->grid_clean_cap;
   h->grid_clean_cap = 0;  // pessimistic until this build has gone through
   h->grid_dirty_slots = 0;
   if (n == 0) return fail(h, NDT_ERR_NO_TARGET, "empty target cloud");
   if (n > (size_t)std::numeric_limits<int>::max() / 2) return fail(h, NDT_ERR_INVALID_ARG, "target too large");
   hipStream_t s = h->stream;
   const int nrows = bounds_rows(n);
-  const int min_pts = std::max(3, h->prm.min_points_per_voxel);  // ref: voxel_grid_covariance.h:176-184
-  const int max_leaves = (int)(n / (size_t)min_pts) + 1;
-  const float leaf = h->prm.resolution, inv_leaf = 1.0f / h->prm.resolution;
+  br.min_pts = std::max(3, h->prm.min_points_per_voxel);  // ref: voxel_grid_covariance.h:176-184
+  br.max_leaves = (int)(n / (size_t)br.min_pts) + 1;
+  const int max_leaves = br.max_leaves;
+  br.leaf = h->prm.resolution;
+  br.inv_leaf = 1.0f / h->prm.resolution;
 
   HIP_TRY(h, h->small.ensure(16));
   HIP_TRY(h, h->brows.ensure(8 * (size_t)std::max(nrows, bucket_build_tiles(n))));
   HIP_TRY(h, h->bucket_off.ensure(260));
-  auto neutral_bounds = [&]() -> hipError_t {   // (re)initialise the bounds words of the two-launch build
-    int w[8];
-    bucket_bounds_neutral(w);
-    hipError_t e = hipMemcpyAsync(h->bnd.p, w, sizeof(w), hipMemcpyHostToDevice, s);
-    return e == hipSuccess ? hipStreamSynchronize(s) : e;   // (w lives on this frame)
-  };
   if (!h->bnd.p) {
     HIP_TRY(h, h->bnd.ensure(8));
-    HIP_TRY(h, neutral_bounds());
+    int rc = neutral_bounds(h);
+    if (rc) return rc;
   }
   HIP_TRY(h, h->gd.ensure(1));
   HIP_TRY(h, h->gdh.ensure(1));
@@ -432,7 +471,7 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
   }
   HIP_TRY(h, h->nleaf.ensure(4));  // [0] slots, [1] valid, [2] buckets that declined (two-launch build)
   // a re-allocation of `stats` would lose the cells the previous build published
-  if ((size_t)max_leaves > h->stats.cap) clean_cap = 0;
+  if ((size_t)max_leaves > h->stats.cap) br.clean_cap = 0;
   HIP_TRY(h, h->keys.ensure(n));
   HIP_TRY(h, h->xyz4.ensure(4 * n));
   HIP_TRY(h, h->vals.ensure(n));
@@ -448,58 +487,75 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
   HIP_TRY(h, h->fin_counts.ensure((size_t)finalize_blocks(max_leaves)));
   HIP_TRY(h, h->sort_tmp.ensure(sort_temp_bytes(n)));
   // fused = launches that wait, inside the kernel, for sibling blocks (k_sort_pass, k_runs<RUNS_FUSED>)
-  bool fused = fused_build_enabled();
-  const bool fused_sort = fused && fused_sort_fits(n, h->n_cus);
+  br.fused = fused_build_enabled();
+  br.fused_sort = br.fused && fused_sort_fits(n, h->n_cus);
   // the two-launch build: steady state only (decided per attempt below), and it shares the tag table
-  bool bucketed_ok = bucket_build_enabled() && bucket_build_fits(n, h->n_cus);
+  br.bucketed_ok = bucket_build_enabled() && bucket_build_fits(n, h->n_cus);
   // A cloud the two-launch build declined (BG_BUCKET: a bucket beyond a block's LDS or hash table, far-away coordinates)
   // is usually followed by more of its kind (the same map, the next keyframe): the attempt costs two launches and, for a
   // late decline, a full clear of the index grid, so after a decline the next 8 builds go sort-based straight away, 16 after
   // the next decline, ... at most 64.
-  if (bucketed_ok && h->bucket_skip > 0) {
+  if (br.bucketed_ok && h->bucket_skip > 0) {
     --h->bucket_skip;
-    bucketed_ok = false;
+    br.bucketed_ok = false;
   }
-  if ((fused_sort || bucketed_ok) && !h->sort_tags.p) {
+  if ((br.fused_sort || br.bucketed_ok) && !h->sort_tags.p) {
     HIP_TRY(h, h->sort_tags.ensure(fused_table_words()));
     HIP_TRY(h, hipMemsetAsync(h->sort_tags.p, 0, h->sort_tags.cap * sizeof(uint32_t), s));
     h->sort_seq = 0;
   }
-  if (fused && run_tag_words(n) > h->run_tags.cap) {
+  if (br.fused && run_tag_words(n) > h->run_tags.cap) {
     HIP_TRY(h, h->run_tags.ensure(run_tag_words(n)));
     HIP_TRY(h, hipMemsetAsync(h->run_tags.p, 0, h->run_tags.cap * sizeof(uint32_t), s));
     h->run_seq = 0;
   }
 
   // device time of the build by HIP events when kernel timing is on (ndt_enable_kernel_timing; bench.py's
-  // instrumented pass); otherwise ms_build is the wall time of this call and the two event records, the
-  // event query and the elapsed-time call (3-4 us of host time) are saved
+  // instrumented pass); otherwise ms_build is the wall time from the build's enqueue to its verdict and the two
+  // event records, the event query and the elapsed-time call (3-4 us of host time) are saved
   static const int events_env = [] { const char* e = getenv("NDT_BUILD_EVENTS"); return e ? atoi(e) : -1; }();
-  const bool build_events = events_env >= 0 ? events_env != 0 : h->timing;
-  const auto t_build0 = std::chrono::steady_clock::now();
-  if (build_events) HIP_TRY(h, hipEventRecord(h->ev0, s));
-  bool built = false;
+  br.build_events = events_env >= 0 ? events_env != 0 : h->timing;
+  br.t0 = std::chrono::steady_clock::now();
+  if (br.build_events) HIP_TRY(h, hipEventRecord(h->ev0, s));
   static const bool poll_env = [] { const char* e = getenv("NDT_BUILD_WAIT"); return !(e && std::strcmp(e, "sync") == 0); }();
-  const bool poll_done = poll_env && h->prm.wait_mode == NDT_WAIT_SPIN;
-  for (int attempt = 0; attempt < 5; ++attempt) {
-    const bool optimistic = clean_cap != 0 && clean_cap == h->cell2leaf.cap;
-    const bool bucketed = bucketed_ok && optimistic;
-    const long long lim = std::numeric_limits<int32_t>::max();
-    const long long cap_cells = optimistic ? (long long)h->cell2leaf.cap : lim;
-    int passes = optimistic ? sort_passes_for_cells(cap_cells) : 0;
-    h->gdh.h->status = -1;
-    const int done_tag = (int)((++h->build_seq << 1) & 0x7fffffffu) | 1;  // odd: never 0, never the previous one
-    h->small.h[10] = 0;
-    if (bucketed) {
-      // bounds, partition, sort, sums and statistics in two launches (k_bucket_pass, k_bucket_leaves)
-      FinalizeParams fpb{h->prm.eig_inflation_ratio, h->prm.cov_mode};
-      HIP_TRY(h, launch_bucket_build(x, y, z, n, leaf, inv_leaf, cap_cells, min_pts, fpb, h->gd.p, h->gdh.d, h->sort_tags.p,
-                                     &h->sort_seq, h->stats.p, dirty_slots, h->cell2leaf.p, h->cell2leaf.cap, h->bnd.p,
-                                     h->bucket_off.p, h->nleaf.p, h->tickets.p + 4, h->xyz4.p, h->leaf_sums.p, h->rec.p,
-                                     h->cent.p, h->stats.p, max_leaves, h->small.d + 8, done_tag, s));
-    } else {
-    launch_bounds_geometry(x, y, z, n, leaf, inv_leaf, cap_cells, passes, h->brows.p, h->tickets.p, h->gd.p, h->gdh.d,
-                           optimistic ? h->stats.p : nullptr, optimistic ? dirty_slots : 0, h->cell2leaf.p,
+  br.poll_done = poll_env && h->prm.wait_mode == NDT_WAIT_SPIN;
+  br.attempt = 0;
+  return NDT_OK;
+}
+
+// The launches of one attempt.
+//
+// Steady state ("optimistic"): the dense grid and every scratch buffer exist from an earlier
+// build, so the whole chain of launches is enqueued without waiting for the bounds -- the
+// geometry and the sort plan are derived on the device (BuildGeom) and checked against the
+// capacities the host assumed; ONE wait at the end (build_collect).  First build, or a cloud that
+// outgrew the buffers: the host waits for the geometry once, allocates, and goes on.  A refused
+// optimistic build (BG_CAPACITY / BG_PASSES) is repeated that way.
+int build_enqueue(ndt_handle* h, ndt_handle::BuildRun& br) {
+  hipStream_t s = h->stream;
+  const float *x = br.x, *y = br.y, *z = br.z;
+  const size_t n = br.n;
+  const int min_pts = br.min_pts, max_leaves = br.max_leaves;
+  br.optimistic = br.clean_cap != 0 && br.clean_cap == h->cell2leaf.cap;
+  br.bucketed = br.bucketed_ok && br.optimistic;
+  const bool optimistic = br.optimistic;
+  const long long lim = std::numeric_limits<int32_t>::max();
+  const long long cap_cells = optimistic ? (long long)h->cell2leaf.cap : lim;
+  int passes = optimistic ? sort_passes_for_cells(cap_cells) : 0;
+  h->gdh.h->status = -1;
+  br.done_tag = (int)((++h->build_seq << 1) & 0x7fffffffu) | 1;  // odd: never 0, never the previous one
+  const int done_tag = br.done_tag;
+  h->small.h[10] = 0;
+  if (br.bucketed) {
+    // bounds, partition, sort, sums and statistics in two launches (k_bucket_pass, k_bucket_leaves)
+    FinalizeParams fpb{h->prm.eig_inflation_ratio, h->prm.cov_mode};
+    HIP_TRY(h, launch_bucket_build(x, y, z, n, br.leaf, br.inv_leaf, cap_cells, min_pts, fpb, h->gd.p, h->gdh.d, h->sort_tags.p,
+                                   &h->sort_seq, h->stats.p, br.dirty_slots, h->cell2leaf.p, h->cell2leaf.cap, h->bnd.p,
+                                   h->bucket_off.p, h->nleaf.p, h->tickets.p + 4, h->xyz4.p, h->leaf_sums.p, h->rec.p,
+                                   h->cent.p, h->stats.p, max_leaves, h->small.d + 8, done_tag, s));
+  } else {
+    launch_bounds_geometry(x, y, z, n, br.leaf, br.inv_leaf, cap_cells, passes, h->brows.p, h->tickets.p, h->gd.p, h->gdh.d,
+                           optimistic ? h->stats.p : nullptr, optimistic ? br.dirty_slots : 0, h->cell2leaf.p,
                            h->cell2leaf.cap, h->nleaf.p, s);
     if (!optimistic) {
       HIP_TRY(h, hipStreamSynchronize(s));
@@ -513,7 +569,7 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
     }
     HIP_TRY(h, h->stats.ensure((size_t)max_leaves));
     bool in_b = false;
-    if (fused && fused_sort) {
+    if (br.fused && br.fused_sort) {
       HIP_TRY(h, sort_cloud_fused(x, y, z, n, fused_tile_for(n, h->n_cus), h->gd.p, h->gdh.d, h->xyz4.p, h->keys.p, h->keys2.p, h->vals.p, h->vals2.p,
                                   passes, h->sort_tags.p, &h->sort_seq, s, &in_b));
     } else {
@@ -523,98 +579,114 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
     const uint32_t* keys_sorted = in_b ? h->keys2.p : h->keys.p;
     const uint32_t* vals_sorted = in_b ? h->vals2.p : h->vals.p;
     HIP_TRY(h, launch_find_runs(keys_sorted, n, h->gd.p, h->gdh.d, min_pts, h->nleaf.p, h->run_counts.p, h->run_offsets.p,
-                                h->tickets.p + 1, fused ? h->run_tags.p : nullptr, h->run_tags.cap, &h->run_seq,
+                                h->tickets.p + 1, br.fused ? h->run_tags.p : nullptr, h->run_tags.cap, &h->run_seq,
                                 h->leaf_start.p, h->leaf_cnt.p, s));
     FinalizeParams fp{h->prm.eig_inflation_ratio, h->prm.cov_mode};
     launch_finalize_leaves(h->xyz4.p, keys_sorted, vals_sorted, h->nleaf.p, h->leaf_start.p, h->leaf_cnt.p, max_leaves,
                            fp, h->leaf_sums.p, h->rec.p, h->cent.p, h->stats.p, h->cell2leaf.p, h->fin_counts.p, h->tickets.p + 2,
                            h->small.d + 8, done_tag, s);
-    }  // (sort-based pipeline)
-    HIP_TRY(h, hipGetLastError());
-    if (build_events) HIP_TRY(h, hipEventRecord(h->ev1, s));
-    if (poll_done) {
-      // the last block of the last kernel writes {slots, accepted, tag} to pinned memory in one
-      // store: watching that word costs less than a stream synchronisation (which wakes this
-      // thread through the runtime's signal); every later launch is ordered behind the build by
-      // the stream anyway.  A build that does not report within 2 s is left to the runtime.
-      volatile int* done = h->small.h + 10;
-      const auto t_wait = std::chrono::steady_clock::now();
-      unsigned spins = 0;
-      while (*done != done_tag) {
-        _mm_pause();
-        if ((++spins & 0xfffu) == 0 &&
-            std::chrono::steady_clock::now() - t_wait > std::chrono::seconds(2)) break;
-      }
-      std::atomic_thread_fence(std::memory_order_acquire);  // counts and geometry are read after the tag
-      if (*done == done_tag) {
-        if (build_events) {
-          hipError_t q;
-          while ((q = hipEventQuery(h->ev1)) == hipErrorNotReady) _mm_pause();
-          HIP_TRY(h, q);
-        }
-      } else {
-        HIP_TRY(h, hipStreamSynchronize(s));
+  }  // (sort-based pipeline)
+  HIP_TRY(h, hipGetLastError());
+  if (br.build_events) HIP_TRY(h, hipEventRecord(h->ev1, s));
+  return NDT_OK;
+}
+
+// Waits for the verdict of the attempt in flight.  0: built; 1: once more (br says how); < 0: error.
+int build_collect(ndt_handle* h, ndt_handle::BuildRun& br) {
+  hipStream_t s = h->stream;
+  const int done_tag = br.done_tag;
+  if (br.poll_done) {
+    // the last block of the last kernel writes {slots, accepted, tag} to pinned memory in one
+    // store: watching that word costs less than a stream synchronisation (which wakes this
+    // thread through the runtime's signal); every later launch is ordered behind the build by
+    // the stream anyway.  A build that does not report within 2 s is left to the runtime.
+    volatile int* done = h->small.h + 10;
+    const auto t_wait = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (*done != done_tag) {
+      _mm_pause();
+      if ((++spins & 0xfffu) == 0 &&
+          std::chrono::steady_clock::now() - t_wait > std::chrono::seconds(2)) break;
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);  // counts and geometry are read after the tag
+    if (*done == done_tag) {
+      if (br.build_events) {
+        hipError_t q;
+        while ((q = hipEventQuery(h->ev1)) == hipErrorNotReady) _mm_pause();
+        HIP_TRY(h, q);
       }
     } else {
       HIP_TRY(h, hipStreamSynchronize(s));
     }
-    const BuildGeom& bg = *h->gdh.h;
-    if (bucketed && (bg.status == BG_BUCKET || bg.status == BG_SPIN)) {
-      // declined (a bucket beyond a block's LDS or table, huge coordinates) or gave up waiting for sibling
-      // blocks.  Once more, sort-based.  BG_SPIN: neither launch has written a leaf and the old cells are
-      // already reset; BG_BUCKET may come late (one bucket's table overflowed after others had published
-      // leaves): that retry does not trust the grid -- full clear, geometry awaited.
-      bucketed_ok = false;
-      dirty_slots = 0;
-      if (bg.status == BG_BUCKET) {
-        clean_cap = 0;
-        h->bucket_backoff = std::min(64, std::max(8, 2 * h->bucket_backoff));
-        h->bucket_skip = h->bucket_backoff;
-      }
-      ++h->n_bucket_fallbacks;
-      HIP_TRY(h, neutral_bounds());   // (the launch pair resets them itself on every path; belt and braces)
-      continue;
-    }
-    if (bucketed && bg.status == BG_OK) {
-      ++h->n_bucket_builds;
-      h->bucket_backoff = 0;
-    }
-    if (optimistic && (bg.status == BG_CAPACITY || bg.status == BG_PASSES)) {
-      // the cloud outgrew the dense grid (or the enqueued sort passes): nothing after the bounds
-      // kernel ran; the old cells were reset by it.  Once more, waiting for the geometry.
-      clean_cap = 0;
-      dirty_slots = 0;
-      continue;
-    }
-    if (fused && bg.status == BG_SPIN) {
-      // a fused launch gave up waiting for its sibling blocks (the CUs were held by other work).
-      // Once more with the classic three-launch passes, which never wait inside a kernel.
-      // (k_runs<RUNS_FUSED> publishes a block's tag BEFORE it waits, so its last block can set nleaf > 0
-      // while a middle block gave up: k_leaf_finalize may then have written indices of stale slots into
-      // the grid.  The retry therefore does not trust the grid: full clear, geometry awaited.)
-      fused = false;
-      dirty_slots = 0;
-      clean_cap = 0;
-      ++h->n_fused_sort_fallbacks;
-      continue;
-    }
-    if (bg.status == BG_NO_FINITE) return fail(h, NDT_ERR_NO_TARGET, "target has no finite point");
-    if (bg.status == BG_OVERFLOW)
-      return fail(h, NDT_ERR_GRID_OVERFLOW, std::string("leaf size too small for the target extent (index overflow)") +
-                                                (bucketed ? " [two-launch build" : " [sort-based build") + ", finite points " +
-                                                std::to_string(bg.n_finite) + "]");
-    if (bg.status != BG_OK)
-      return fail(h, NDT_ERR_HIP, "voxel-grid build ended without a verdict (internal, status " + std::to_string(bg.status) +
-                                      (bucketed ? ", two-launch build)" : ", sort-based build)"));
-    h->geom = bg.g;
-    for (int a = 0; a < 3; ++a) h->max_b[a] = bg.max_b[a];
-    built = true;
-    break;
+  } else {
+    HIP_TRY(h, hipStreamSynchronize(s));
   }
-  if (!built) return fail(h, NDT_ERR_HIP, "voxel-grid build did not go through (internal)");
+  const BuildGeom& bg = *h->gdh.h;
+  if (br.bucketed && (bg.status == BG_BUCKET || bg.status == BG_SPIN)) {
+    // declined (a bucket beyond a block's LDS or table, huge coordinates) or gave up waiting for sibling
+    // blocks.  Once more, sort-based.  BG_SPIN: neither launch has written a leaf and the old cells are
+    // already reset; BG_BUCKET may come late (one bucket's table overflowed after others had published
+    // leaves): that retry does not trust the grid -- full clear, geometry awaited.
+    br.bucketed_ok = false;
+    br.dirty_slots = 0;
+    if (bg.status == BG_BUCKET) {
+      br.clean_cap = 0;
+      h->bucket_backoff = std::min(64, std::max(8, 2 * h->bucket_backoff));
+      h->bucket_skip = h->bucket_backoff;
+    }
+    ++h->n_bucket_fallbacks;
+    int rc = neutral_bounds(h);   // (the launch pair resets them itself on every path; belt and braces)
+    return rc ? rc : 1;
+  }
+  if (br.bucketed && bg.status == BG_OK) {
+    ++h->n_bucket_builds;
+    h->bucket_backoff = 0;
+  }
+  if (br.optimistic && (bg.status == BG_CAPACITY || bg.status == BG_PASSES)) {
+    // the cloud outgrew the dense grid (or the enqueued sort passes): nothing after the bounds
+    // kernel ran; the old cells were reset by it.  Once more, waiting for the geometry.
+    br.clean_cap = 0;
+    br.dirty_slots = 0;
+    return 1;
+  }
+  if (br.fused && bg.status == BG_SPIN) {
+    // a fused launch gave up waiting for its sibling blocks (the CUs were held by other work).
+    // Once more with the classic three-launch passes, which never wait inside a kernel.
+    // (k_runs<RUNS_FUSED> publishes a block's tag BEFORE it waits, so its last block can set nleaf > 0
+    // while a middle block gave up: k_leaf_finalize may then have written indices of stale slots into
+    // the grid.  The retry therefore does not trust the grid: full clear, geometry awaited.)
+    br.fused = false;
+    br.dirty_slots = 0;
+    br.clean_cap = 0;
+    ++h->n_fused_sort_fallbacks;
+    return 1;
+  }
+  if (bg.status == BG_NO_FINITE) return fail(h, NDT_ERR_NO_TARGET, "target has no finite point");
+  if (bg.status == BG_OVERFLOW)
+    return fail(h, NDT_ERR_GRID_OVERFLOW, std::string("leaf size too small for the target extent (index overflow)") +
+                                              (br.bucketed ? " [two-launch build" : " [sort-based build") + ", finite points " +
+                                              std::to_string(bg.n_finite) + "]");
+  if (bg.status != BG_OK)
+    return fail(h, NDT_ERR_HIP, "voxel-grid build ended without a verdict (internal, status " + std::to_string(bg.status) +
+                                    (br.bucketed ? ", two-launch build)" : ", sort-based build)"));
+  h->geom = bg.g;
+  for (int a = 0; a < 3; ++a) h->max_b[a] = bg.max_b[a];
+  return 0;
+}
+
+// collects the attempt in flight, repeats the build as often as its verdicts ask for, and publishes the grid
+int build_complete(ndt_handle* h, ndt_handle::BuildRun& br) {
+  for (;;) {
+    int rc = build_collect(h, br);
+    if (rc < 0) return rc;
+    if (rc == 0) break;
+    if (++br.attempt >= 5) return fail(h, NDT_ERR_HIP, "voxel-grid build did not go through (internal)");
+    rc = build_enqueue(h, br);
+    if (rc) return rc;
+  }
   float ms = 0;
-  if (build_events) HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-  else ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_build0).count();
+  if (br.build_events) HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  else ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - br.t0).count();
   h->ms_build = ms;
   h->tm.ms_last_build = ms;
   h->n_slots = h->small.h[8];
@@ -629,6 +701,73 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
     if (rc) return rc;
   }
   return NDT_OK;
+}
+
+// The voxel-grid build proper; x/y/z are device pointers.  `defer`: a steady-state build is only ENQUEUED (the
+// asynchronous host hand-off): the arrays must stay valid -- they are the engine's own copy there -- and the first
+// call that needs the grid collects the verdict through settle().  A first build, or one that has to wait for the
+// geometry anyway, completes here either way.
+int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, size_t n, bool defer = false) {
+  h->build_pending = false;
+  h->deferred_rc = 0;
+  h->ms_settle_wait = 0;
+  int rc = build_begin(h, x, y, z, n, h->brun);
+  if (rc) return rc;
+  rc = build_enqueue(h, h->brun);
+  if (rc) return rc;
+  if (defer && h->brun.optimistic) {
+    h->build_pending = true;
+    return NDT_OK;
+  }
+  return build_complete(h, h->brun);
+}
+
+// Completes whatever an asynchronous hand-off left in flight that the caller is about to depend on: the pending
+// build's verdict (a failed build is reported HERE, by the first call that needs the grid), and the order of the
+// engine's streams behind the source lane.
+int settle_build(ndt_handle* h) {
+  if (!h->build_pending) return NDT_OK;
+  h->build_pending = false;
+  const auto t0 = std::chrono::steady_clock::now();
+  int rc = build_complete(h, h->brun);
+  h->ms_settle_wait = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (rc) {  // kept for the first call that needs the grid (the collecting call may be a setter that does not)
+    h->deferred_rc = rc;
+    h->deferred_msg = h->err;
+  }
+  return rc;
+}
+
+int settle_source(ndt_handle* h) {
+  if (!h->src_upload_pending) return NDT_OK;
+  h->src_upload_pending = false;
+  HIP_TRY(h, hipStreamWaitEvent(h->stream, h->lane_s.done, 0));
+  HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->lane_s.done, 0));
+  return NDT_OK;
+}
+
+// The source lane's stream starts behind the target lane's TRANSFER (not its build): both transfers share one PCIe
+// link, the target's is on the critical path (the build waits for it; the source is not needed before the first
+// evaluation), and the source's 2.4 MB then cross while the build runs and the link is idle.
+int source_behind_target_transfer(ndt_handle* h, bool async) {
+  if (async && h->lane_t.busy) HIP_TRY(h, hipStreamWaitEvent(h->ustream, h->lane_t.done, 0));
+  return NDT_OK;
+}
+
+// for calls that need the grid: a deferred build's failure is theirs to report
+int settle(ndt_handle* h) {
+  (void)settle_build(h);
+  int rs = settle_source(h);
+  if (!h->have_grid && h->deferred_rc) return fail(h, h->deferred_rc, h->deferred_msg);
+  return rs;
+}
+
+// for calls that replace the target: the pending build is completed (its scratch and the engine's own copy of
+// the cloud are about to be reused) and its verdict dropped
+void settle_discard(ndt_handle* h) {
+  (void)settle_build(h);
+  h->deferred_rc = 0;
+  h->deferred_msg.clear();
 }
 
 void fill_pose_consts(const double p[6], const float T[16], PoseConsts* pc) {
@@ -664,6 +803,8 @@ int ensure_counters(ndt_handle* h, size_t k) {
 }
 
 int ready_for_eval(ndt_handle* h) {
+  int rc = settle(h);
+  if (rc) return rc;
   if (!h->have_grid || h->n_valid <= 0) return fail(h, NDT_ERR_NO_TARGET, "no target voxel grid (setInputTarget first)");
   if (h->n_src == 0 && h->red.mode() == NDT_REDUCE_NONE) return fail(h, NDT_ERR_NO_SOURCE, "no source cloud (setInputSource first)");
   return NDT_OK;
@@ -1122,8 +1263,13 @@ int ndt_create(const ndt_params* p, ndt_handle** out) {
     const char* e = getenv("NDT_PRELAUNCH_STREAMS");
     h->two_streams = !(e && atoi(e) == 1);
   }
+  {
+    const char* e = getenv("NDT_HANDOFF");  // A/B aid: "sync" = the blocking hand-off of rounds 1-3
+    if (e && std::strcmp(e, "sync") == 0) h->handoff_mode = NDT_HANDOFF_SYNC;
+  }
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&h->ustream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
       hipEventCreate(&h->ev2) != hipSuccess) {
     delete h;
@@ -1136,21 +1282,30 @@ int ndt_create(const ndt_params* p, ndt_handle** out) {
 int ndt_destroy(ndt_handle* h) {
   if (!h) return NDT_OK;
   (void)hipSetDevice(h->device);
+  settle_discard(h);
+  if (h->ustream) (void)hipStreamSynchronize(h->ustream);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->stream2) (void)hipStreamSynchronize(h->stream2);
+  h->pool.reset();
+  for (ndt_handle::UploadLane* lane : {&h->lane_t, &h->lane_s}) {
+    lane->stage.release();
+    if (lane->done) (void)hipEventDestroy(lane->done);
+    if (lane->t0) (void)hipEventDestroy(lane->t0);
+    if (lane->t1) (void)hipEventDestroy(lane->t1);
+  }
   h->red.destroy();
   h->tx.release(); h->ty.release(); h->tz.release();
   h->keys.release(); h->vals.release(); h->keys2.release(); h->vals2.release();
   h->sort_tmp.release(); h->nleaf.release(); h->leaf_start.release(); h->leaf_cnt.release();
   h->cell2leaf.release(); h->rec.release(); h->prec.release(); h->prec_valid = false; h->cent.release(); h->stats.release();
-  h->run_counts.release(); h->run_offsets.release(); h->fin_counts.release(); h->bucket_off.release(); h->bnd.release(); h->upl_tmp.release(); h->sort_tags.release(); h->run_tags.release(); h->xyz4.release(); h->leaf_sums.release();
+  h->run_counts.release(); h->run_offsets.release(); h->fin_counts.release(); h->bucket_off.release(); h->bnd.release(); h->sort_tags.release(); h->run_tags.release(); h->xyz4.release(); h->leaf_sums.release();
   h->brows.release(); h->tickets.release(); h->gd.release(); h->gdh.release();
   for (auto& kv : h->keyframes) { kv.second.x.release(); kv.second.y.release(); kv.second.z.release(); }
   h->keyframes.clear();
   h->sx.release(); h->sy.release(); h->sz.release();
   h->ox.release(); h->oy.release(); h->oz.release(); h->skeys.release(); h->skeys2.release();
   h->svals.release(); h->svals2.release(); h->ssort_tmp.release(); h->splan.release();
-  h->stage.release(); h->result.release(); h->small.release(); h->partials.release();
+  h->result.release(); h->small.release(); h->partials.release();
   h->dres.release(); h->dposes.release(); h->hposes.release(); h->counters.release(); h->flag.release();
   if (h->mbox) (void)hipFree(h->mbox);
   if (h->bposes) (void)hipFree(h->bposes);
@@ -1159,6 +1314,7 @@ int ndt_destroy(ndt_handle* h) {
   if (h->ev2) (void)hipEventDestroy(h->ev2);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   if (h->stream2) (void)hipStreamDestroy(h->stream2);
+  if (h->ustream) (void)hipStreamDestroy(h->ustream);
   h->arrive_ctr.release(); h->arrived.release();
   delete h;
   return NDT_OK;
@@ -1176,6 +1332,11 @@ int ndt_set_params(ndt_handle* h, const ndt_params* p) {
   if (!h || !p) return NDT_ERR_INVALID_ARG;
   std::string why;
   if (!params_valid(p, &why)) return fail(h, NDT_ERR_INVALID_ARG, why);
+  if (h->build_pending) {
+    int rc0 = bind_device(h);
+    if (rc0) return rc0;
+    (void)settle_build(h);  // (a failure stays with the handle for the first call that needs the grid)
+  }
   const bool grid_changed = h->have_grid && (std::fabs(p->resolution - h->prm.resolution) > 1e-6f ||
                                              p->min_points_per_voxel != h->prm.min_points_per_voxel ||
                                              p->eig_inflation_ratio != h->prm.eig_inflation_ratio ||
@@ -1208,18 +1369,22 @@ int ndt_set_target(ndt_handle* h, const float* xyz, size_t n, size_t stride_byte
   if (!h || (!xyz && n) || stride_bytes < 12 || stride_bytes % 4) return NDT_ERR_INVALID_ARG;
   int rc = bind_device(h);
   if (rc) return rc;
-  rc = upload_soa(h, xyz, nullptr, nullptr, nullptr, n, stride_bytes, h->tx, h->ty, h->tz);
+  settle_discard(h);
+  const bool async = h->handoff_mode == NDT_HANDOFF_ASYNC;
+  rc = upload_soa(h, h->lane_t, h->stream, xyz, nullptr, nullptr, nullptr, n, stride_bytes, h->tx, h->ty, h->tz, !async);
   if (rc) return rc;
-  return build_grid(h, h->tx.p, h->ty.p, h->tz.p, n);
+  return build_grid(h, h->tx.p, h->ty.p, h->tz.p, n, async);
 }
 
 int ndt_set_target_soa(ndt_handle* h, const float* x, const float* y, const float* z, size_t n) {
   if (!h || ((!x || !y || !z) && n)) return NDT_ERR_INVALID_ARG;
   int rc = bind_device(h);
   if (rc) return rc;
-  rc = upload_soa(h, nullptr, x, y, z, n, 0, h->tx, h->ty, h->tz);
+  settle_discard(h);
+  const bool async = h->handoff_mode == NDT_HANDOFF_ASYNC;
+  rc = upload_soa(h, h->lane_t, h->stream, nullptr, x, y, z, n, 0, h->tx, h->ty, h->tz, !async);
   if (rc) return rc;
-  return build_grid(h, h->tx.p, h->ty.p, h->tz.p, n);
+  return build_grid(h, h->tx.p, h->ty.p, h->tz.p, n, async);
 }
 
 int ndt_set_target_device(ndt_handle* h, const float* dx, const float* dy, const float* dz, size_t n) {
@@ -1228,6 +1393,7 @@ int ndt_set_target_device(ndt_handle* h, const float* dx, const float* dy, const
   if (rc) return rc;
   // built straight from the caller's arrays; nothing is retained, so a later
   // resolution change cannot re-voxelise this target
+  settle_discard(h);
   h->tx.release(); h->ty.release(); h->tz.release();
   return build_grid(h, dx, dy, dz, n);
 }
@@ -1238,8 +1404,14 @@ int ndt_set_source(ndt_handle* h, const float* xyz, size_t n, size_t stride_byte
   if (rc) return rc;
   h->vx = h->vy = h->vz = nullptr;
   h->n_src = 0;
-  rc = upload_soa(h, xyz, nullptr, nullptr, nullptr, n, stride_bytes, h->sx, h->sy, h->sz);
+  // asynchronous hand-off: on the source lane's own stream, so that its copies run beside the target's build; the
+  // engine's streams are ordered behind it by the first call that evaluates (settle_source)
+  const bool async = h->handoff_mode == NDT_HANDOFF_ASYNC;
+  rc = source_behind_target_transfer(h, async);
   if (rc) return rc;
+  rc = upload_soa(h, h->lane_s, async ? h->ustream : h->stream, xyz, nullptr, nullptr, nullptr, n, stride_bytes, h->sx, h->sy, h->sz, !async);
+  if (rc) return rc;
+  h->src_upload_pending = async && n > 0;
   h->vx = h->sx.p; h->vy = h->sy.p; h->vz = h->sz.p;
   h->n_src = n;
   h->src_sorted = false;
@@ -1252,8 +1424,12 @@ int ndt_set_source_soa(ndt_handle* h, const float* x, const float* y, const floa
   if (rc) return rc;
   h->vx = h->vy = h->vz = nullptr;
   h->n_src = 0;
-  rc = upload_soa(h, nullptr, x, y, z, n, 0, h->sx, h->sy, h->sz);
+  const bool async = h->handoff_mode == NDT_HANDOFF_ASYNC;
+  rc = source_behind_target_transfer(h, async);
   if (rc) return rc;
+  rc = upload_soa(h, h->lane_s, async ? h->ustream : h->stream, nullptr, x, y, z, n, 0, h->sx, h->sy, h->sz, !async);
+  if (rc) return rc;
+  h->src_upload_pending = async && n > 0;
   h->vx = h->sx.p; h->vy = h->sy.p; h->vz = h->sz.p;
   h->n_src = n;
   h->src_sorted = false;
@@ -1263,6 +1439,8 @@ int ndt_set_source_soa(ndt_handle* h, const float* x, const float* y, const floa
 int ndt_set_source_device(ndt_handle* h, const float* dx, const float* dy, const float* dz, size_t n) {
   if (!h || ((!dx || !dy || !dz) && n)) return NDT_ERR_INVALID_ARG;
   int rc = bind_device(h);
+  if (rc) return rc;
+  rc = settle_source(h);  // a source hand-off still in flight writes the same arrays on its own stream
   if (rc) return rc;
   HIP_TRY(h, h->sx.ensure(n));
   HIP_TRY(h, h->sy.ensure(n));
@@ -1318,7 +1496,8 @@ int ndt_multigrid_add_target(ndt_handle* h, int64_t id, const float* xyz, size_t
   if (!h || !xyz || n == 0 || stride_bytes < 12 || stride_bytes % 4) return NDT_ERR_INVALID_ARG;
   int rc = bind_device(h);
   if (rc) return rc;
-  rc = upload_soa(h, xyz, nullptr, nullptr, nullptr, n, stride_bytes, h->tx, h->ty, h->tz);
+  settle_discard(h);
+  rc = upload_soa(h, h->lane_t, h->stream, xyz, nullptr, nullptr, nullptr, n, stride_bytes, h->tx, h->ty, h->tz, true);
   if (rc) return rc;
   rc = build_grid(h, h->tx.p, h->ty.p, h->tz.p, n);
   // the handle's single-grid table is scratch here: whatever happens, it is not a target to align to,
@@ -1372,6 +1551,7 @@ int ndt_multigrid_create_kdtree(ndt_handle* h) {
   if (!h) return NDT_ERR_INVALID_ARG;
   int rc = bind_device(h);
   if (rc) return rc;
+  settle_discard(h);
   h->have_grid = false;
   h->multi_active = false;
   h->src_sorted = false;
@@ -1475,7 +1655,7 @@ int ndt_keyframe_put(ndt_handle* h, int64_t id, const float* xyz, size_t n, size
   int rc = bind_device(h);
   if (rc) return rc;
   ndt_handle::Keyframe& kf = h->keyframes[id];
-  rc = upload_soa(h, xyz, nullptr, nullptr, nullptr, n, stride_bytes, kf.x, kf.y, kf.z);
+  rc = upload_soa(h, h->lane_t, h->stream, xyz, nullptr, nullptr, nullptr, n, stride_bytes, kf.x, kf.y, kf.z, true);
   if (rc) return rc;
   kf.n = n;
   return NDT_OK;
@@ -1511,6 +1691,7 @@ int ndt_set_target_from_keyframes(ndt_handle* h, const int64_t* ids, const doubl
     if (it == h->keyframes.end()) return fail(h, NDT_ERR_INVALID_ARG, "unknown keyframe id");
     total += it->second.n;
   }
+  settle_discard(h);
   HIP_TRY(h, h->tx.ensure(total));
   HIP_TRY(h, h->ty.ensure(total));
   HIP_TRY(h, h->tz.ensure(total));
@@ -1522,7 +1703,8 @@ int ndt_set_target_from_keyframes(ndt_handle* h, const int64_t* ids, const doubl
     off += kf.n;
   }
   HIP_TRY(h, hipGetLastError());
-  return build_grid(h, h->tx.p, h->ty.p, h->tz.p, total);
+  // (the assembled cloud is the engine's own: the build may stay in flight like a host hand-off's)
+  return build_grid(h, h->tx.p, h->ty.p, h->tz.p, total, h->handoff_mode == NDT_HANDOFF_ASYNC);
 }
 
 int ndt_set_global_source_size(ndt_handle* h, int64_t n_total) {
@@ -1763,6 +1945,8 @@ int ndt_transform_source(ndt_handle* h, const float T[16], float* out_xyz, size_
   if (rc) return rc;
   if (cap_points < h->n_src) return fail(h, NDT_ERR_INVALID_ARG, "output buffer too small");
   if (h->n_src == 0) return NDT_OK;
+  rc = settle_source(h);
+  if (rc) return rc;
   PoseConsts pc{};
   for (int i = 0; i < 3; ++i) {
     for (int j = 0; j < 3; ++j) pc.R[3 * i + j] = T[4 * j + i];
@@ -1778,9 +1962,18 @@ int ndt_transform_source(ndt_handle* h, const float T[16], float* out_xyz, size_
   return NDT_OK;
 }
 
-int ndt_get_grid_info(const ndt_handle* h, ndt_grid_info* out) {
-  if (!h || !out) return NDT_ERR_INVALID_ARG;
+int ndt_get_grid_info(const ndt_handle* hc, ndt_grid_info* out) {
+  if (!hc || !out) return NDT_ERR_INVALID_ARG;
   std::memset(out, 0, sizeof(*out));
+  ndt_handle* h = const_cast<ndt_handle*>(hc);  // logically const: a pending build is the grid it describes
+  if (h->build_pending || h->src_upload_pending) {
+    int rc = bind_device(h);
+    if (rc) return rc;
+  }
+  {
+    int rc = settle(h);
+    if (rc) return rc;
+  }
   if (!h->have_grid) return NDT_ERR_NO_TARGET;
   for (int a = 0; a < 3; ++a) {
     out->min_b[a] = h->geom.min_b[a];
@@ -1798,8 +1991,12 @@ int ndt_get_grid_info(const ndt_handle* h, ndt_grid_info* out) {
 
 int64_t ndt_export_leaves(ndt_handle* h, ndt_leaf* out, size_t cap) {
   if (!h || (!out && cap)) return NDT_ERR_INVALID_ARG;
-  if (!h->have_grid) return NDT_ERR_NO_TARGET;
   if (bind_device(h)) return NDT_ERR_HIP;
+  {
+    int rc = settle(h);
+    if (rc) return rc;
+  }
+  if (!h->have_grid) return NDT_ERR_NO_TARGET;
   std::vector<LeafStats> st((size_t)h->n_slots);
   if (h->multi_active) {
     st = h->multi_stats;  // table order; `cell` is the union grid's index
@@ -1938,6 +2135,7 @@ int ndt_debug_sort_pairs(ndt_handle* h, const uint32_t* keys, size_t n, int end_
   if (n == 0) return NDT_OK;
   int rc = bind_device(h);
   if (rc) return rc;
+  settle_discard(h);
   hipStream_t s = h->stream;
   HIP_TRY(h, h->keys.ensure(n));
   HIP_TRY(h, h->vals.ensure(n));
@@ -1957,6 +2155,42 @@ int ndt_debug_sort_pairs(ndt_handle* h, const uint32_t* keys, size_t n, int end_
   HIP_TRY(h, hipMemcpyAsync(vals_out, in_b ? h->vals2.p : h->vals.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   HIP_TRY(h, hipStreamSynchronize(s));
   h->have_grid = false;  // the build's scratch was overwritten
+  return NDT_OK;
+}
+
+int ndt_set_handoff_mode(ndt_handle* h, int mode) {
+  if (!h) return NDT_ERR_INVALID_ARG;
+  if (mode != NDT_HANDOFF_ASYNC && mode != NDT_HANDOFF_SYNC) return fail(h, NDT_ERR_INVALID_ARG, "unknown hand-off mode");
+  h->handoff_mode = mode;
+  return NDT_OK;
+}
+
+int ndt_get_handoff_mode(const ndt_handle* h) { return h ? h->handoff_mode : NDT_ERR_INVALID_ARG; }
+
+int ndt_wait(ndt_handle* h) {
+  if (!h) return NDT_ERR_INVALID_ARG;
+  int rc = bind_device(h);
+  if (rc) return rc;
+  (void)settle_build(h);
+  rc = settle_source(h);
+  if (rc) return rc;
+  rc = lane_wait(h, h->lane_t);
+  if (rc) return rc;
+  rc = lane_wait(h, h->lane_s);
+  if (rc) return rc;
+  if (!h->have_grid && h->deferred_rc) return fail(h, h->deferred_rc, h->deferred_msg);
+  return NDT_OK;
+}
+
+int ndt_get_handoff_timing(const ndt_handle* h, ndt_handoff_timing* out) {
+  if (!h || !out) return NDT_ERR_INVALID_ARG;
+  std::memset(out, 0, sizeof(*out));
+  out->target = h->lane_t.tm;
+  out->source = h->lane_s.tm;
+  out->ms_build_wait = h->ms_settle_wait;
+  out->mode = h->handoff_mode;
+  out->cpu_budget = host_cpu_budget();
+  out->repack_workers = (int)repack_workers();
   return NDT_OK;
 }
 

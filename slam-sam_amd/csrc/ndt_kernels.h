@@ -83,7 +83,8 @@ hipError_t launch_find_runs(const uint32_t* keys_sorted, size_t n, BuildGeom* gd
                             size_t run_tags_cap, uint32_t* seq, int* leaf_start, int* leaf_cnt, hipStream_t s);
 
 // tmp: the cloud chunk by chunk as [x | y | z] of `chunk` points (the last chunk shorter) -> SoA arrays
-void launch_unchunk_soa(const float* tmp, size_t n, size_t chunk, float* x, float* y, float* z, hipStream_t s);
+// host hand-off: one chunk [x(seg) | y(seg) | z(seg)] in mapped pinned host memory -> the SoA arrays (pulled over PCIe)
+void launch_pull_chunk(const float* stage_dev, size_t len, size_t seg, float* x, float* y, float* z, hipStream_t s);
 // multi-grid union table: cell2leaf[cells[i]] = slots[i], i < n (device arrays)
 void launch_scatter_heads(const int* cells, const int* slots, size_t n, int* cell2leaf, hipStream_t s);
 int finalize_blocks(int max_leaves);

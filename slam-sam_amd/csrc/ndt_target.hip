@@ -2229,18 +2229,28 @@ hipError_t sort_source_by_blocks(const float* x, const float* y, const float* z,
   return hipGetLastError();
 }
 
-// three SoA arrays in one launch (three hipMemcpyAsync cost three dispatches)
-// host upload: tmp holds the cloud chunk by chunk as [x(chunk) | y(chunk) | z(chunk)] (one H2D copy per
-// chunk instead of three); this puts it into the three SoA arrays
-__global__ void __launch_bounds__(256) k_unchunk_soa(const float* __restrict__ tmp, size_t n, size_t chunk,
-                                                    float* __restrict__ x, float* __restrict__ y, float* __restrict__ z) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const size_t lo = i / chunk * chunk, len = (n - lo < chunk) ? n - lo : chunk, off = i - lo;
-  const float* b = tmp + 3 * lo;
-  x[i] = b[off];
-  y[i] = b[len + off];
-  z[i] = b[2 * len + off];
+// Host hand-off: one chunk of a cloud, laid out in MAPPED PINNED HOST memory as [x(seg) | y(seg) | z(seg)] (seg = the
+// chunk's point count rounded up to 4), is pulled over PCIe straight into the three SoA arrays.  A kernel per chunk
+// instead of a copy-engine transfer per chunk plus a conversion kernel: the copy engine pays ~10 us per transfer (eight
+// 1.5 MB copies: 41 GB/s, one 12 MB copy: 55), a 64-block pull kernel per chunk reaches 49 GB/s and needs no second
+// pass over the data (tools/h2d_pull_probe.hip, profiles/r04_h2d_pull_probe.txt).  Few blocks on purpose: PCIe needs
+// ~100 KB in flight, not the machine.
+__global__ void __launch_bounds__(256) k_pull_chunk(const float* __restrict__ src, size_t len, size_t seg,
+                                                   float* __restrict__ x, float* __restrict__ y, float* __restrict__ z) {
+  const size_t n4 = len >> 2, stride = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool vec = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)z | (uintptr_t)src) & 15) == 0;
+  float* const dst[3] = {x, y, z};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float* s = src + (size_t)a * seg;
+    float* d = dst[a];
+    if (vec) {
+      for (size_t i = t; i < n4; i += stride) reinterpret_cast<float4*>(d)[i] = reinterpret_cast<const float4*>(s)[i];
+      if (t < (len & 3)) d[(n4 << 2) + t] = s[(n4 << 2) + t];
+    } else {
+      for (size_t i = t; i < len; i += stride) d[i] = s[i];
+    }
+  }
 }
 
 // multi-grid union table: cell2leaf[cells[i]] = slots[i] for the first leaf of every occupied cell
@@ -2563,9 +2573,10 @@ int build_read_stamps(unsigned long long* out) {
 #endif
 }
 
-void launch_unchunk_soa(const float* tmp, size_t n, size_t chunk, float* x, float* y, float* z, hipStream_t s) {
-  if (n == 0) return;
-  hipLaunchKernelGGL(k_unchunk_soa, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, tmp, n, chunk, x, y, z);
+void launch_pull_chunk(const float* stage_dev, size_t len, size_t seg, float* x, float* y, float* z, hipStream_t s) {
+  if (len == 0) return;
+  const unsigned blocks = (unsigned)std::min<size_t>(64, (len / 4 + 255) / 256 + 1);
+  hipLaunchKernelGGL(k_pull_chunk, dim3(blocks), dim3(256), 0, s, stage_dev, len, seg, x, y, z);
 }
 
 void launch_scatter_heads(const int* cells, const int* slots, size_t n, int* cell2leaf, hipStream_t s) {

@@ -6,7 +6,10 @@
 //   * the 6x6 solve (Cholesky fast path and eigen route), result_covariance, pose <-> matrix;
 //   * the shared-memory reducer with 4 threads x 2000 rounds (bit-identical sums on every rank);
 //   * SE(3) exp / log round trips;
-//   * the upload path's worker pool growing between two jobs whose captures live on dead frames.
+//   * the upload path's worker pool growing between two jobs whose captures live on dead frames;
+//   * the host half of the asynchronous cloud hand-off (stage_cloud): every layout and stride against a scalar
+//     restatement, the caller's cloud in an exactly-sized heap block (no byte beyond the last point's z is read)
+//     that is overwritten and freed THE MOMENT the call returns -- the staging copy must already be complete.
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <unistd.h>
@@ -14,11 +17,13 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <random>
 #include <unistd.h>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../slam-sam_amd/csrc/ndt_comm.h"
@@ -222,6 +227,61 @@ int main() {
       CHECK(upload(9, 64));
       CHECK(pool.pending == 0 && !pool.job);
     }
+  }
+
+  // ---- host half of the cloud hand-off ------------------------------------------------------------
+  // ndt_set_target / ndt_set_source return once stage_cloud has returned; from then on the caller may free or
+  // overwrite its cloud while the copies out of staging are still running.  Here the "copy engine" is a callback
+  // that records the chunks; the checks run AFTER the caller's memory is gone.
+  {
+    ndt::RepackPool pool;
+    std::uniform_real_distribution<float> U(-100.f, 100.f);
+    const size_t sizes[] = {1, 2, 3, 4, 5, 7, 8, 63, 4095, 8192, 8193, 20000, 131072, 131073, 300001};
+    const size_t strides[] = {12, 16, 20, 32, 48, 0 /* SoA */};
+    for (size_t n : sizes)
+      for (size_t stride : strides)
+        for (unsigned workers : {0u, 3u}) {
+          std::vector<float> want(3 * n);
+          for (auto& v : want) v = U(rng);
+          std::vector<float> stage(ndt::StageJob::stage_floats(n), -7.0f);
+          std::vector<std::pair<size_t, size_t>> chunks;
+          ndt::StageJob job;
+          job.n = n;
+          job.stage = stage.data();
+          char* aos = nullptr;
+          float *sx = nullptr, *sy = nullptr, *sz = nullptr;
+          if (stride) {
+            // exactly the bytes a strided cloud of n points owns: (n - 1) * stride + 12
+            const size_t bytes = (n - 1) * stride + 12;
+            aos = static_cast<char*>(std::malloc(bytes));
+            std::memset(aos, 0x5a, bytes);
+            for (size_t i = 0; i < n; ++i) std::memcpy(aos + i * stride, &want[3 * i], 12);
+            job.aos = aos;
+            job.stride = stride;
+          } else {
+            sx = static_cast<float*>(std::malloc(n * 4)); sy = static_cast<float*>(std::malloc(n * 4)); sz = static_cast<float*>(std::malloc(n * 4));
+            for (size_t i = 0; i < n; ++i) { sx[i] = want[3 * i]; sy[i] = want[3 * i + 1]; sz[i] = want[3 * i + 2]; }
+            job.x = sx; job.y = sy; job.z = sz;
+          }
+          ndt::stage_cloud(&pool, workers, job, [&](size_t c, size_t lo, size_t hi) {
+            CHECK(c == chunks.size());
+            chunks.emplace_back(lo, hi);
+          });
+          // the call has returned: the caller's memory is the caller's again
+          if (aos) { std::memset(aos, 0xff, (n - 1) * stride + 12); std::free(aos); }
+          if (sx) { std::memset(sx, 0xff, n * 4); std::free(sx); std::free(sy); std::free(sz); }
+          size_t covered = 0;
+          for (auto& ch : chunks) { CHECK(ch.first == covered); covered = ch.second; }
+          CHECK(covered == n);
+          bool same = true;
+          for (size_t i = 0; i < n && same; ++i) {
+            const size_t c0 = i / job.chunk * job.chunk, len = job.seg(i / job.chunk), off = i - c0;
+            const float* b = stage.data() + 3 * c0;
+            same = b[off] == want[3 * i] && b[len + off] == want[3 * i + 1] && b[2 * len + off] == want[3 * i + 2];
+          }
+          CHECK(same);
+        }
+    CHECK(ndt::host_cpu_budget() >= 1);
   }
 
   // ---- SE(3) ---------------------------------------------------------------------------------------

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(pkg):
     for name in declared:
         assert hasattr(L, name), "libndt_hip.so lacks %s" % name
     assert sorted(pkg.ABI_SYMBOLS) == declared  # the Python binding covers the whole ABI
-    assert L.ndt_abi_version() == 2
+    assert L.ndt_abi_version() == 3
 
 
 def test_abi_signatures_have_no_torch_types():

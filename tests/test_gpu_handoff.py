@@ -1,0 +1,160 @@
+"""The asynchronous hand-off of HOST clouds (ndt_set_target / ndt_set_source; the drivers hold host
+pcl::PointCloud<PointXYZI>, ref: run/pipeline.cpp:554-561): the calls return once the caller's memory has been
+consumed, copies and build finish behind them, the first call that needs them waits.  Nothing about the RESULTS may
+depend on the mode: every number here is compared bit for bit with the blocking hand-off of rounds 1-3."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _ndt(pkg, **kw):
+    base = dict(device_id=0, resolution=1.0, step_size=0.1, trans_epsilon=1e-4, max_iterations=35)
+    base.update(kw)
+    return pkg.NormalDistributionsTransform(**base)
+
+
+def _xyzi(a, fill=3.5):
+    out = np.full((len(a), 8), fill, np.float32)
+    out[:, :3] = a
+    return out
+
+
+def _leaves_equal(a, b):
+    for f in ("cell", "count", "mean", "cov", "icov", "evals"):
+        assert np.array_equal(a[f], b[f]), f
+
+
+def test_async_and_sync_handoff_agree_bit_for_bit(pkg, S):
+    """Scan after scan (steady-state builds are the deferred ones), three layouts, the caller's arrays
+    overwritten the moment the call returns."""
+    ca, cb = S.config_c2(), S.config_c1()
+    clouds = [(ca["target"], ca["source"], ca["guess"]), (cb["target"], cb["source"], cb["guess"]),
+              (ca["target"][::2], ca["source"][::3], ca["guess"])]
+    out = {}
+    for mode in (pkg.HANDOFF_SYNC, pkg.HANDOFF_ASYNC):
+        ndt = _ndt(pkg)
+        ndt.setHandoffMode(mode)
+        assert ndt.getHandoffMode() == mode
+        res = []
+        for rep in range(3):
+            for tgt, src, guess in clouds:
+                for layout in ("xyz", "xyzi", "soa"):
+                    if layout == "xyz":
+                        t, s = tgt.copy(), src.copy()
+                        ndt.setInputTarget(t); t[:] = np.nan
+                        ndt.setInputSource(s); s[:] = np.nan
+                    elif layout == "xyzi":
+                        t, s = _xyzi(tgt), _xyzi(src)
+                        ndt.setInputTarget(t); t[:] = np.nan
+                        ndt.setInputSource(s); s[:] = np.nan
+                    else:
+                        t = [np.ascontiguousarray(tgt[:, a]) for a in range(3)]
+                        s = [np.ascontiguousarray(src[:, a]) for a in range(3)]
+                        ndt.setInputTargetSoA(*t); [v.fill(np.nan) for v in t]
+                        ndt.setInputSourceSoA(*s); [v.fill(np.nan) for v in s]
+                    T = ndt.align(guess)
+                    r = ndt.getResult()
+                    res.append((T.copy(), r["iterations"], r["n_evaluations"], r["score"], r["hessian"].copy()))
+            if rep == 0:
+                res.append(ndt.getLeaves())
+        out[mode] = res
+        ndt.close()
+    for a, b in zip(out[pkg.HANDOFF_SYNC], out[pkg.HANDOFF_ASYNC]):
+        if isinstance(a, dict):
+            _leaves_equal(a, b)
+        else:
+            assert np.array_equal(a[0], b[0]) and a[1] == b[1] and a[2] == b[2] and a[3] == b[3]
+            assert np.array_equal(a[4], b[4])
+
+
+def test_deferred_build_failure_is_reported_by_the_first_consumer(pkg, S):
+    """A steady-state build that fails is reported by the first call that needs the grid (and by wait()), with the
+    status the blocking hand-off returns from setInputTarget; a later good target clears it."""
+    cfg = S.config_c1()
+    bad = np.full((5000, 3), np.nan, np.float32)
+    ndt = _ndt(pkg)
+    ndt.setInputTarget(cfg["target"])
+    ndt.setInputSource(cfg["source"])
+    ndt.align(cfg["guess"])
+    assert ndt.hasConverged()
+    # blocking hand-off: the error comes from setInputTarget itself
+    ndt.setHandoffMode(pkg.HANDOFF_SYNC)
+    with pytest.raises(pkg.NdtError) as ei:
+        ndt.setInputTarget(bad)
+    assert ei.value.code == -4
+    ndt.setInputTarget(cfg["target"])
+    ndt.align(cfg["guess"])
+    # asynchronous: setInputTarget has nothing to report yet; align / getGridInfo / getLeaves / wait do
+    ndt.setHandoffMode(pkg.HANDOFF_ASYNC)
+    ndt.setInputTarget(bad)
+    ndt.setStepSize(0.1)   # a setter in between neither reports nor loses the failure
+    with pytest.raises(pkg.NdtError) as ei:
+        ndt.align(cfg["guess"])
+    assert ei.value.code == -4 and "finite" in str(ei.value)
+    for call in (ndt.getGridInfo, ndt.getLeaves, ndt.wait):
+        with pytest.raises(pkg.NdtError) as ei:
+            call()
+        assert ei.value.code == -4
+    # the build after a failed one starts from a cleared index grid and waits for its geometry like a handle's
+    # first build: it completes inside the call, so its failure is reported there
+    with pytest.raises(pkg.NdtError) as ei:
+        ndt.setInputTarget(bad)
+    assert ei.value.code == -4
+    ndt.setInputTarget(cfg["target"])
+    ndt.wait()
+    ndt.setInputTarget(bad)       # steady state again: deferred
+    with pytest.raises(pkg.NdtError):
+        ndt.wait()
+    ndt.setInputTarget(cfg["target"])
+    ndt.wait()
+    T = ndt.align(cfg["guess"])
+    dt, dr = S.pose_error(T, cfg["gt"])
+    assert ndt.hasConverged() and dt < 0.05 and dr < 0.035
+
+
+def test_handoff_overlaps_and_every_consumer_waits(pkg, O, S):
+    """Target and source handed over back to back, then every kind of consumer first: each must see the NEW clouds."""
+    a, b = S.config_c1(), S.config_c2()
+    ndt = _ndt(pkg)
+    ndt.setInputTarget(a["target"]); ndt.setInputSource(a["source"]); ndt.align(a["guess"])   # first build: blocking
+    consumers = {
+        "align": lambda: ndt.align(b["guess"]),
+        "evalDerivatives": lambda: ndt.evalDerivatives(O.matrix_to_pose(b["guess"])),
+        "scoreTransform": lambda: ndt.scoreTransform(b["guess"]),
+        "getGridInfo": ndt.getGridInfo,
+        "getLeaves": ndt.getLeaves,
+        "setResolution": lambda: ndt.setResolution(1.0),
+        "transformSource": lambda: ndt.transformSource(b["guess"]) if hasattr(ndt, "transformSource") else None,
+    }
+    grid_b = O.Grid(b["target"], O.default_params(resolution=1.0))
+    ref = grid_b.derivatives(b["source"], O.matrix_to_pose(b["guess"]))
+    for name, first in consumers.items():
+        ndt.setInputTarget(a["target"]); ndt.setInputSource(a["source"]); ndt.align(a["guess"])
+        ndt.setInputTarget(b["target"])
+        ndt.setInputSource(b["source"])
+        first()
+        gi = ndt.getGridInfo()
+        assert gi["n_leaves"] == grid_b.n_leaves, name
+        e = ndt.evalDerivatives(O.matrix_to_pose(b["guess"]))[0]
+        assert e["n_pairs"] == ref["n_pairs"], name
+        np.testing.assert_allclose(e["score"], ref["score"], rtol=1e-9, err_msg=name)
+    t = ndt.getHandoffTiming()
+    assert t["mode"] == pkg.HANDOFF_ASYNC and t["target"]["n_points"] == len(b["target"])
+    assert t["source"]["n_points"] == len(b["source"]) and t["target"]["threads"] >= 1 and t["cpu_budget"] >= 1
+    assert t["target"]["bytes_dma"] == 12 * len(b["target"])
+
+
+def test_handoff_timing_reports_dma_rate(pkg, S):
+    cfg = S.config_c2()
+    ndt = _ndt(pkg)
+    t32, s32 = _xyzi(cfg["target"]), _xyzi(cfg["source"])
+    for _ in range(2):
+        ndt.setInputTarget(t32); ndt.setInputSource(s32); ndt.align(cfg["guess"])
+    ndt.enableKernelTiming(True)
+    ndt.setInputTarget(t32); ndt.setInputSource(s32); ndt.align(cfg["guess"])
+    ndt.wait()
+    t = ndt.getHandoffTiming()
+    ndt.enableKernelTiming(False)
+    assert t["target"]["bytes_in"] == 32 * len(t32) and t["target"]["ms_dma"] > 0 and t["target"]["dma_gb_per_s"] > 1.0
+    assert t["source"]["ms_dma"] > 0 and t["source"]["ms_repack"] > 0
