@@ -36,6 +36,8 @@ for _v in ("OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "BLIS_NUM_THREADS"):
     os.environ.setdefault(_v, "1")
 # A rank that stops answering inside an all-reduce is a failed reduce variant here, not something to sit out
 os.environ.setdefault("NDT_COMM_TIMEOUT_S", "20")
+import hashlib
+import struct
 import sys
 import threading
 import time
@@ -201,8 +203,9 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
     hip = R.Hip()
-    if hip.device_count() <= 0:
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    # LOCAL_RANK is the device ordinal; a rank whose launcher narrowed the visible devices to one uses device 0
+    # and says so in config.launch; LOCAL_RANK beyond the visible devices otherwise ends the rank with one clear line
+    local_rank, device_note = R.pick_device(local_rank, world, hip.device_count(), rehearsal)
     hip.set_device(local_rank)
     multi = world > 1 or force_dist
     board = R.Board(R.board_path(), rank, world) if multi else None
@@ -289,12 +292,21 @@ def main():
         if elapsed == float("inf"):
             return None
         pre1 = ndt.prelaunchCounters()
-        err_t, err_r = S.pose_error(ndt.getResult()["T"], cfg["gt"])
+        last = ndt.getResult()
+        err_t, err_r = S.pose_error(last["T"], cfg["gt"])
+        # the answer, bit for bit: final transform and Hessian of the last step, iterations and evaluations of all steps
+        digest = hashlib.sha256(np.ascontiguousarray(last["T"]).tobytes() + np.ascontiguousarray(last["hessian"]).tobytes() +
+                                struct.pack("<qq", iters, evals)).hexdigest()[:16]
         return dict(elapsed=elapsed, iters=iters, evals=evals, reused=reused, t_build=t_build, t_align=t_align,
-                    prelaunched=pre1[0] - pre0[0], prelaunch_timeouts=pre1[2] - pre0[2], err_m=err_t, err_rad=err_r)
+                    prelaunched=pre1[0] - pre0[0], prelaunch_timeouts=pre1[2] - pre0[2], err_m=err_t, err_rad=err_r,
+                    digest=digest, lost_row_retries=ndt.lostRowRetries())
+
+    unavailable = {}
 
     def init_reducer(mode):
-        """Creates the engine's cross-rank reducer on every rank; False if any rank failed."""
+        """Creates the engine's cross-rank reducer on every rank; False if any rank failed.  A transport the engine
+        REFUSES because it cannot work here (NDT_ERR_UNSUPPORTED: no peer access, an area that cannot be opened) is
+        recorded as unavailable with the engine's reason -- distinct from one that failed while running."""
         ok = 1.0
         try:
             if mode == "rccl":   # the engine's own RCCL communicator; rank 0's id travels over the board
@@ -310,9 +322,17 @@ def main():
                 ndt.commInitShm(name, rank, world)
         except (pkg.NdtError, AttributeError) as e:
             print("rank %d: %s reducer failed (%s)" % (rank, mode, e), file=sys.stderr, flush=True)
-            ok = 0.0
-        if board.allmin(ok) == 0.0:
+            ok = -1.0 if getattr(e, "code", 0) == -9 else 0.0
+            unavailable[mode] = str(e)
+        worst = board.allmin(ok)
+        if worst <= 0.0:
             ndt.commDestroy()
+            if worst < 0.0:
+                # every rank reports the same variant the same way: the reason of the lowest rank that has one
+                reasons = board.allgather(unavailable.get(mode, "").encode()[:250])
+                unavailable[mode] = next((r.decode(errors="replace") for r in reasons if r), "unsupported")
+            else:
+                unavailable.pop(mode, None)
             return False
         ndt.setGlobalSourceSize(n_src_total)
         return True
@@ -433,12 +453,31 @@ def main():
         for _ in range(3):
             hstep()
         k, iters, tt, ts, ta = 10, 0, 0.0, 0.0, 0.0
+        rp_t = rp_s = bw = 0.0
         t0 = time.perf_counter()
         for _ in range(k):
             a, b_, c_ = hstep()
             tt += a; ts += b_; ta += c_
             iters += ndt.getFinalNumIteration()
+            ht = ndt.getHandoffTiming()
+            rp_t += ht["target"]["ms_repack"]; rp_s += ht["source"]["ms_repack"]; bw += ht["ms_build_wait"]
         el = time.perf_counter() - t0
+        # one instrumented scan for what the engine can only time with events: the transfers and the build
+        ndt.enableKernelTiming(True)
+        hstep()
+        ndt.wait()
+        hi = ndt.getHandoffTiming()
+        gi_h = ndt.getGridInfo()
+        ndt.enableKernelTiming(False)
+        # the same scan with the blocking hand-off of rounds 1-3 (ndt_set_handoff_mode), for the difference
+        ndt.setHandoffMode(pkg.HANDOFF_SYNC)
+        for _ in range(2):
+            hstep()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            hstep()
+        el_sync = time.perf_counter() - t1
+        ndt.setHandoffMode(pkg.HANDOFF_ASYNC)
         # leave the engine as the timed steps use it
         ndt.setInputTargetDevice(tptr[0], tptr[1], tptr[2], n_tgt)
         ndt.setInputSourceDeviceView(sptr[0], sptr[1], sptr[2], c)
@@ -457,10 +496,23 @@ def main():
                                "1.14's steps), same source size, synthetic room")
             except Exception as e:  # noqa: BLE001
                 pre = {"error": str(e)}
-        return {"what": "PCIe-inclusive: host PointXYZI (32 B/pt) clouds through ndt_set_target / ndt_set_source, then align",
+        return {"what": "PCIe-inclusive: host PointXYZI (32 B/pt) clouds through ndt_set_target / ndt_set_source, then align; "
+                        "asynchronous hand-off (the calls return once the caller's cloud is repacked into pinned staging; "
+                        "transfer and build run behind, the target's under the source's repack; align waits for them)",
                 "pcl_registration": pre,
                 "value": iters / el, "unit": "iterations/s", "ms_scan": 1e3 * el / k, "ms_set_target": 1e3 * tt / k,
-                "ms_set_source": 1e3 * ts / k, "ms_align": 1e3 * ta / k, "steps": k}
+                "ms_set_source": 1e3 * ts / k, "ms_align": 1e3 * ta / k, "steps": k,
+                "ms_scan_blocking_handoff": 1e3 * el_sync / 5,
+                "breakdown": {"ms_repack_target": rp_t / k, "ms_repack_source": rp_s / k,
+                              "ms_align_waited_for_build": bw / k,
+                              "ms_transfer_target": hi["target"]["ms_dma"], "ms_transfer_source": hi["source"]["ms_dma"],
+                              "pcie_gb_per_s_target": hi["target"]["dma_gb_per_s"], "pcie_gb_per_s_source": hi["source"]["dma_gb_per_s"],
+                              "bytes_read_target": hi["target"]["bytes_in"], "bytes_over_pcie_target": hi["target"]["bytes_dma"],
+                              "ms_build_device": gi_h["ms_build"], "repack_threads": hi["target"]["threads"],
+                              "cpu_budget": hi["cpu_budget"],
+                              "note": "ms_transfer_*: device time from before a cloud's first chunk to behind its last (HIP "
+                                      "events, one instrumented scan): chunks are pulled over PCIe as the repack finishes "
+                                      "them, so this window contains the repack it overlaps"}}
 
     def scaling_probe():
         """Not part of `value`: the same engine on a source five times larger (the map's own
@@ -542,6 +594,18 @@ def main():
         hc = host_cloud()
         if out is not None and hc is not None:
             out["host_cloud"] = hc
+        # the other single-GPU configurations of BASELINE.json (C2 scan-to-scan, C5 replay), bounded to a few seconds
+        if out is not None and os.environ.get("NDT_BENCH_CONFIGS", "1") == "1":
+            import bench_configs as BC
+            cfgs = {}
+            for name, fn in (("C2", lambda: BC.c2_block(pkg, hip)), ("C5", lambda: BC.c5_block(pkg))):
+                try:
+                    t_c = time.perf_counter()
+                    cfgs[name] = fn()
+                    cfgs[name]["seconds"] = time.perf_counter() - t_c
+                except Exception as e:  # noqa: BLE001  -- never at the cost of the headline line
+                    cfgs[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+            out["configs"] = cfgs
         probe = scaling_probe()
         if out is not None and probe is not None:
             out["scaling_probe"] = probe
@@ -561,15 +625,22 @@ def main():
         forced = os.environ.get("NDT_BENCH_REDUCE")
         modes = [forced] if forced in ("rccl", "shm", "p2p") else ["shm", "p2p", "rccl"]
         out, best = None, None
-        state = {"out": None}
+        state = {"out": None, "mode": None}
+        digests = {}
+        # Every variant runs under a watchdog with its share of the wall budget (ranks.variant_budget: the driver allows
+        # 600 s for the whole command): a transport that hangs costs its own share, not the measurement -- the watchdog
+        # prints the line assembled from the variants that did finish and ends the rank with status 4.
+        budget = R.variant_budget(len(modes))
 
         def on_timeout():
-            """The RCCL pass did not finish: print what the earlier passes measured (marked as a failed
-            RCCL leg) and end EVERY rank with a non-zero status, so the hang shows in the run record
-            instead of passing as rc 0."""
+            """A variant did not finish inside its budget: print what the earlier variants measured (this one marked as
+            timed out) and end EVERY rank with a non-zero status, so the hang shows in the run record instead of
+            passing as rc 0."""
+            mode = state["mode"]
+            print("rank %d: reduce variant %s exceeded its wall budget of %.0f s" % (rank, mode, budget), file=sys.stderr, flush=True)
             if rank == 0 and state["out"] is not None:
-                state["out"]["config"]["reduce_variants"]["rccl"] = "timed out"
-                state["out"]["reduce_failed"] = "rccl"
+                state["out"]["config"]["reduce_variants"][mode] = "timed out"
+                state["out"]["reduce_failed"] = mode
                 os.write(json_fd, (json.dumps(state["out"]) + "\n").encode())
             if shm_name["name"]:
                 try:
@@ -581,15 +652,17 @@ def main():
             os._exit(4)
 
         for mode in modes:
-            dog = None
-            if mode == "rccl":
-                dog = threading.Timer(float(os.environ.get("NDT_BENCH_RCCL_TIMEOUT", "150")), on_timeout)
-                dog.daemon = True
-                dog.start()
+            state["mode"] = mode
+            dog = threading.Timer(float(os.environ.get("NDT_BENCH_RCCL_TIMEOUT", budget)) if mode == "rccl" else budget, on_timeout)
+            dog.daemon = True
+            dog.start()
             if not init_reducer(mode):
-                variants[mode] = None
-                if out is not None:
-                    out.setdefault("reduce_failed", mode)
+                if mode in unavailable:
+                    variants[mode] = {"unavailable": unavailable[mode]}
+                else:
+                    variants[mode] = None
+                    if out is not None:
+                        out.setdefault("reduce_failed", mode)
             else:
                 n_comm = ndt.commRankCount()
                 current["mode"], current["steps"] = mode, 0
@@ -600,13 +673,28 @@ def main():
                         out.setdefault("reduce_failed", mode)
                     ndt.commDestroy()
                 else:
-                    # a transport that sums wrongly shows up in the answer: the same scan must land on the same pose
+                    # A transport that sums wrongly shows up in the answer.  (1) the same scan must land on the same pose;
+                    # (2) every rank runs the same host loop on the same sums: final transform, Hessian, iterations and
+                    # evaluations must agree BIT FOR BIT across the ranks; (3) shm and p2p add the same rows in the same
+                    # rank order: their answers must be identical too (RCCL's ring adds in another order: not required).
                     sane = bool(board.allmax(0.0 if res["err_m"] < 0.05 else 1.0) == 0.0)
+                    all_digests = [d.decode() for d in board.allgather(res["digest"].encode())]
+                    ranks_agree = len(set(all_digests)) == 1
+                    digests[mode] = all_digests[0] if ranks_agree else None
                     variants[mode] = {"value": res["iters"] / res["elapsed"], "ms_per_step": 1e3 * res["elapsed"] / args.steps,
                                       "ranks": n_comm, "evaluations_prelaunched_per_align": res["prelaunched"] / args.steps,
-                                      "iterations_per_align": res["iters"] / args.steps, "final_error_m": res["err_m"]}
+                                      "iterations_per_align": res["iters"] / args.steps, "final_error_m": res["err_m"],
+                                      "answer_digest": digests[mode], "ranks_bit_identical": ranks_agree,
+                                      "lost_row_retries": res["lost_row_retries"]}
                     if not sane:
                         variants[mode]["suspect"] = "final pose more than 5 cm from ground truth: not eligible as the headline"
+                    elif not ranks_agree:
+                        sane = False
+                        variants[mode]["suspect"] = "the ranks' answers differ (%s): not eligible as the headline" % ",".join(all_digests)
+                    elif mode in ("shm", "p2p") and all(digests.get(m) for m in ("shm", "p2p")) and digests["shm"] != digests["p2p"]:
+                        sane = False
+                        variants[mode]["suspect"] = ("answer differs from the shm variant's (%s vs %s): the two add the same rows in "
+                                                     "the same order and must agree bit for bit" % (digests["p2p"], digests["shm"]))
                     if mode == "rccl":
                         variants[mode]["ncclCommCount"] = n_comm
                     if out is None and sane:
@@ -623,14 +711,15 @@ def main():
                     ndt.commDestroy()
             if rank == 0:
                 state["out"] = out
-            if dog is not None:
-                board.barrier()
-                dog.cancel()
+            board.barrier()
+            dog.cancel()
         if best is None:
             raise SystemExit("no cross-rank reducer could be created")
         if out is not None and "config" in out:
             out["config"]["rccl"] = comm_record()
-            out["config"]["launch"] = "self-launched ranks" if "NDT_RANKS_BOARD" in os.environ else "external launcher"
+            out["config"]["launch"] = ("self-launched ranks" if "NDT_RANKS_BOARD" in os.environ else "external launcher") + \
+                                      ("; " + device_note if device_note else "")
+            out["config"]["variant_wall_budget_s"] = budget
         if rank != 0:
             out = None
         board.barrier()

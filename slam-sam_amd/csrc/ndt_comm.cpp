@@ -229,18 +229,15 @@ int Reducer::init_p2p(const void* handles, int rank, int nranks, std::string* er
     if (err) *err = "ndt_comm_init_p2p before ndt_comm_p2p_handle";
     return NDT_ERR_INVALID_ARG;
   }
-  // peer access to every other visible device (xGMI): kernels of this device will store into their memory
-  int dev = 0, ndev = 0;
+  // Peer access (xGMI): kernels of this device will store into the other ranks' memory.  A transport that cannot work
+  // is REFUSED here, with a reason (NDT_ERR_UNSUPPORTED): an area that cannot be opened, or one on a device this one
+  // has no peer access to, would otherwise surface as a 20 ms kernel-side time-out per evaluation.
+  int dev = 0;
   (void)hipGetDevice(&dev);
-  (void)hipGetDeviceCount(&ndev);
-  for (int d = 0; d < ndev; ++d) {
-    if (d == dev) continue;
-    int can = 0;
-    if (hipDeviceCanAccessPeer(&can, dev, d) == hipSuccess && can) {
-      hipError_t e = hipDeviceEnablePeerAccess(d, 0);
-      if (e != hipSuccess) (void)hipGetLastError();  // already enabled: fine
-    }
-  }
+  auto close_opened = [&](int upto) {
+    for (int q = 0; q < upto; ++q)
+      if (q != rank && xpeer_[q]) { (void)hipIpcCloseMemHandle(xpeer_[q]); xpeer_[q] = nullptr; }
+  };
   XchgInfo info;
   std::memset(&info, 0, sizeof(info));
   info.rank = rank;
@@ -253,12 +250,35 @@ int Reducer::init_p2p(const void* handles, int rank, int nranks, std::string* er
     hipError_t e = hipIpcOpenMemHandle(&p, hd, hipIpcMemLazyEnablePeerAccess);
     if (e != hipSuccess || !p) {
       (void)hipGetLastError();
-      if (err) *err = hip_err("hipIpcOpenMemHandle(peer exchange area)", e);
-      for (int q = 0; q < r; ++q)
-        if (q != rank && xpeer_[q]) { (void)hipIpcCloseMemHandle(xpeer_[q]); xpeer_[q] = nullptr; }
-      return NDT_ERR_COMM;
+      if (err) *err = "p2p unavailable: " + hip_err(("hipIpcOpenMemHandle(exchange area of rank " + std::to_string(r) + ")").c_str(), e) +
+                      " -- are all ranks' devices visible to every rank (no per-rank HIP_VISIBLE_DEVICES)?";
+      close_opened(r);
+      return NDT_ERR_UNSUPPORTED;
     }
     xpeer_[r] = p;
+    hipPointerAttribute_t attr;
+    std::memset(&attr, 0, sizeof(attr));
+    if (hipPointerGetAttributes(&attr, p) == hipSuccess && attr.device != dev) {
+      int can = 0;
+      hipError_t ea = hipDeviceCanAccessPeer(&can, dev, attr.device);
+      if (ea != hipSuccess || !can) {
+        (void)hipGetLastError();
+        if (err) *err = "p2p unavailable: device " + std::to_string(dev) + " has no peer access to device " +
+                        std::to_string(attr.device) + " (rank " + std::to_string(r) + ")";
+        close_opened(r + 1);
+        return NDT_ERR_UNSUPPORTED;
+      }
+      hipError_t ep = hipDeviceEnablePeerAccess(attr.device, 0);
+      if (ep != hipSuccess && ep != hipErrorPeerAccessAlreadyEnabled) {
+        (void)hipGetLastError();
+        if (err) *err = "p2p unavailable: " + hip_err("hipDeviceEnablePeerAccess", ep);
+        close_opened(r + 1);
+        return NDT_ERR_UNSUPPORTED;
+      }
+      (void)hipGetLastError();
+    } else {
+      (void)hipGetLastError();
+    }
   }
   for (int r = 0; r < nranks; ++r) info.area[r] = (unsigned long long)reinterpret_cast<uintptr_t>(xpeer_[r]);
   hipError_t e = hipSuccess;
@@ -278,6 +298,27 @@ int Reducer::init_p2p(const void* handles, int rank, int nranks, std::string* er
   return NDT_OK;
 }
 
+#ifdef __HIPCC__
+namespace {
+struct RowArg { unsigned long long w[2 * NDT_EVAL_WORDS]; };
+// The host leg of the exchange writes a row exactly as the derivative kernel does: lane v stores slot v {round, value}
+// with ONE 16-byte system-scope store into every rank's area -- a reader sees a slot entirely old or entirely new.  (A
+// 512-byte hipMemcpy into a peer's mapping promises nothing about the order in which its bytes land: ADVICE r03.)
+__global__ void __launch_bounds__(64) k_publish_row(XchgInfo info, unsigned long long round, RowArg row) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const int v = threadIdx.x;
+  if (v >= NDT_EVAL_WORDS) return;
+  u32x4 d;
+  d.x = (unsigned int)row.w[2 * v]; d.y = (unsigned int)(row.w[2 * v] >> 32);
+  d.z = (unsigned int)row.w[2 * v + 1]; d.w = (unsigned int)(row.w[2 * v + 1] >> 32);
+  for (int r = 0; r < info.nranks; ++r) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(info.area[r]), 0, 0xFFFFFFFFu, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(d, rs, xchg_slot_offset(round, info.rank, v), 0, 17 /* sc0 sc1: system scope */);
+  }
+}
+}  // namespace
+#endif
+
 // one row {round, value} x n of the own rank into every rank's area, from the host (batched evaluations)
 int Reducer::p2p_publish_from_host(uint64_t round, const double* words, int n, std::string* err) {
   unsigned long long row[2 * NDT_EVAL_WORDS];
@@ -286,6 +327,25 @@ int Reducer::p2p_publish_from_host(uint64_t round, const double* words, int n, s
     double w = v < n ? words[v] : 0.0;
     std::memcpy(&row[2 * v + 1], &w, sizeof(double));
   }
+#ifdef __HIPCC__
+  {
+    XchgInfo info;
+    std::memset(&info, 0, sizeof(info));
+    info.rank = rank_;
+    info.nranks = nranks_;
+    for (int r = 0; r < nranks_; ++r) info.area[r] = (unsigned long long)reinterpret_cast<uintptr_t>(xpeer_[r]);
+    RowArg ra;
+    std::memcpy(ra.w, row, sizeof(row));
+    hipLaunchKernelGGL(k_publish_row, dim3(1), dim3(64), 0, nullptr, info, (unsigned long long)round, ra);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) {
+      if (err) *err = hip_err("peer-write from the host (publish kernel)", e);
+      return NDT_ERR_COMM;
+    }
+    return NDT_OK;
+  }
+#endif
   for (int r = 0; r < nranks_; ++r) {
     hipError_t e = hipMemcpy(static_cast<char*>(xpeer_[r]) + xchg_slot_offset(round, rank_, 0), row, sizeof(row), hipMemcpyHostToDevice);
     if (e != hipSuccess) {

@@ -821,7 +821,7 @@ __device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], double
                                                     int single_level_max, bool fixed_summer,
                                                     const XchgInfo* __restrict__ xi, unsigned long long xround,
                                                     int my_row /* this block's row */, int nb /* rows = computing blocks */,
-                                                    bool dedicated /* a block without points adds the rows */) {
+                                                    bool dedicated /* a block without points adds the rows */, int mute_row = 0) {
   __shared__ double lds_w[MAX_WAVES][EV_WORDS];
   __shared__ double lds_c[MAX_COLS][EV_WORDS];
   __shared__ int s_last;
@@ -836,6 +836,9 @@ __device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], double
     double sum = 0.0;
     const int nwaves = (int)blockDim.x >> 6;
     for (int wv = 0; wv < nwaves; ++wv) sum += lds_w[wv][threadIdx.x];
+#ifdef NDT_TEST_SEAMS
+    if (mute_row != my_row + 1)   // (seam: this block's row never arrives)
+#endif
     store_slot(rrows, ((unsigned int)my_row * EV_WORDS + threadIdx.x) * 16u, seq, sum, false);
   }
   NDT_STAMP(4);
@@ -1129,7 +1132,7 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
                       flag ? flag + (size_t)blockIdx.y * ROW_WORDS : nullptr,  // pose y's 32 host slots
                       seq, ec.single_level_max,
                       ec.fixed_summer != 0, BATCH ? nullptr : xinfo, xround, chunk,
-                      (int)gridDim.x - ec.dedicated_summer, ec.dedicated_summer != 0);
+                      (int)gridDim.x - ec.dedicated_summer, ec.dedicated_summer != 0, ec.mute_row);
 }
 
 __global__ void __launch_bounds__(256) k_transform(const float* __restrict__ sx, const float* __restrict__ sy,
@@ -1250,13 +1253,20 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
                         unsigned long long seq, const PoseMailbox* d_mbox, const XchgInfo* d_xinfo,
                         unsigned long long xround, unsigned int* d_arrive_ctr, unsigned long long* d_arrived_host,
                         hipEvent_t ev_start, hipEvent_t ev_stop) {
-  const int blocks = derivs_grid_blocks(n_src, d_poses ? K : 1);
+  int blocks = derivs_grid_blocks(n_src, d_poses ? K : 1);
   const int threads = derivs_block_threads(n_src, d_poses ? K : 1);
   const int mode = ec.score_only ? 3 : (!ec.need_hessian ? 0 : (ec.gauss_newton ? 2 : 1));
   EvalConsts ecl = ec;
   ecl.single_level_max = deriv_single_level_max();
   ecl.fixed_summer = deriv_fixed_summer();
   ecl.dedicated_summer = derivs_dedicated_summer(n_src, d_poses ? K : 1);
+  if (ec.safe_sum) {
+    // Same rows in the same order, added by the block that draws the last ticket: by then every row has been issued,
+    // so nothing in the launch waits for a block that is not resident (a device shared with other processes).
+    ecl.fixed_summer = 0;
+    ecl.dedicated_summer = 0;
+    blocks = derivs_point_blocks(n_src, d_poses ? K : 1);
+  }
   static const bool xcd_on = [] { const char* e = getenv("NDT_DERIV_XCD"); return !(e && atoi(e) == 0); }();  // A/B knob
   // Only while the whole grid is resident at once (at most one block per compute unit): on larger grids an XCD that
   // drew an expensive eighth of the source finishes late, round after round (C3, 400 k / 800 k points: 26.9 / 44.6 us

@@ -127,6 +127,9 @@ struct EvalConsts {
   int multigrid;   // 1: the table is a union of grids (radius search, leaves of a cell chained through VoxelRecord::pad)
   int packed;      // 1: the kernel's `rec` argument points at PackedRecord[] (48 bytes per leaf) instead of VoxelRecord[]
   int xcd_chunks;  // 1: the blocks an XCD receives (workgroup id mod 8) take CONSECUTIVE chunks of the source (single-pose launches)
+  int safe_sum;    // 1: the final sum is made by the block that draws the LAST TICKET (no block waits for rows of blocks that
+                   // may not be resident): the re-evaluation after a lost row
+  int mute_row;    // test seam (libndt_hip_seams.so only): row + 1 of the block that withholds its partial row; 0 = none
 };
 
 // layout of one evaluation (matches NDT_EVAL_WORDS in include/ndt_hip.h)

@@ -182,21 +182,92 @@ def board_path():
     return "/dev/shm/ndt_board_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"))
 
 
+def pick_device(local_rank, world, device_count, rehearsal=False):
+    """Which device a rank binds, and a note for config.launch.  One rank per device is the deployment: LOCAL_RANK is the
+    device ordinal.  A launcher that narrows the visible devices per rank (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES:
+    device count 1 while WORLD_SIZE > 1) leaves exactly one choice, device 0 -- hipSetDevice(LOCAL_RANK) would fail
+    there.  Anything else with LOCAL_RANK beyond the device count is a launch error: one clear line, non-zero exit."""
+    if device_count <= 0:
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if rehearsal:
+        return 0, "rehearsal: every rank on device 0 (NDT_BENCH_SINGLE_DEVICE=1)"
+    if local_rank < device_count:
+        return local_rank, None
+    if device_count == 1 and world > 1:
+        return 0, "rank sees ONE device (visible devices narrowed per rank by the launcher): device 0 used for LOCAL_RANK %d" % local_rank
+    raise SystemExit("bench.py: LOCAL_RANK %d but only %d device(s) visible to this rank (WORLD_SIZE %d): launch one rank per "
+                     "visible device, or narrow the visible devices to one per rank" % (local_rank, device_count, world))
+
+
+def variant_budget(n_variants, total=None):
+    """Wall seconds one reduce variant of a multi-rank bench may take before the watchdog ends the run with what has been
+    measured: the driver allows 600 s for the whole command; NDT_BENCH_WALL_BUDGET (default 420 s) is split evenly over
+    the variants plus one share for set-up, the probe and tear-down.  NDT_BENCH_VARIANT_TIMEOUT pins it."""
+    pinned = os.environ.get("NDT_BENCH_VARIANT_TIMEOUT")
+    if pinned:
+        return max(1.0, float(pinned))
+    if total is None:
+        total = float(os.environ.get("NDT_BENCH_WALL_BUDGET", "420"))
+    return max(5.0, total / (max(1, n_variants) + 1))
+
+
+def _die_with_parent():
+    """preexec_fn of a rank: SIGTERM when the parent dies, however it dies (a SIGKILLed parent cannot tell anyone)."""
+    try:
+        C.CDLL("libc.so.6", use_errno=True).prctl(1, 15)   # PR_SET_PDEATHSIG, SIGTERM
+    except Exception:
+        pass
+
+
 def launch(nranks, argv, timeout=None, extra_env=None):
     """PARENT side: start `nranks` children running `argv` (one per GPU; LOCAL_RANK = RANK), relay rank
     0's stdout line by line, wait for all.  Returns the exit status for the parent: 0 only if every child
     returned 0.  A child that fails takes the others down (they would wait for it for ever).  The parent
-    never touches a GPU."""
+    never touches a GPU.  The ranks run in sessions of their own and are ended with the parent: SIGTERM / SIGINT to
+    the parent (`timeout -k 10 400 python bench.py --gpus 2` signals only the parent) is passed on to every rank's
+    process group, a parent that is killed outright takes them along through PR_SET_PDEATHSIG, and the board file is
+    unlinked on every way out."""
+    import signal
     base = dict(os.environ)
     base.update(extra_env or {})
     base["WORLD_SIZE"] = str(nranks)
     base["NDT_RANKS_BOARD"] = "/dev/shm/ndt_board_%d_%d" % (os.getpid(), time.monotonic_ns() & 0xFFFFFF)
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL / hipIpc across processes need it on this pool
     procs = []
+    stop = {"sig": None}
+
+    def on_signal(signum, _frame):
+        stop["sig"] = signum
+
+    old = {}
+    for sg in (signal.SIGTERM, signal.SIGINT):
+        try:
+            old[sg] = signal.signal(sg, on_signal)
+        except ValueError:   # not the main thread
+            pass
+    try:
+        return _launch(nranks, argv, timeout, base, procs, stop)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+        for sg, h in old.items():
+            signal.signal(sg, h)
+        try:
+            os.unlink(base["NDT_RANKS_BOARD"])
+        except OSError:
+            pass
+
+
+def _launch(nranks, argv, timeout, base, procs, stop):
+    import signal
     for r in range(nranks):
         env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen(argv, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr,
-                                      text=(r == 0)))
+                                      text=(r == 0), start_new_session=True, preexec_fn=_die_with_parent))
     import threading
 
     def relay():
@@ -217,26 +288,31 @@ def launch(nranks, argv, timeout=None, extra_env=None):
                 if rc != 0 and status == 0:
                     status = rc if rc > 0 else 128 - rc
                     print("ranks.launch: rank %d exited with %d; stopping the others" % (r, rc), file=sys.stderr, flush=True)
-        if status != 0 or (timeout is not None and time.monotonic() - t0 > timeout):
-            if status == 0:
+        if status != 0 or stop["sig"] is not None or (timeout is not None and time.monotonic() - t0 > timeout):
+            if status == 0 and stop["sig"] is not None:
+                status = 128 + int(stop["sig"])
+                print("ranks.launch: signal %d: stopping the ranks" % stop["sig"], file=sys.stderr, flush=True)
+            elif status == 0:
                 status = 124
                 print("ranks.launch: timed out after %.0f s" % timeout, file=sys.stderr, flush=True)
             t_kill = time.monotonic()
             for r in sorted(live):
-                procs[r].terminate()
+                try:
+                    os.killpg(procs[r].pid, signal.SIGTERM)   # the rank's whole session (it may have children of its own)
+                except OSError:
+                    pass
             for r in sorted(live):
                 try:
                     procs[r].wait(timeout=max(0.1, 10.0 - (time.monotonic() - t_kill)))
                 except subprocess.TimeoutExpired:
-                    procs[r].kill()
+                    try:
+                        os.killpg(procs[r].pid, signal.SIGKILL)
+                    except OSError:
+                        pass
                     procs[r].wait()
             live.clear()
         time.sleep(0.02)
     t.join(timeout=5.0)
-    try:
-        os.unlink(base["NDT_RANKS_BOARD"])
-    except OSError:
-        pass
     return status
 
 

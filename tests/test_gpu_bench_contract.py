@@ -35,6 +35,24 @@ def test_bench_line_schema():
     assert abs(rb["achieved"] - rb["algorithmic_bytes"] / (rb["ms_device"] * 1e-3) / 1e9) < 1e-6 * rb["achieved"]
     hc = d["host_cloud"]
     assert hc["unit"] == "iterations/s" and 0 < hc["value"] < d["value"] and hc["ms_scan"] > d["ms_per_step"]
+    bd = hc["breakdown"]
+    assert bd["ms_repack_target"] > 0 and bd["ms_repack_source"] > 0 and bd["ms_align_waited_for_build"] >= 0
+    assert bd["ms_transfer_target"] > 0 and bd["pcie_gb_per_s_target"] > 1 and bd["bytes_over_pcie_target"] == 12 * d["config"]["n_target"]
+    assert bd["bytes_read_target"] == 32 * d["config"]["n_target"] and bd["repack_threads"] >= 1 and bd["ms_build_device"] > 0
+    # the hand-off the unchanged drivers use (run/pipeline.cpp:554-561): returns before the device has the cloud
+    assert hc["ms_set_target"] < hc["ms_scan_blocking_handoff"] and hc["ms_scan_blocking_handoff"] > 0
+    # the other single-GPU configurations on the same line: C2 scan-to-scan, C5 replay (BASELINE.json configs[1], [4])
+    c2 = d["configs"]["C2"]
+    assert "error" not in c2 and c2["unit"] == "iterations/s" and c2["value"] > 0 and c2["ms_scan"] > 0 and c2["us_per_evaluation"] > 0
+    assert 0 < c2["roofline"]["frac"] < 1 and c2["roofline"]["kernel"] == "k_derivatives" and c2["final_error_vs_ground_truth"]["m"] < 0.05
+    c5 = d["configs"]["C5"]
+    assert "error" not in c5
+    for leg in ("ndt_host_clouds", "ndt_device_keyframes", "svn_k20"):
+        assert c5[leg]["hz"] > 0 and c5[leg]["ms_per_frame"] > 0 and "final_error_vs_ground_truth" in c5[leg], leg
+    assert c5["ndt_host_clouds"]["max_error_m"] < 0.05 and c5["ndt_device_keyframes"]["max_error_m"] < 0.05
+    st = c5["svn_k20"]["stage1"]
+    assert st["poses_per_launch"] == 20 and st["ms_per_launch"] > 0 and 0 < st["frac"] < 1 and st["launches_timed"] >= 1
+    assert c5["svn_k20"]["mean_error_m"] < c5["svn_k20"]["mean_prior_error_m"]
     assert d["evaluations_reused_per_align"] >= 0 and d["config"]["rccl"]["version"] > 20000
     assert 0 <= d["evaluations_prelaunched_per_align"] < d["evaluations_per_align"] and d["prelaunch_timeouts"] == 0
     cb = d["cpu_baseline"]
@@ -58,10 +76,36 @@ def test_bench_gpus_2_from_a_plain_invocation():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     v = d["config"]["reduce_variants"]
-    assert set(v) == {"shm", "p2p", "rccl"} and v["rccl"] is None and d.get("reduce_failed") == "rccl"
+    # RCCL cannot work with two ranks on one device: reported as unavailable with the reason, not as a failure
+    assert set(v) == {"shm", "p2p", "rccl"} and "duplicate" in v["rccl"]["unavailable"] and "reduce_failed" not in d
     assert v["shm"]["value"] > 0 and v["p2p"]["value"] > 0 and v["shm"]["ranks"] == 2 and v["p2p"]["ranks"] == 2
-    assert d["config"]["reduce"] in ("shm", "p2p") and d["config"]["launch"] == "self-launched ranks"
+    # every rank runs the same host loop on the same sums, and shm / p2p add the same rows in the same order
+    assert v["shm"]["ranks_bit_identical"] and v["p2p"]["ranks_bit_identical"] and "suspect" not in v["shm"] and "suspect" not in v["p2p"]
+    assert v["shm"]["answer_digest"] == v["p2p"]["answer_digest"]
+    assert d["config"]["reduce"] in ("shm", "p2p") and d["config"]["launch"].startswith("self-launched ranks; rehearsal")
+    assert d["config"]["variant_wall_budget_s"] > 0
     assert d["config"]["sharding"] == "source/2" and d["final_error_vs_ground_truth"]["m"] < 0.05
+
+
+def test_bench_four_ranks_on_one_device_rehearsal():
+    """The shape that aborted in round 3 (gpurun_out/r03/bench_4on1.err: three ranks lost a partial row while four
+    processes time-sliced one device): four ranks on the box's one device, launch-per-phase build, run ONCE.  rc 0,
+    one line, every rank on the same pose bit for bit.  A lost row is no longer an error either (it is re-evaluated
+    through the ticketed sum) -- the line says how often that happened."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NDT_RANKS_BOARD")}
+    env.update(NDT_BENCH_PROBE="0", NDT_BENCH_SINGLE_DEVICE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    v = d["config"]["reduce_variants"]
+    assert d["n_gpus"] == 4 and d["config"]["sharding"] == "source/4" and d["final_error_vs_ground_truth"]["m"] < 0.05
+    for m in ("shm", "p2p"):
+        assert v[m]["ranks"] == 4 and v[m]["ranks_bit_identical"] and "suspect" not in v[m] and v[m]["lost_row_retries"] >= 0
+    assert v["shm"]["answer_digest"] == v["p2p"]["answer_digest"]
+    assert "hand-off lost" not in r.stderr
 
 
 def test_bench_forced_distributed_one_rank_runs_rccl():

@@ -309,6 +309,68 @@ print("again equal", bool(np.array_equal(T0, T2)))
     assert timeouts == 1
 
 
+def test_lost_row_is_re_evaluated_through_the_ticketed_sum(pkg, S):
+    """An ordinary launch whose summing block gives up waiting for a partial row (seam: one block withholds its row;
+    in the field: a device shared with other processes, gpurun_out/r03/bench_4on1.err) is not an error yet: the pose
+    is evaluated once more, stream-synchronised, with the final sum made by the block that draws the last ticket.
+    Same sums bit for bit (same rows, same order).  (Own process: the seam is read once from the environment.)"""
+    import subprocess, sys, os
+    code = r"""
+import sys, time, numpy as np
+sys.path.insert(0, %r)
+import __graft_entry__ as ge
+pkg = ge.load_package(); S = pkg.synth
+cfg = S.config_c2()
+kw = dict(resolution=1.0, step_size=0.1, trans_epsilon=1e-4, max_iterations=35)
+ndt = pkg.NormalDistributionsTransform(device_id=0, **kw)
+ndt.setInputTarget(cfg["target"]); ndt.setInputSource(cfg["source"])
+p = np.array([0.4, 0.05, 0.0, 0.0, 0.0, 0.03])
+e0 = ndt.evalDerivatives(p)[0]            # launch 0 (batched entry point: not the seam's)
+T0 = ndt.align(cfg["guess"])              # launch 1 = the align's first evaluation: its block 2 withholds its row
+r0 = ndt.getResult()
+print("retries", ndt.lostRowRetries(), "converged", ndt.hasConverged())
+T1 = ndt.align(cfg["guess"])
+r1 = ndt.getResult()
+print("equal", bool(np.array_equal(T0, T1)), r0["iterations"] == r1["iterations"], r0["score"] == r1["score"],
+      bool(np.array_equal(r0["hessian"], r1["hessian"])))
+print("retries after", ndt.lostRowRetries())
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NDT_DEBUG_MUTE_ROW_AT="1", NDT_HIP_LIB=SEAMS_LIB)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "retries 1 converged True" in p.stdout, p.stdout
+    assert "equal True True True True" in p.stdout and "retries after 1" in p.stdout, p.stdout
+
+
+def test_pose_that_lands_at_the_deadline_with_two_streams(pkg, S):
+    """The pose of a pre-launched kernel arrives right at its 20 ms deadline: some blocks have left, others compute
+    (every block times out on its own clock).  Whatever mixture results, the host drains both streams before the
+    re-launch reuses the rows: same transform as without pre-launching, and the next align is clean."""
+    import subprocess, sys, os
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import __graft_entry__ as ge
+pkg = ge.load_package(); S = pkg.synth
+cfg = S.config_c3()
+kw = dict(resolution=0.5, step_size=0.1, trans_epsilon=1e-4, max_iterations=35)
+ref = pkg.NormalDistributionsTransform(device_id=0, prelaunch=pkg.PRELAUNCH_OFF, **kw)
+ref.setInputTarget(cfg["target"]); ref.setInputSource(cfg["source"])
+T0 = ref.align(cfg["guess"])
+ndt = pkg.NormalDistributionsTransform(device_id=0, **kw)
+ndt.setInputTarget(cfg["target"]); ndt.setInputSource(cfg["source"])
+ok = True
+for k in range(4):
+    T = ndt.align(cfg["guess"])
+    ok = ok and bool(np.array_equal(T0, T))
+print("equal", ok, "counters", ndt.prelaunchCounters(), "overlapped", ndt.prelaunchOverlapped())
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NDT_DEBUG_PUBLISH_DELAY_MS="20", NDT_HIP_LIB=SEAMS_LIB)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "equal True" in p.stdout, p.stdout
+
+
 def test_batched_scoring_and_xy_covariance_estimators(pkg, O, S):
     """ndt_score_transforms: K poses in one launch == K single scoring launches, bit for bit.
     The 2-D covariance estimators of tier4 ndt_omp [RECALLED] on top of it: MULTI_NDT (re-align

@@ -113,6 +113,83 @@ def test_bench_gpus_2_is_runnable_as_the_driver_runs_it():
     assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]   # no line from a run that measured nothing
 
 
+def test_rank_device_choice_and_wall_budget():
+    """First contact with a multi-GPU node: one rank per device is the rule; a rank whose launcher
+    narrowed the visible devices to one uses device 0 and says so; LOCAL_RANK beyond the visible devices otherwise
+    is a launch error with one clear line.  Every reduce variant gets a share of the wall budget."""
+    R = _pkg().ranks
+    assert R.pick_device(5, 8, 8) == (5, None)
+    dev, note = R.pick_device(5, 8, 1)
+    assert dev == 0 and "ONE device" in note and "LOCAL_RANK 5" in note
+    dev, note = R.pick_device(3, 4, 1, rehearsal=True)
+    assert dev == 0 and "rehearsal" in note
+    with pytest.raises(SystemExit) as ei:
+        R.pick_device(5, 8, 4)
+    assert "LOCAL_RANK 5" in str(ei.value) and "4 device(s)" in str(ei.value)
+    with pytest.raises(SystemExit) as ei:
+        R.pick_device(0, 1, 0)
+    assert "no CPU fallback" in str(ei.value)
+    old = {k: os.environ.pop(k, None) for k in ("NDT_BENCH_WALL_BUDGET", "NDT_BENCH_VARIANT_TIMEOUT")}
+    try:
+        assert R.variant_budget(3) == pytest.approx(105.0)          # 420 s over three variants + one share
+        assert 3 * R.variant_budget(3) + 60 < 600                   # ... ends well inside the driver's 600 s
+        assert R.variant_budget(1, total=100.0) == pytest.approx(50.0)
+        os.environ["NDT_BENCH_VARIANT_TIMEOUT"] = "7"
+        assert R.variant_budget(3) == 7.0
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+
+
+def test_signalled_parent_takes_its_ranks_along(tmp_path):
+    """`timeout -k 10 400 python bench.py --gpus 2` signals only the parent: SIGTERM is passed on to the ranks (each in
+    a session of its own), the board file is unlinked; a parent that is KILLED takes them along too (PDEATHSIG)."""
+    import signal
+    child = tmp_path / "sleeper.py"
+    child.write_text("import os, sys, time\nopen(sys.argv[1] + '.' + os.environ['RANK'], 'w').write(str(os.getpid()))\ntime.sleep(120)\n")
+    parent_code = ("import sys; sys.path.insert(0, %r); import __graft_entry__ as ge; R = ge.load_package().ranks; "
+                   "sys.exit(R.launch(2, [sys.executable, %r, %r], timeout=100))")
+
+    def pids(prefix):
+        out = []
+        for r in range(2):
+            f = "%s.%d" % (prefix, r)
+            t0 = time.monotonic()
+            while not (os.path.exists(f) and open(f).read().strip()):
+                assert time.monotonic() - t0 < 60
+                time.sleep(0.02)
+            out.append(int(open(f).read()))
+        return out
+
+    def gone(pid):
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            return True
+        try:   # a zombie whose parent (this test's grandchild) is gone is reaped by init; treat 'Z' as gone
+            return open("/proc/%d/stat" % pid).read().split()[2] == "Z"
+        except OSError:
+            return True
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NDT_RANKS_BOARD")}
+    for how in (signal.SIGTERM, signal.SIGKILL):
+        prefix = str(tmp_path / ("pid%d" % how))
+        p = subprocess.Popen([sys.executable, "-c", parent_code % (ROOT, str(child), prefix)], env=env)
+        kids = pids(prefix)
+        boards = [f for f in os.listdir("/dev/shm") if f.startswith("ndt_board_%d_" % p.pid)]
+        os.kill(p.pid, how)
+        p.wait(timeout=60)
+        t0 = time.monotonic()
+        while not all(gone(k) for k in kids):
+            assert time.monotonic() - t0 < 30, "ranks survived their parent (%s)" % how
+            time.sleep(0.05)
+        if how == signal.SIGTERM:
+            assert p.returncode == 128 + signal.SIGTERM
+            assert not [f for f in boards if os.path.exists("/dev/shm/" + f)]
+
+
 def test_bench_imports_no_torch():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "import torch" not in src and "torch.cuda" not in src
