@@ -300,6 +300,24 @@ int ndt_set_target_from_keyframes(ndt_handle* h, const int64_t* ids, const doubl
  * serves both */
 int ndt_set_source_from_keyframe(ndt_handle* h, int64_t id);
 
+/* pcl::VoxelGrid downsample on the device (ref: run/pipeline_ins_map_distribution.cpp:324-340: the accumulated map
+ * is filtered at `mapvoxelsize` before the NDT export).  PCL's published algorithm: the grid of
+ * getMinMax3D over the finite points, voxel index floor(p * inv_leaf) - min_b, every field averaged (in float) over
+ * the points of an occupied voxel, output in ascending voxel index; non-finite points are dropped; a grid of more than
+ * INT32_MAX cells is refused (NDT_ERR_GRID_OVERFLOW).  Within a voxel the points are added in input order.
+ *  - _device: SoA float arrays in device memory in and out (intensity arrays may be NULL); at most `cap` points are
+ *    written, *n_out receives the number of occupied voxels (NDT_ERR_INVALID_ARG if it exceeds cap; cap = n always
+ *    suffices).  The output arrays can go straight into ndt_set_target_device: no host round trip.
+ *  - host form: a strided cloud in (stride_bytes apart; intensity at intensity_offset_bytes, < 0: none --
+ *    pcl::PointXYZI: stride 32, intensity at 16) and a cloud of the same layout out (only x, y, z and intensity are
+ *    written).
+ * The handle's target grid and source are left untouched. */
+int ndt_voxel_downsample_device(ndt_handle* h, const float* dx, const float* dy, const float* dz, const float* d_intensity,
+                                size_t n, float leaf, float* ox, float* oy, float* oz, float* o_intensity, size_t cap,
+                                size_t* n_out);
+int ndt_voxel_downsample(ndt_handle* h, const float* xyz, size_t n, size_t stride_bytes, long intensity_offset_bytes,
+                         float leaf, float* out, size_t cap, size_t* n_out);
+
 /* setRegularizationPose (ref: run/pipeline_ligo_tc.cpp:531) */
 int ndt_set_regularization_pose(ndt_handle* h, const float pose_colmajor[16]);
 int ndt_clear_regularization_pose(ndt_handle* h);

@@ -37,6 +37,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -374,6 +375,23 @@ class NormalDistributionsTransform
       for (int64_t i = 0; i < n; ++i) grid_.leaves_.emplace_back((size_t)buf[i].index, TargetGrid::Leaf{buf[i]});
     }
     return grid_;
+  }
+
+  // ---- pcl::VoxelGrid on the device (ref: run/pipeline_ins_map_distribution.cpp:324-340: vg.setLeafSize(vs, vs, vs);
+  // vg.setInputCloud(map); vg.filter(*ds_map)) ----
+  // `out` receives the centroid (x, y, z and, for point types with an `intensity` member at byte 16, the intensity) of
+  // every occupied voxel in ascending voxel index; the engine's target and source are left as they are
+  template <class Cloud>
+  void voxelDownsample(const Cloud& in, float leaf, Cloud& out) {
+    out.points.clear();
+    if (!h_) { status_ = NDT_ERR_NO_DEVICE; return; }
+    if (in.points.empty()) { status_ = NDT_OK; return; }
+    using P = typename std::decay<decltype(in.points[0])>::type;
+    out.points.resize(in.points.size());   // value-initialised points: the fields the engine does not write keep their defaults
+    size_t m = 0;
+    status_ = ndt_voxel_downsample(h_, &in.points[0].x, in.points.size(), sizeof(P), sizeof(P) >= 32 ? 16 : -1, leaf,
+                                   &out.points[0].x, out.points.size(), &m);
+    out.points.resize(status_ == NDT_OK ? m : 0);
   }
 
   // ---- device-resident keyframe archive (ref: run/pipeline_ligo_tc.cpp:519-529, run/pipeline.cpp:554-557,784) ----

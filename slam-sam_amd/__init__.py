@@ -149,6 +149,7 @@ ABI_SYMBOLS = [
     "ndt_xy_covariance_multi_ndt_score", "ndt_source_changed", "ndt_comm_rank_count", "ndt_comm_p2p_handle", "ndt_comm_init_p2p",
     "ndt_set_record_format", "ndt_get_record_format",
     "ndt_set_handoff_mode", "ndt_get_handoff_mode", "ndt_wait", "ndt_get_handoff_timing",
+    "ndt_voxel_downsample_device", "ndt_voxel_downsample",
 ]
 
 _lib = None
@@ -232,6 +233,10 @@ def lib():
         L.ndt_propose_poses_to_search.argtypes = [C.POINTER(Result), dp, dp, C.c_int, fp]
         L.ndt_xy_covariance_multi_ndt.argtypes = [vp, C.POINTER(Result), fp, C.c_int, dp, dp]
         L.ndt_xy_covariance_multi_ndt_score.argtypes = [vp, C.POINTER(Result), fp, C.c_int, C.c_double, dp, dp]
+        L.ndt_voxel_downsample_device.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, C.c_float, vp, vp, vp, vp, C.c_size_t,
+                                                  C.POINTER(C.c_size_t)]
+        L.ndt_voxel_downsample.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_long, C.c_float, vp, C.c_size_t,
+                                           C.POINTER(C.c_size_t)]
         L.ndt_set_handoff_mode.argtypes = [vp, C.c_int]
         L.ndt_get_handoff_mode.argtypes = [vp]
         L.ndt_wait.argtypes = [vp]
@@ -490,6 +495,30 @@ class NormalDistributionsTransform:
         ids_a = (C.c_int64 * len(ids))(*[int(i) for i in ids])
         p = np.ascontiguousarray(np.stack([np.asarray(T, dtype=np.float64).T for T in poses])).ravel()
         self._check(lib().ndt_set_target_from_keyframes(self._h, ids_a, _dp(p), len(ids)))
+
+    # --- pcl::VoxelGrid downsample (ref: run/pipeline_ins_map_distribution.cpp:324-340) ---
+    def voxelDownsampleDevice(self, dx, dy, dz, n, leaf, ox, oy, oz, cap, d_intensity=None, o_intensity=None):
+        """SoA device arrays in, centroids of the occupied voxels (ascending voxel index) out; returns their number.
+        The output arrays can be handed to setInputTargetDevice as they are."""
+        m = C.c_size_t(0)
+        self._check(lib().ndt_voxel_downsample_device(self._h, dx, dy, dz, d_intensity, int(n), float(leaf), ox, oy, oz,
+                                                      o_intensity, int(cap), C.byref(m)))
+        return int(m.value)
+
+    def voxelDownsample(self, cloud, leaf, intensity_column=None):
+        """Host cloud (N x >= 3 float32; intensity_column: index of the intensity field, 4 for pcl::PointXYZI's
+        8-float layout) -> the filtered cloud in the same layout (other columns zero)."""
+        a = np.ascontiguousarray(cloud, dtype=np.float32)
+        if a.ndim != 2 or a.shape[1] < 3:
+            raise ValueError("cloud must be N x >=3 float32")
+        out = np.zeros_like(a)
+        if len(a) == 0:
+            return out
+        m = C.c_size_t(0)
+        off = -1 if intensity_column is None else 4 * int(intensity_column)
+        self._check(lib().ndt_voxel_downsample(self._h, a.ctypes.data, len(a), a.strides[0], off, float(leaf),
+                                               out.ctypes.data, len(out), C.byref(m)))
+        return out[:m.value]
 
     def setGlobalSourceSize(self, n):
         self._check(lib().ndt_set_global_source_size(self._h, int(n)))

@@ -763,6 +763,10 @@ int settle(ndt_handle* h) {
   return rs;
 }
 
+// for calls that borrow the build's scratch but leave the target alone: the pending build is completed and, if it
+// failed, its verdict kept for the first call that needs the grid
+void settle_discard_keep_grid(ndt_handle* h) { (void)settle_build(h); }
+
 // for calls that replace the target: the pending build is completed (its scratch and the engine's own copy of
 // the cloud are about to be reused) and its verdict dropped
 void settle_discard(ndt_handle* h) {
@@ -1739,6 +1743,115 @@ int ndt_set_target_from_keyframes(ndt_handle* h, const int64_t* ids, const doubl
   HIP_TRY(h, hipGetLastError());
   // (the assembled cloud is the engine's own: the build may stay in flight like a host hand-off's)
   return build_grid(h, h->tx.p, h->ty.p, h->tz.p, total, h->handoff_mode == NDT_HANDOFF_ASYNC);
+}
+
+// pcl::VoxelGrid on the device (ref: run/pipeline_ins_map_distribution.cpp:324-340, leaf = mapvoxelsize): bounds ->
+// keys -> stable radix sort -> runs -> centroids with the build's own launch-per-phase kernels (min_pts = 1, no
+// statistics).  Uses the build's scratch; the handle's target grid and its source are left as they are.
+static int voxel_downsample_device_impl(ndt_handle* h, const float* dx, const float* dy, const float* dz, const float* di,
+                                        size_t n, float leaf, float* ox, float* oy, float* oz, float* oi, size_t cap,
+                                        size_t* n_out) {
+  *n_out = 0;
+  if (n == 0) return NDT_OK;
+  if (n > (size_t)std::numeric_limits<int>::max() / 2) return fail(h, NDT_ERR_INVALID_ARG, "cloud too large");
+  settle_discard_keep_grid(h);
+  hipStream_t s = h->stream;
+  HIP_TRY(h, h->brows.ensure(8 * (size_t)std::max(bounds_rows(n), bucket_build_tiles(n))));
+  HIP_TRY(h, h->gd.ensure(1));
+  HIP_TRY(h, h->gdh.ensure(1));
+  if (!h->tickets.p) {
+    HIP_TRY(h, h->tickets.ensure(6));
+    HIP_TRY(h, hipMemsetAsync(h->tickets.p, 0, h->tickets.cap * sizeof(unsigned int), s));
+  }
+  HIP_TRY(h, h->nleaf.ensure(4));
+  HIP_TRY(h, h->keys.ensure(n));
+  HIP_TRY(h, h->xyz4.ensure(4 * n));
+  HIP_TRY(h, h->vals.ensure(n));
+  HIP_TRY(h, h->keys2.ensure(n));
+  HIP_TRY(h, h->vals2.ensure(n));
+  HIP_TRY(h, h->leaf_start.ensure(n + 1));
+  HIP_TRY(h, h->leaf_cnt.ensure(n + 1));
+  HIP_TRY(h, h->run_counts.ensure((size_t)runs_blocks(n)));
+  HIP_TRY(h, h->run_offsets.ensure((size_t)runs_blocks(n)));
+  HIP_TRY(h, h->sort_tmp.ensure(sort_temp_bytes(n)));
+  HIP_TRY(h, h->small.ensure(16));
+  h->gdh.h->status = -1;
+  // the geometry is awaited (its pass count sizes the sort): a full, launch-per-phase pipeline that never waits
+  // inside a kernel; no cell of the handle's index grid is touched (old_stats = null, no dirty slots)
+  launch_bounds_geometry(dx, dy, dz, n, leaf, 1.0f / leaf, (long long)std::numeric_limits<int32_t>::max(), 0, h->brows.p,
+                         h->tickets.p, h->gd.p, h->gdh.d, nullptr, 0, nullptr, 0, h->nleaf.p, s);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipStreamSynchronize(s));
+  const BuildGeom bg = *h->gdh.h;
+  if (bg.status == BG_NO_FINITE) return NDT_OK;   // nothing finite: an empty output, as PCL's filter leaves it
+  if (bg.status != BG_OK)
+    return fail(h, NDT_ERR_GRID_OVERFLOW, "leaf size too small for the cloud's extent (index overflow; PCL's VoxelGrid refuses the same cloud)");
+  launch_cell_keys(dx, dy, dz, n, h->gd.p, h->keys.p, h->xyz4.p, h->sort_tmp.p, s);
+  bool in_b = false;
+  HIP_TRY(h, sort_pairs(h->sort_tmp.p, h->keys.p, h->keys2.p, h->vals.p, h->vals2.p, n, bg.passes, h->gd.p, s, &in_b));
+  const uint32_t* keys_sorted = in_b ? h->keys2.p : h->keys.p;
+  const uint32_t* vals_sorted = in_b ? h->vals2.p : h->vals.p;
+  HIP_TRY(h, launch_find_runs(keys_sorted, n, h->gd.p, h->gdh.d, /*min_pts=*/1, h->nleaf.p, h->run_counts.p, h->run_offsets.p,
+                              h->tickets.p + 1, nullptr, 0, &h->run_seq, h->leaf_start.p, h->leaf_cnt.p, s));
+  launch_voxel_centroids(h->xyz4.p, di, vals_sorted, h->nleaf.p, h->leaf_start.p, h->leaf_cnt.p, n, cap, ox, oy, oz, oi, s);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(h->small.h + 12, h->nleaf.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipStreamSynchronize(s));
+  *n_out = (size_t)h->small.h[12];
+  if (*n_out > cap) return fail(h, NDT_ERR_INVALID_ARG, "output capacity too small: " + std::to_string(*n_out) + " occupied voxels");
+  return NDT_OK;
+}
+
+int ndt_voxel_downsample_device(ndt_handle* h, const float* dx, const float* dy, const float* dz, const float* d_intensity,
+                                size_t n, float leaf, float* ox, float* oy, float* oz, float* o_intensity, size_t cap,
+                                size_t* n_out) {
+  if (!h || !n_out || ((!dx || !dy || !dz) && n) || ((!ox || !oy || !oz) && cap) || !(leaf > 1e-6f)) return NDT_ERR_INVALID_ARG;
+  int rc = bind_device(h);
+  if (rc) return rc;
+  return voxel_downsample_device_impl(h, dx, dy, dz, d_intensity, n, leaf, ox, oy, oz, o_intensity, cap, n_out);
+}
+
+int ndt_voxel_downsample(ndt_handle* h, const float* xyz, size_t n, size_t stride_bytes, long intensity_offset_bytes,
+                         float leaf, float* out, size_t cap, size_t* n_out) {
+  if (!h || !n_out || (!xyz && n) || (!out && cap) || stride_bytes < 12 || stride_bytes % 4 || !(leaf > 1e-6f) ||
+      (intensity_offset_bytes >= 0 && (intensity_offset_bytes % 4 || (size_t)intensity_offset_bytes + 4 > stride_bytes ||
+                                       intensity_offset_bytes < 12)))
+    return NDT_ERR_INVALID_ARG;
+  int rc = bind_device(h);
+  if (rc) return rc;
+  *n_out = 0;
+  if (n == 0) return NDT_OK;
+  const bool has_i = intensity_offset_bytes >= 0;
+  DevBuf<float> x, y, z, in_i, o;   // scratch of this call (a shutdown-time operation in the reference)
+  auto done = [&](int code) { x.release(); y.release(); z.release(); in_i.release(); o.release(); return code; };
+  rc = upload_soa(h, h->lane_t, h->stream, xyz, nullptr, nullptr, nullptr, n, stride_bytes, x, y, z, true);
+  if (rc) return done(rc);
+  std::vector<float> tmp;
+  if (has_i) {
+    tmp.resize(n);
+    const char* base = reinterpret_cast<const char*>(xyz) + intensity_offset_bytes;
+    for (size_t i = 0; i < n; ++i) tmp[i] = *reinterpret_cast<const float*>(base + i * stride_bytes);
+    hipError_t e = in_i.ensure(n);
+    if (e == hipSuccess) e = hipMemcpy(in_i.p, tmp.data(), n * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return done(fail(h, NDT_ERR_HIP, hipGetErrorString(e)));
+  }
+  const size_t ocap = std::min(cap, n);
+  hipError_t e = o.ensure(4 * std::max<size_t>(ocap, 1));
+  if (e != hipSuccess) return done(fail(h, e == hipErrorOutOfMemory ? NDT_ERR_ALLOC : NDT_ERR_HIP, hipGetErrorString(e)));
+  float* ox = o.p, *oy = o.p + ocap, *oz = o.p + 2 * ocap, *oi = o.p + 3 * ocap;
+  rc = voxel_downsample_device_impl(h, x.p, y.p, z.p, has_i ? in_i.p : nullptr, n, leaf, ox, oy, oz, has_i ? oi : nullptr, ocap, n_out);
+  if (rc) return done(rc);
+  const size_t m = *n_out;
+  std::vector<float> back(4 * ocap);
+  e = hipMemcpy(back.data(), o.p, (has_i ? 4 : 3) * ocap * sizeof(float), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return done(fail(h, NDT_ERR_HIP, hipGetErrorString(e)));
+  char* ob = reinterpret_cast<char*>(out);
+  for (size_t i = 0; i < m; ++i) {
+    float* p = reinterpret_cast<float*>(ob + i * stride_bytes);
+    p[0] = back[i]; p[1] = back[ocap + i]; p[2] = back[2 * ocap + i];
+    if (has_i) *reinterpret_cast<float*>(ob + i * stride_bytes + intensity_offset_bytes) = back[3 * ocap + i];
+  }
+  return done(NDT_OK);
 }
 
 int ndt_set_global_source_size(ndt_handle* h, int64_t n_total) {

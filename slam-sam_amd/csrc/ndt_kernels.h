@@ -85,6 +85,11 @@ hipError_t launch_find_runs(const uint32_t* keys_sorted, size_t n, BuildGeom* gd
 // tmp: the cloud chunk by chunk as [x | y | z] of `chunk` points (the last chunk shorter) -> SoA arrays
 // host hand-off: one chunk [x(seg) | y(seg) | z(seg)] in mapped pinned host memory -> the SoA arrays (pulled over PCIe)
 void launch_pull_chunk(const float* stage_dev, size_t len, size_t seg, float* x, float* y, float* z, hipStream_t s);
+// pcl::VoxelGrid centroids of the runs found by launch_find_runs(min_pts = 1): output point r = float mean of run r's
+// points (and of `intensity`, may be null; oi may be null), ascending voxel index; at most `cap` points are written
+void launch_voxel_centroids(const float* xyz4, const float* intensity, const uint32_t* vals_sorted, const int* d_nleaf,
+                            const int* leaf_start, const int* leaf_cnt, size_t max_runs, size_t cap, float* ox, float* oy,
+                            float* oz, float* oi, hipStream_t s);
 // multi-grid union table: cell2leaf[cells[i]] = slots[i], i < n (device arrays)
 void launch_scatter_heads(const int* cells, const int* slots, size_t n, int* cell2leaf, hipStream_t s);
 int finalize_blocks(int max_leaves);

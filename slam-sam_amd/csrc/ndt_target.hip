@@ -2253,6 +2253,31 @@ __global__ void __launch_bounds__(256) k_pull_chunk(const float* __restrict__ sr
   }
 }
 
+// pcl::VoxelGrid centroids (ref: run/pipeline_ins_map_distribution.cpp:324-340; PCL's published algorithm: every field
+// averaged over the points of an occupied voxel, output in ascending voxel index): run r of the sorted keys =
+// points vals_sorted[start .. start + cnt) -> one output point.  float sums in sorted order (the radix sort is stable:
+// input order within a voxel) and a float division, as PCL's CentroidPoint accumulates -- PCL's own order within a voxel
+// is whatever its unstable index sort left, so agreement with it is to rounding, with a stable-sort restatement exact.
+__global__ void __launch_bounds__(256) k_voxel_centroids(const float4* __restrict__ xyz4, const float* __restrict__ inten,
+                                                        const uint32_t* __restrict__ vals_sorted, const int* __restrict__ d_nleaf,
+                                                        const int* __restrict__ leaf_start, const int* __restrict__ leaf_cnt,
+                                                        int cap, float* __restrict__ ox, float* __restrict__ oy,
+                                                        float* __restrict__ oz, float* __restrict__ oi) {
+  const int r = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (r >= d_nleaf[0] || r >= cap) return;
+  const int start = leaf_start[r], cnt = leaf_cnt[r];
+  float sx = 0.0f, sy = 0.0f, sz = 0.0f, si = 0.0f;
+  for (int j = 0; j < cnt; ++j) {
+    const uint32_t p = vals_sorted[start + j];
+    const float4 q = xyz4[p];
+    sx += q.x; sy += q.y; sz += q.z;
+    if (inten) si += inten[p];
+  }
+  const float nf = (float)cnt;
+  ox[r] = sx / nf; oy[r] = sy / nf; oz[r] = sz / nf;
+  if (oi) oi[r] = inten ? si / nf : 0.0f;
+}
+
 // multi-grid union table: cell2leaf[cells[i]] = slots[i] for the first leaf of every occupied cell
 __global__ void __launch_bounds__(256) k_scatter_heads(const int* __restrict__ cells, const int* __restrict__ slots,
                                                       int n, int* __restrict__ cell2leaf) {
@@ -2577,6 +2602,15 @@ void launch_pull_chunk(const float* stage_dev, size_t len, size_t seg, float* x,
   if (len == 0) return;
   const unsigned blocks = (unsigned)std::min<size_t>(64, (len / 4 + 255) / 256 + 1);
   hipLaunchKernelGGL(k_pull_chunk, dim3(blocks), dim3(256), 0, s, stage_dev, len, seg, x, y, z);
+}
+
+void launch_voxel_centroids(const float* xyz4, const float* intensity, const uint32_t* vals_sorted, const int* d_nleaf,
+                            const int* leaf_start, const int* leaf_cnt, size_t max_runs, size_t cap, float* ox, float* oy,
+                            float* oz, float* oi, hipStream_t s) {
+  const size_t m = std::min(max_runs, cap);
+  if (m == 0) return;
+  hipLaunchKernelGGL(k_voxel_centroids, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float4*>(xyz4),
+                     intensity, vals_sorted, d_nleaf, leaf_start, leaf_cnt, (int)std::min<size_t>(cap, 0x7fffffff), ox, oy, oz, oi);
 }
 
 void launch_scatter_heads(const int* cells, const int* slots, size_t n, int* cell2leaf, hipStream_t s) {

@@ -152,6 +152,19 @@ int main() {
     ok = ok && st0 == NDT_OK && std::sqrt(e4) < 0.05 && union_leaves > cells.getLeaves().size() &&
          mg.getCurrentMapIDs().size() == 1 && st1 == NDT_ERR_NO_TARGET;
   }
+  {  // pcl::VoxelGrid on the device (ref: run/pipeline_ins_map_distribution.cpp:324-340), handshake + wait() of the hand-off
+    ndt_hip::NormalDistributionsTransform<PointT, PointT> vg;
+    Cloud ds;
+    vg.voxelDownsample(*tgt, 0.5f, ds);
+    bool inside = !ds.points.empty() && ds.points.size() < tgt->points.size();
+    for (size_t i = 0; i < ds.points.size() && inside; ++i) inside = std::isfinite(ds.points[i].x) && std::isfinite(ds.points[i].z);
+    vg.setResolution(1.0f);
+    vg.setInputTarget(tgt);
+    vg.setInputTarget(tgt);            // steady state: asynchronous
+    const int w = vg.wait();
+    std::printf("voxelDownsample: %zu -> %zu points, status %d; wait() = %d\n", tgt->points.size(), ds.points.size(), vg.lastStatus(), w);
+    ok = ok && inside && w == NDT_OK;
+  }
   // svn_ndt-shaped adapter: K = 8 particles, Gauss-Newton Hessian, one launch per iteration
   ndt_hip::SvnNormalDistributionsTransform<PointT, PointT> svn;
   svn.setResolution(1.0f);
