@@ -491,7 +491,7 @@ def test_prelaunched_evaluations_survive_a_starved_host():
     BLAS pool busy under the box's CPU quota): waiting kernels give up, their notices must not replace
     the unread result of their predecessor (they did, with one shared result buffer: the host then
     waited 5 s for tags that were gone and reported NDT_ERR_HIP).  Every align returns the reference
-    result; give-ups are counted and handled.  tests/gpu_mbox_stress.py, own process."""
+    result; give-ups are counted and handled.  tools/mbox_stress.py, own process."""
     import subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_mbox_stress.py"), "2500"],

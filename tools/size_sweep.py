@@ -1,5 +1,5 @@
 """Derivative-kernel time vs source size on the C3 map and on the C3-wide map (tuning aid, not
-collected by pytest).  `python tests/gpu_size_sweep.py [c3|wide|both]`."""
+collected by pytest).  `python tools/size_sweep.py [c3|wide|both]`."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,6 +1,6 @@
 """A/B numbers on the C3 workload (tuning aid, not collected by pytest): device-resident step (build + set
 source + align) as bench.py times it, build time, per-evaluation wall time and HIP-event kernel time.
-Usage: python tests/gpu_step_ab.py <tag>; knobs come from the environment (NDT_PRELAUNCH_STREAMS,
+Usage: python tools/step_ab.py <tag>; knobs come from the environment (NDT_PRELAUNCH_STREAMS,
 NDT_DERIV_BLOCK, NDT_BUCKET_BUILD, ...)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

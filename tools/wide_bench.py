@@ -1,5 +1,5 @@
 """C3 vs C3-wide: the device-resident step and the derivative kernel, for PMC / rocprof passes
-(tuning aid, not collected by pytest).  `python tests/gpu_wide_bench.py [c3|wide] [shuffle]`;
+(tuning aid, not collected by pytest).  `python tools/wide_bench.py [c3|wide] [shuffle]`;
 `shuffle` permutes the source (no scan coherence at all)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
