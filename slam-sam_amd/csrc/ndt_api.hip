@@ -796,6 +796,7 @@ EvalConsts make_eval_consts(const ndt_handle* h, bool need_h) {
   ec.multigrid = h->multi_active ? 1 : 0;
   ec.mbox_tagged = h->mbox_tagged ? 1 : 0;
   ec.mbox_preload = h->mbox_preload ? 1 : 0;
+  ec.compute_units = h->n_cus;   // block shapes and the XCD count are those of THIS handle's device (CPX partitions: 32)
   return ec;
 }
 
@@ -987,7 +988,7 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
   {
     int rc = records_for_eval(h, &ec, &records);
     if (rc) return rc;
-    rc = ensure_partials(h, derivs_partials_words(h->n_src, 1));
+    rc = ensure_partials(h, derivs_partials_words(h->n_src, 1, h->n_cus));
     if (rc) return rc;
   }
   HIP_TRY(h, h->result.ensure(EV_WORDS));
@@ -1289,7 +1290,6 @@ int ndt_create(const ndt_params* p, ndt_handle** out) {
   {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) h->n_cus = cus;
-    if (h->n_cus > 0) derivs_set_compute_units(h->n_cus);  // one block per CU is sized for THIS device (CPX partitions: 32)
   }
   {  // A/B knobs of the pose hand-over to pre-launched kernels (profiles/r02_mailbox_ab.txt)
     const char* t = getenv("NDT_MBOX_TAGGED");
@@ -1976,7 +1976,7 @@ static int eval_batch(ndt_handle* h, const double* poses6, const float* transfor
   const VoxelRecord* records = nullptr;
   rc = records_for_eval(h, &ec, &records);
   if (rc) return rc;
-  rc = ensure_partials(h, derivs_partials_words(h->n_src, K));
+  rc = ensure_partials(h, derivs_partials_words(h->n_src, K, h->n_cus));
   if (rc) return rc;
   HIP_TRY(h, h->result.ensure((size_t)K * EV_WORDS));
   HIP_TRY(h, h->dres.ensure((size_t)K * EV_WORDS));

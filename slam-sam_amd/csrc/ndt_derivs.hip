@@ -930,17 +930,6 @@ constexpr unsigned int KERNARG_TABLES_OFFSET = offsetof(DerivKernArgs, pose) + o
 static_assert(offsetof(PoseConsts, hang) == offsetof(PoseConsts, jang) + 24 * sizeof(float) &&
               offsetof(AngleTables, hang) == 24 * sizeof(float), "jang / hang must be contiguous");
 
-// Which chunk of the source a block works on.  The hardware hands workgroup g to XCD g mod 8, and every XCD has its
-// own 4 MB L2 that is cold at the start of a launch: with chunk = g each L2 sees every eighth stretch of the scan,
-// i.e. the whole map, and fetches the whole record table and index grid once per XCD.  With the blocks of one XCD on
-// CONSECUTIVE chunks an L2 serves one eighth of the scan's extent.  A bijection of [0, G) for any G; block 0 keeps
-// chunk 0 (the dedicated summing block); rows are numbered by chunk, so the final sum -- fixed order over the rows --
-// does not change by a bit.
-__device__ __forceinline__ int xcd_chunk(int g, int G) {
-  const int x = g & 7, j = g >> 3, q = G >> 3, r = G & 7;
-  return x * q + min(x, r) + j;
-}
-
 // NB: neighbourhood -- 0 DIRECT1, 1 DIRECT7, 2 KDTREE, 3 DIRECT26, 4 multi-grid union; 5 / 6: DIRECT1 / DIRECT7 on the
 // 48-byte packed record table (the 27-cell neighbourhoods always read the 80-byte records)
 // MBOX (single-pose only): a pre-launched evaluation -- the pose is not in the kernel arguments
@@ -975,7 +964,13 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
   // per-point expansion to the block reduction, not across the pair loop
   // (with a dedicated summing block the points start at block 1; block 0's threads own none)
   const bool summing_block = ec.dedicated_summer != 0 && blockIdx.x == 0;
-  const int chunk = (!BATCH && ec.xcd_chunks ? xcd_chunk((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x) - ec.dedicated_summer;
+  // (position among the row's point blocks; the XCD of position 0 follows from the block's LINEAR workgroup id;
+  // xcd_chunk: ndt_device.h)
+  const int pos = (int)blockIdx.x - ec.dedicated_summer, npos = (int)gridDim.x - ec.dedicated_summer;
+  const int chunk = (ec.xcd_count > 1 && !summing_block)
+                        ? xcd_chunk(pos, npos, (int)(((unsigned int)blockIdx.y * gridDim.x + (unsigned int)ec.dedicated_summer) % (unsigned int)ec.xcd_count),
+                                    ec.xcd_count, ec.xcd_stripe)
+                        : pos;
   const int i = summing_block ? n : chunk * (int)blockDim.x + threadIdx.x;
   float x = 0.0f, y = 0.0f, z = 0.0f;
   if (MBOX) {
@@ -1148,8 +1143,8 @@ __global__ void __launch_bounds__(256) k_transform(const float* __restrict__ sx,
 
 }  // namespace
 
-size_t derivs_partials_words(size_t n_src, int K) {
-  return (size_t)K * ((size_t)derivs_grid_blocks(n_src, K) + NGROUPS) * ROW_WORDS;
+size_t derivs_partials_words(size_t n_src, int K, int cus) {
+  return (size_t)K * ((size_t)derivs_grid_blocks(n_src, K, cus) + NGROUPS) * ROW_WORDS;
 }
 int derivs_counters_per_pose() { return COUNTERS_PER_POSE; }
 
@@ -1176,9 +1171,9 @@ int derivs_read_stamps(unsigned long long* out, int nblocks) {
 // which keeps every CU at <= 4 waves/SIMD and leaves <= 256 rows for the final sum
 // (profiles/r02_block_sweep.txt: 16.6 us at 832, 17.2 at 1024, 20.3 at 512).
 // NDT_DERIV_BLOCK overrides it for tuning.
-// compute units of the device the engine runs on (ndt_create sets it; all devices of a node are alike)
-static int g_compute_units = 256;
-void derivs_set_compute_units(int n) { if (n > 0) g_compute_units = n; }
+// (the compute units of the handle's device come in as `cus`: two engines on differently partitioned devices in one
+// process must not share a block shape)
+static inline int cus_or_default(int cus) { return cus > 0 ? cus : 256; }
 
 namespace {
 int deriv_single_level_max() {
@@ -1202,7 +1197,8 @@ bool deriv_dedicated_enabled() {
 }
 }  // namespace
 
-int derivs_block_threads(size_t n_src, int K) {
+int derivs_block_threads(size_t n_src, int K, int cus) {
+  const int g_compute_units = cus_or_default(cus);
   static const int forced = [] {
     const char* e = getenv("NDT_DERIV_BLOCK");  // multiple of 64, 64..1024
     int v = e ? atoi(e) : 0;
@@ -1231,19 +1227,19 @@ int derivs_block_threads(size_t n_src, int K) {
 }
 
 // blocks that own points
-static int derivs_point_blocks(size_t n_src, int K) {
-  const size_t bt = (size_t)derivs_block_threads(n_src, K);
+static int derivs_point_blocks(size_t n_src, int K, int cus) {
+  const size_t bt = (size_t)derivs_block_threads(n_src, K, cus);
   size_t blocks = (n_src + bt - 1) / bt;  // one point per thread
   if (blocks < 1) blocks = 1;
   return (int)blocks;
 }
 
 // 1: block 0 of the grid owns no points and adds the rows (single-level grids with the fixed summer)
-static int derivs_dedicated_summer(size_t n_src, int K) {
-  return deriv_dedicated_enabled() && deriv_fixed_summer() != 0 && derivs_point_blocks(n_src, K) <= deriv_single_level_max() ? 1 : 0;
+static int derivs_dedicated_summer(size_t n_src, int K, int cus) {
+  return deriv_dedicated_enabled() && deriv_fixed_summer() != 0 && derivs_point_blocks(n_src, K, cus) <= deriv_single_level_max() ? 1 : 0;
 }
 
-int derivs_grid_blocks(size_t n_src, int K) { return derivs_point_blocks(n_src, K) + derivs_dedicated_summer(n_src, K); }
+int derivs_grid_blocks(size_t n_src, int K, int cus) { return derivs_point_blocks(n_src, K, cus) + derivs_dedicated_summer(n_src, K, cus); }
 
 void launch_derivatives(const float* sx, const float* sy, const float* sz, size_t n_src,
                         const GridGeom& g, const int* cell2leaf, const VoxelRecord* rec, const float* cent4,
@@ -1253,25 +1249,43 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
                         unsigned long long seq, const PoseMailbox* d_mbox, const XchgInfo* d_xinfo,
                         unsigned long long xround, unsigned int* d_arrive_ctr, unsigned long long* d_arrived_host,
                         hipEvent_t ev_start, hipEvent_t ev_stop) {
-  int blocks = derivs_grid_blocks(n_src, d_poses ? K : 1);
-  const int threads = derivs_block_threads(n_src, d_poses ? K : 1);
+  const int cus = cus_or_default(ec.compute_units);
+  int blocks = derivs_grid_blocks(n_src, d_poses ? K : 1, cus);
+  const int threads = derivs_block_threads(n_src, d_poses ? K : 1, cus);
   const int mode = ec.score_only ? 3 : (!ec.need_hessian ? 0 : (ec.gauss_newton ? 2 : 1));
   EvalConsts ecl = ec;
   ecl.single_level_max = deriv_single_level_max();
   ecl.fixed_summer = deriv_fixed_summer();
-  ecl.dedicated_summer = derivs_dedicated_summer(n_src, d_poses ? K : 1);
+  ecl.dedicated_summer = derivs_dedicated_summer(n_src, d_poses ? K : 1, cus);
   if (ec.safe_sum) {
     // Same rows in the same order, added by the block that draws the last ticket: by then every row has been issued,
     // so nothing in the launch waits for a block that is not resident (a device shared with other processes).
     ecl.fixed_summer = 0;
     ecl.dedicated_summer = 0;
-    blocks = derivs_point_blocks(n_src, d_poses ? K : 1);
+    blocks = derivs_point_blocks(n_src, d_poses ? K : 1, cus);
   }
-  static const bool xcd_on = [] { const char* e = getenv("NDT_DERIV_XCD"); return !(e && atoi(e) == 0); }();  // A/B knob
-  // Only while the whole grid is resident at once (at most one block per compute unit): on larger grids an XCD that
-  // drew an expensive eighth of the source finishes late, round after round (C3, 400 k / 800 k points: 26.9 / 44.6 us
-  // against 23.7 / 37.6 with chunk = block id; profiles/r03_xcd_chunks.txt)
-  ecl.xcd_chunks = (!d_poses && xcd_on && blocks >= 16 && blocks <= g_compute_units + 1) ? 1 : 0;
+  // XCD-aware chunk assignment (xcd_chunk, ndt_device.h).  gfx950 has 32 compute units per XCD: 8 XCDs on a whole MI355X,
+  // one in a CPX partition (nothing to do there).  Grids that are resident at once (at most one block per compute unit)
+  // take the whole row as one stripe.  NDT_DERIV_XCD: 0 = off, 1 = resident single-pose grids only (default), 2 = also
+  // larger grids and batched launches, in stripes of one residency round (blocks per CU from the block size: 16 waves
+  // per CU).  Measured in round 4 (profiles/r04_xcd_stripes_ab.txt): the stripes LOSE -- C3 400 k / 800 k points 25.8 /
+  // 40.7 us against 24.1 / 39.1 with chunk = block id, C3-wide 30.0 / 48.9 against 28.1 / 46.1, the SVN Stage-1 launch
+  // (20 poses x 131 k points) 87.7 against 83.3 -- so they stay a knob.
+  static const int xcd_mode = [] { const char* e = getenv("NDT_DERIV_XCD"); return e ? atoi(e) : 1; }();  // A/B knob
+  const int nxcd = std::max(1, cus / 32);
+  const int point_blocks = blocks - ecl.dedicated_summer;
+  const int per_cu = std::max(1, 1024 / threads);
+  const bool resident = blocks <= cus * per_cu + 1 && !d_poses;
+  ecl.xcd_count = 0;
+  ecl.xcd_stripe = 0;
+  if (nxcd > 1 && point_blocks >= 2 * nxcd && xcd_mode != 0) {
+    if (!d_poses && blocks <= cus + 1) {
+      ecl.xcd_count = nxcd;                 // the whole grid at once: one stripe (round 3's case)
+    } else if (xcd_mode >= 2) {
+      ecl.xcd_count = nxcd;
+      ecl.xcd_stripe = resident ? 0 : std::max(1, (cus / nxcd) * per_cu);
+    }
+  }
   // DIRECT7 / DIRECT1 only: the union's leaves are chained through VoxelRecord::pad, and in the 27-cell neighbourhoods
   // the format (as a run-time flag) cost more than the shorter fetch gave back (KDTREE 21.9 -> 22.5 us, DIRECT26 29.1 -> 29.7)
   if (ec.multigrid || ec.kdtree || ec.direct26) ecl.packed = 0;

@@ -126,11 +126,43 @@ struct EvalConsts {
   int mbox_preload; // pre-launched kernels: 1 = the point is fetched before the wait for the pose
   int multigrid;   // 1: the table is a union of grids (radius search, leaves of a cell chained through VoxelRecord::pad)
   int packed;      // 1: the kernel's `rec` argument points at PackedRecord[] (48 bytes per leaf) instead of VoxelRecord[]
-  int xcd_chunks;  // 1: the blocks an XCD receives (workgroup id mod 8) take CONSECUTIVE chunks of the source (single-pose launches)
+  int xcd_count;   // > 1: the blocks an XCD receives (linear workgroup id mod xcd_count) take CONSECUTIVE chunks of the source
+  int xcd_stripe;  // ... per stripe of xcd_count * xcd_stripe blocks (0: the whole row is one stripe); see xcd_chunk()
+  int compute_units;  // host side only: compute units of the handle's device (block shapes, XCD count)
   int safe_sum;    // 1: the final sum is made by the block that draws the LAST TICKET (no block waits for rows of blocks that
                    // may not be resident): the re-evaluation after a lost row
   int mute_row;    // test seam (libndt_hip_seams.so only): row + 1 of the block that withholds its partial row; 0 = none
 };
+
+// Which chunk of the source a block works on.  The hardware hands workgroup w (linear id over the whole grid) to XCD
+// w mod X, and every XCD has its own 4 MB L2 that is cold at the start of a launch: with chunk = block id each L2 sees
+// every X-th stretch of the scan, i.e. the whole map, and fetches the whole record table and index grid once per XCD.
+// With the blocks of one XCD on CONSECUTIVE chunks an L2 serves one X-th of a stretch of the scan.
+//   p    position of the block among the L blocks that share the work (point blocks of one pose's row)
+//   off  XCD of position 0 (a row of a batched launch starts wherever the previous row ended; a dedicated summing
+//        block in front shifts everything by one)
+//   m    chunks per XCD and STRIPE, 0 = the whole row is one stripe.  A grid of several residency rounds is cut into
+//        stripes of X * m positions (one round each): within a stripe XCD x takes m consecutive chunks, so every XCD
+//        works through every stripe (an XCD that drew an expensive eighth of the WHOLE source finished late, round
+//        after round: round 3's reason to keep this to resident grids) and still sees one X-th of the stripe.
+// A bijection of [0, L) for any L, off, X >= 1, m; rows are numbered by chunk, so the final sum -- fixed order over the
+// rows -- does not change by a bit whatever the mapping.
+__host__ __device__ inline int xcd_chunk(int p, int L, int off, int X, int m) {
+  int base = 0, l = p, len = L;
+  if (m > 0) {
+    const int S = X * m;
+    base = (p / S) * S;
+    l = p - base;
+    len = (L - base < S) ? L - base : S;
+  }
+  const int x = (l + off) % X;              // the XCD this block runs on
+  const int b0 = (x - off % X + X) % X;     // first position of the stripe on that XCD
+  const int j = (l - b0) / X;               // rank among the stripe's blocks of that XCD
+  const int q = len / X, r = len % X;
+  int start = 0;
+  for (int xx = 0; xx < x; ++xx) start += q + (((xx - off % X + X) % X) < r ? 1 : 0);
+  return base + start + j;
+}
 
 // layout of one evaluation (matches NDT_EVAL_WORDS in include/ndt_hip.h)
 enum {

@@ -123,10 +123,11 @@ hipError_t sort_source_by_blocks(const float* x, const float* y, const float* z,
                                  float* oz, hipStream_t s);
 
 // ---- derivative evaluation (ndt_derivs.hip) ---------------------------------
-void derivs_set_compute_units(int n);  // CUs of the device: single-pose launches of mid-sized scans are shaped one block per CU
-int derivs_grid_blocks(size_t n_src, int K);
-int derivs_block_threads(size_t n_src, int K);
-size_t derivs_partials_words(size_t n_src, int K);  // doubles needed in d_partials
+// cus: compute units of the handle's device (EvalConsts::compute_units): single-pose launches of mid-sized scans are
+// shaped one block per CU, and the XCD count follows from it
+int derivs_grid_blocks(size_t n_src, int K, int cus);
+int derivs_block_threads(size_t n_src, int K, int cus);
+size_t derivs_partials_words(size_t n_src, int K, int cus);  // doubles needed in d_partials
 int derivs_counters_per_pose();
 int derivs_read_stamps(unsigned long long* out, int nblocks);  // diagnostic builds (-DNDT_STAMPS) only                     // ticket words per pose in d_counters
 // d_partials: derivs_partials_words() doubles, ZEROED when allocated (rows of tagged slots);

