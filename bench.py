@@ -384,7 +384,7 @@ def main():
                        "reduce": reduce_mode, "reduce_variants": variants},
             "ms_target_build_device": gi["ms_build"],
             "final_error_vs_ground_truth": {"m": err_t, "rad": err_r},
-            # `bound`: what the evidence shows limits this launch (80 % of the 200 k-point launch is a
+            # `bound`: what the evidence shows limits this launch (DESIGN 4.1 / HISTORY 4.1: half of the 200 k-point launch is a
             # fixed latency chain, the rest VALU issue); `roof`: the roofline `achieved` / `peak` / `frac` are
             # priced against, as the contract defines them (algorithmic bytes over the HBM peak)
             "roofline": {"bound": "latency/valu", "roof": "hbm", "kernel": "k_derivatives", "achieved": achieved, "peak": HBM_PEAK_GBS,

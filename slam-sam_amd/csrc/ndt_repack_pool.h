@@ -73,7 +73,7 @@ struct RepackPool {
   std::atomic<unsigned long> gen{0};
   std::atomic<int> pending{0};       // workers that have not finished the current generation's job yet
   std::atomic<bool> stop{false};
-  int spin_us = 250;
+  int spin_us = 100;   // (a driver at 10-20 Hz: ~1 ms of spinning per second and worker; a 1 kHz replay keeps them awake)
   // A worker only ever runs the job of a generation that was published AFTER it started: it is born
   // with `seen` = the generation current at that moment (read under the mutex).  A worker born with
   // seen = 0 into a pool whose gen was already > 0 used to wake at once and run the PREVIOUS upload's
