@@ -158,3 +158,90 @@ def test_handoff_timing_reports_dma_rate(pkg, S):
     ndt.enableKernelTiming(False)
     assert t["target"]["bytes_in"] == 32 * len(t32) and t["target"]["ms_dma"] > 0 and t["target"]["dma_gb_per_s"] > 1.0
     assert t["source"]["ms_dma"] > 0 and t["source"]["ms_repack"] > 0
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_random_api_sequences_async_equals_sync(pkg, S, hipmem, seed):
+    """Differential fuzz of the asynchronous hand-off's bookkeeping: two engines, one blocking, one asynchronous, are fed
+    the SAME random sequence of calls (targets and sources through every entry point, consumers of every kind, keyframes,
+    downsample, parameter changes in between) -- whatever is pending when a call arrives, every observable must be
+    identical, errors included."""
+    rng = np.random.default_rng(seed)
+    a, b = S.config_c1(), S.config_c2()
+    clouds = [a["target"], b["target"][::2], a["target"][::3] + np.float32(0.25), b["target"]]
+    sources = [a["source"], b["source"][::4], a["source"][::2]]
+    guesses = [a["guess"], b["guess"], a["guess"]]
+    bad = np.full((3000, 3), np.nan, np.float32)
+    dev = {k: [hipmem.upload(np.ascontiguousarray(c[:, ax])) for ax in range(3)] for k, c in enumerate(clouds)}
+    dsrc = {k: [hipmem.upload(np.ascontiguousarray(c[:, ax])) for ax in range(3)] for k, c in enumerate(sources)}
+    eng = {}
+    for mode in (pkg.HANDOFF_SYNC, pkg.HANDOFF_ASYNC):
+        e = _ndt(pkg)
+        e.setHandoffMode(mode)
+        e.setInputTarget(clouds[0]); e.setInputSource(sources[0]); e.align(guesses[0])
+        eng[mode] = e
+
+    def call(e, op, k):
+        """One operation -> a comparable observation (or the error's status code)."""
+        try:
+            if op == "target":
+                e.setInputTarget(clouds[k % 4]); return "ok"
+            if op == "target_xyzi":
+                e.setInputTarget(_xyzi(clouds[k % 4])); return "ok"
+            if op == "target_soa":
+                e.setInputTargetSoA(*[np.ascontiguousarray(clouds[k % 4][:, ax]) for ax in range(3)]); return "ok"
+            if op == "target_dev":
+                d = dev[k % 4]; e.setInputTargetDevice(d[0], d[1], d[2], len(clouds[k % 4])); return "ok"
+            if op == "target_bad":
+                e.setInputTarget(bad); return "ok"
+            if op == "source":
+                e.setInputSource(sources[k % 3]); return "ok"
+            if op == "source_soa":
+                e.setInputSourceSoA(*[np.ascontiguousarray(sources[k % 3][:, ax]) for ax in range(3)]); return "ok"
+            if op == "source_dev":
+                d = dsrc[k % 3]; e.setInputSourceDevice(d[0], d[1], d[2], len(sources[k % 3])); return "ok"
+            if op == "source_view":
+                d = dsrc[k % 3]; e.setInputSourceDeviceView(d[0], d[1], d[2], len(sources[k % 3])); return "ok"
+            if op == "align":
+                T = e.align(guesses[k % 3]); r = e.getResult()
+                return (T.tobytes(), r["iterations"], r["n_evaluations"], r["score"], r["hessian"].tobytes())
+            if op == "eval":
+                ev = e.evalDerivatives(np.array([0.3, 0.05, 0.0, 0.0, 0.01, 0.02 * (k % 5)]))[0]
+                return (ev["score"], ev["n_pairs"], ev["hessian"].tobytes())
+            if op == "score":
+                sc = e.scoreTransform(guesses[k % 3]); return (sc["score"], sc["n_pairs"])
+            if op == "grid":
+                g = e.getGridInfo(); return (int(g["n_leaves"]), int(g["n_cells"]), int(g["n_target_points"]))
+            if op == "leaves":
+                L = e.getLeaves(); return (L["cell"].tobytes(), L["count"].tobytes(), L["cov"].tobytes())
+            if op == "step":
+                e.setStepSize(0.1 if k % 2 else 0.05); return "ok"
+            if op == "resolution":
+                e.setResolution(1.0 if k % 2 else 1.5); return "ok"
+            if op == "keyframe":
+                e.putKeyframe(7, sources[k % 3]); e.setInputSourceFromKeyframe(7); return "ok"
+            if op == "downsample":
+                return e.voxelDownsample(clouds[k % 4][::5], 0.75).tobytes()
+            if op == "wait":
+                e.wait(); return "ok"
+        except pkg.NdtError as err:
+            return ("error", err.code)
+        raise AssertionError(op)
+
+    ops = ["target", "target_xyzi", "target_soa", "target_dev", "source", "source_soa", "source_dev", "source_view",
+           "align", "align", "eval", "score", "grid", "leaves", "step", "resolution", "keyframe", "downsample", "wait",
+           "target_bad"]
+    weights = np.array([4, 3, 2, 2, 4, 2, 1, 1, 5, 5, 3, 2, 2, 1, 2, 1, 1, 1, 1, 1], float)
+    weights /= weights.sum()
+    history = []
+    for i in range(400):
+        op = ops[rng.choice(len(ops), p=weights)]
+        k = int(rng.integers(0, 12))
+        history.append((op, k))
+        ra = call(eng[pkg.HANDOFF_SYNC], op, k)
+        rb = call(eng[pkg.HANDOFF_ASYNC], op, k)
+        if op.startswith("target") and isinstance(ra, tuple) and ra[0] == "error" and rb == "ok":
+            # the blocking hand-off reports a failed build at once, the asynchronous one at the first consumer
+            # (or, for the build after a failed one, at once as well): take the deferred verdict now
+            rb = call(eng[pkg.HANDOFF_ASYNC], "wait", 0)
+        assert ra == rb, (i, history[-8:], ra if not isinstance(ra, tuple) or ra[0] == "error" else "...", rb if not isinstance(rb, tuple) or rb[0] == "error" else "...")
