@@ -2028,10 +2028,8 @@ static int eval_batch(ndt_handle* h, const double* poses6, const float* transfor
     }
   std::memcpy(out, h->result.h, (size_t)K * EV_WORDS * sizeof(double));
   if (!h->red.wants_device_buffer() && h->red.mode() != NDT_REDUCE_NONE) {
-    for (int k = 0; k < K; ++k) {
-      rc = h->red.allreduce_host(out + (size_t)k * EV_WORDS, EV_WORDS, &h->err);
-      if (rc) return rc;
-    }
+    rc = h->red.allreduce_host_batch(out, K, &h->err);   // (P2P: one exchange round per 64 poses, not one per pose)
+    if (rc) return rc;
   }
   if (score_only) return NDT_OK;
   // ridge / regularisation / guards, then repack so callers see finished values

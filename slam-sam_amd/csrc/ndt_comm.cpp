@@ -8,6 +8,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -295,6 +296,7 @@ int Reducer::init_p2p(const void* handles, int rank, int nranks, std::string* er
   rank_ = rank;
   nranks_ = nranks;
   xround_ = 0;
+  xbround_ = 0;
   return NDT_OK;
 }
 
@@ -390,6 +392,99 @@ int Reducer::p2p_finish_on_host(uint64_t round, double* words, int n, std::strin
   return NDT_OK;
 }
 
+#ifdef __HIPCC__
+namespace {
+// block k publishes pose k's row: lane v stores slot v {round, value} into every rank's batch region
+__global__ void __launch_bounds__(64) k_publish_batch(XchgInfo info, unsigned long long round, const double* __restrict__ vals) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const int v = threadIdx.x, k = blockIdx.x;
+  if (v >= NDT_EVAL_WORDS) return;
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(vals[(size_t)k * NDT_EVAL_WORDS + v]);
+  u32x4 d;
+  d.x = (unsigned int)round; d.y = (unsigned int)(round >> 32); d.z = (unsigned int)bits; d.w = (unsigned int)(bits >> 32);
+  for (int r = 0; r < info.nranks; ++r) {
+    char* base = reinterpret_cast<char*>(info.area[r]) + xchg_batch_offset(round, k, info.rank, v);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, 16u, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(d, rs, 0, 0, 17 /* sc0 sc1: system scope */);
+  }
+}
+}  // namespace
+#endif
+
+int Reducer::allreduce_host_batch(double* words, int K, std::string* err) {
+  if (K <= 0) return NDT_OK;
+#ifdef __HIPCC__
+  if (mode_ == NDT_REDUCE_P2P) {
+    if (!xstage_) {
+      hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&xstage_), (size_t)XCHG_BATCH_MAX * NDT_EVAL_WORDS * sizeof(double), hipHostMallocMapped);
+      if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&xback_), (size_t)XCHG_BATCH_MAX * XCHG_MAX_RANKS * 2 * NDT_EVAL_WORDS * sizeof(unsigned long long), 0);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (err) *err = hip_err("pinned staging of the batched exchange", e);
+        return NDT_ERR_COMM;
+      }
+    }
+    XchgInfo info;
+    std::memset(&info, 0, sizeof(info));
+    info.rank = rank_;
+    info.nranks = nranks_;
+    for (int r = 0; r < nranks_; ++r) info.area[r] = (unsigned long long)reinterpret_cast<uintptr_t>(xpeer_[r]);
+    for (int k0 = 0; k0 < K; k0 += XCHG_BATCH_MAX) {
+      const int kb = std::min(XCHG_BATCH_MAX, K - k0);
+      const uint64_t round = ++xbround_;
+      std::memcpy(xstage_, words + (size_t)k0 * NDT_EVAL_WORDS, (size_t)kb * NDT_EVAL_WORDS * sizeof(double));
+      double* stage_dev = nullptr;
+      hipError_t e = hipHostGetDevicePointer(reinterpret_cast<void**>(&stage_dev), xstage_, 0);
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_publish_batch, dim3((unsigned)kb), dim3(64), 0, nullptr, info, (unsigned long long)round, (const double*)stage_dev);
+        e = hipGetLastError();
+      }
+      if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+      if (e != hipSuccess) {
+        if (err) *err = hip_err("batched peer-write from the host", e);
+        return NDT_ERR_COMM;
+      }
+      // gather: the rows of poses 0 .. kb-1, ranks 0 .. nranks-1 of this generation of the OWN area (one strided copy per poll)
+      const size_t row_bytes = (size_t)2 * NDT_EVAL_WORDS * sizeof(unsigned long long);   // 512
+      const size_t width = (size_t)nranks_ * row_bytes, pitch = (size_t)XCHG_MAX_RANKS * row_bytes;
+      const auto t0 = std::chrono::steady_clock::now();
+      for (;;) {
+        e = hipMemcpy2D(xback_, width, static_cast<const char*>(xarea_) + xchg_batch_offset(round, 0, 0, 0), pitch, width, (size_t)kb,
+                        hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+          if (err) *err = hip_err("reading the batched exchange area", e);
+          return NDT_ERR_COMM;
+        }
+        bool ok = true;
+        for (size_t i = 0; i < (size_t)kb * nranks_ * NDT_EVAL_WORDS && ok; ++i) ok = xback_[2 * i] == round;
+        if (ok) break;
+        if (std::chrono::steady_clock::now() - t0 > wait_limit()) {
+          if (err) *err = "peer-write all-reduce (batched) timed out waiting for a rank";
+          return NDT_ERR_COMM;
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(20));
+      }
+      for (int k = 0; k < kb; ++k)
+        for (int v = 0; v < NDT_EVAL_WORDS; ++v) {
+          double s = 0.0;
+          for (int r = 0; r < nranks_; ++r) {   // rank order: every rank obtains bit-identical sums
+            double w;
+            std::memcpy(&w, &xback_[(((size_t)k * nranks_ + r) * NDT_EVAL_WORDS + v) * 2 + 1], sizeof(double));
+            s += w;
+          }
+          words[(size_t)(k0 + k) * NDT_EVAL_WORDS + v] = s;
+        }
+    }
+    return NDT_OK;
+  }
+#endif
+  for (int k = 0; k < K; ++k) {
+    int rc = allreduce_host(words + (size_t)k * NDT_EVAL_WORDS, NDT_EVAL_WORDS, err);
+    if (rc) return rc;
+  }
+  return NDT_OK;
+}
+
 int Reducer::init_hook(ndt_allreduce_fn fn, void* ctx, int rank, int nranks) {
   destroy();
   if (!fn || nranks < 1 || rank < 0 || rank >= nranks) return NDT_ERR_INVALID_ARG;
@@ -418,7 +513,10 @@ void Reducer::destroy() {
     }
     if (xinfo_dev_) { (void)hipFree(xinfo_dev_); xinfo_dev_ = nullptr; }
     if (xarea_) { (void)hipFree(xarea_); xarea_ = nullptr; }
+    if (xstage_) { (void)hipHostFree(xstage_); xstage_ = nullptr; }
+    if (xback_) { (void)hipHostFree(xback_); xback_ = nullptr; }
     xround_ = 0;
+    xbround_ = 0;
   }
   hook_ = nullptr;
   hook_ctx_ = nullptr;

@@ -53,6 +53,10 @@ class Reducer {
   int allreduce_device(double* d_words, int n, hipStream_t s, std::string* err);
   // host-side all-reduce of words that are already on the host, in place
   int allreduce_host(double* words, int n, std::string* err);
+  // K evaluations of NDT_EVAL_WORDS words each (a batched launch's results), in place.  NDT_REDUCE_P2P exchanges up to
+  // XCHG_BATCH_MAX of them in ONE round (one publish kernel, one strided read-back per poll) instead of K rounds of
+  // blocking copies; the other transports go evaluation by evaluation.
+  int allreduce_host_batch(double* words, int K, std::string* err);
 
  private:
   int mode_ = NDT_REDUCE_NONE;
@@ -68,6 +72,9 @@ class Reducer {
   void* xpeer_[XCHG_MAX_RANKS] = {};      // every rank's area as mapped here; [rank_] == xarea_
   void* xinfo_dev_ = nullptr;
   uint64_t xround_ = 0;                   // global evaluations exchanged so far
+  uint64_t xbround_ = 0;                  // batched rounds exchanged so far (their own region of the area, their own tags)
+  double* xstage_ = nullptr;              // pinned, device-mapped: the batch's values on their way to the publish kernel
+  unsigned long long* xback_ = nullptr;   // pinned: the rows of a batch round as read back
   int p2p_publish_from_host(uint64_t round, const double* words, int n, std::string* err);
   // hook
   ndt_allreduce_fn hook_ = nullptr;

@@ -191,13 +191,21 @@ enum {
 // ahead of the slowest -- it cannot publish round k + 2 before every peer has published k + 1, which a
 // peer does only after it has finished reading round k (the lesson of the alternating result buffers).
 constexpr int XCHG_MAX_RANKS = 64;
-constexpr size_t XCHG_AREA_BYTES = (size_t)2 * XCHG_MAX_RANKS * EV_WORDS * 16;  // 64 KB
+constexpr size_t XCHG_SINGLE_BYTES = (size_t)2 * XCHG_MAX_RANKS * EV_WORDS * 16;  // 64 KB: rows of single-pose evaluations
+// Behind them, in the same allocation (one IPC handle): rows of BATCHED evaluations (ndt_eval_derivatives with K poses,
+// SVN Stage 1), exchanged by the host in ONE round per batch of up to XCHG_BATCH_MAX poses: [generation][pose][rank][32 slots]
+constexpr int XCHG_BATCH_MAX = 64;
+constexpr size_t XCHG_BATCH_BYTES = (size_t)2 * XCHG_BATCH_MAX * XCHG_MAX_RANKS * EV_WORDS * 16;  // 4 MB
+constexpr size_t XCHG_AREA_BYTES = XCHG_SINGLE_BYTES + XCHG_BATCH_BYTES;
 struct XchgInfo {
   int rank, nranks;
   unsigned long long area[XCHG_MAX_RANKS];  // every rank's exchange area as mapped in THIS process; [rank] is local
 };
 __host__ __device__ inline unsigned int xchg_slot_offset(unsigned long long round, int row, int word) {
   return (unsigned int)((((unsigned int)(round & 1ull) * XCHG_MAX_RANKS + (unsigned int)row) * EV_WORDS + (unsigned int)word) * 16u);
+}
+__host__ __device__ inline size_t xchg_batch_offset(unsigned long long round, int pose, int row, int word) {
+  return XCHG_SINGLE_BYTES + ((((size_t)(round & 1ull) * XCHG_BATCH_MAX + (size_t)pose) * XCHG_MAX_RANKS + (size_t)row) * EV_WORDS + (size_t)word) * 16u;
 }
 constexpr unsigned long long XCHG_TIMEOUT_TICKS = 2000000ull;  // 20 ms: a peer that is later than that is waited for by the host
 

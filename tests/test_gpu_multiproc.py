@@ -39,10 +39,22 @@ def _worker(rank, world, name, out_dir, mode="shm"):
     used, quit, timeouts = ndt.prelaunchCounters()
     e = ndt.evalDerivatives(r["pose"])[0]            # a batch of one: the host-side round of the same exchange
     sc = ndt.scoreTransform(T)                        # score-only kernel through the in-kernel exchange
+    # real batches (SVN Stage 1's shape): 5 poses = one exchange round of the batched region, 70 poses = two rounds
+    # (64 + 6); then single-pose rounds again -- the two regions and their tags never mix
+    rng = np.random.default_rng(3)
+    poses5 = r["pose"] + rng.normal(0, 0.01, (5, 6))
+    poses70 = r["pose"] + rng.normal(0, 0.01, (70, 6))
+    b5 = ndt.evalDerivatives(poses5)
+    b70 = ndt.evalDerivatives(poses70, compute_hessian=False)
+    b5_again = ndt.evalDerivatives(poses5)
+    assert all(x["score"] == y["score"] and np.array_equal(x["hessian"], y["hessian"]) for x, y in zip(b5, b5_again))
     T2 = ndt.align(cfg["guess"])                      # a second align on the same reducer (round tags keep counting)
     np.savez(os.path.join(out_dir, "%s_rank%d.npz" % (mode, rank)), T=T, T2=T2, it=r["iterations"], ev=r["n_evaluations"],
              H=r["hessian"], tp=r["transform_probability"], n_pairs=e["n_pairs"], score=e["score"], g=e["gradient"],
-             sc=sc["score"], used=used, timeouts=timeouts, finishes=ndt.p2pHostFinishes())
+             sc=sc["score"], used=used, timeouts=timeouts, finishes=ndt.p2pHostFinishes(),
+             b5s=np.array([x["score"] for x in b5]), b5H=np.stack([x["hessian"] for x in b5]),
+             b70s=np.array([x["score"] for x in b70]), b70g=np.stack([x["gradient"] for x in b70]),
+             b70n=np.array([x["n_pairs"] for x in b70]))
     if board is not None:
         board.barrier()   # nobody unmaps a peer's area while that peer may still write into it
     ndt.commDestroy()
@@ -99,7 +111,7 @@ def test_two_processes_one_gpu_peer_write_reduction_equals_shm(pkg, S, tmp_path)
             p.join(600)
             assert p.exitcode == 0, mode
     z = {m: [np.load(os.path.join(str(tmp_path), "%s_rank%d.npz" % (m, k))) for k in range(world)] for m in ("shm", "p2p")}
-    for key in ("T", "T2", "H", "it", "ev", "tp", "n_pairs", "score", "g", "sc"):
+    for key in ("T", "T2", "H", "it", "ev", "tp", "n_pairs", "score", "g", "sc", "b5s", "b5H", "b70s", "b70g", "b70n"):
         a = z["shm"][0][key]
         for m in ("shm", "p2p"):
             for k in range(world):
