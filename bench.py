@@ -224,7 +224,9 @@ def main():
 
     # ranks that share one device (rehearsal): every engine keeps its pre-launched kernels on its own stream -- a
     # waiting kernel holds compute units the other rank's running kernel needs (include/ndt_hip.h, ndt_prelaunch)
-    engine_kw = dict(params, prelaunch=pkg.PRELAUNCH_ONE_STREAM) if (rehearsal and world > 1) else dict(params)
+    # (NDT_BENCH_REHEARSAL_AUTO=1 leaves the choice to NDT_PRELAUNCH_AUTO, which finds out by measurement)
+    force_one = rehearsal and world > 1 and os.environ.get("NDT_BENCH_REHEARSAL_AUTO", "0") != "1"
+    engine_kw = dict(params, prelaunch=pkg.PRELAUNCH_ONE_STREAM) if force_one else dict(params)
     ndt = pkg.NormalDistributionsTransform(device_id=local_rank, **engine_kw)
 
     # what a C++ caller hands over without any per-call work: raw pointers and guess.data()
@@ -299,7 +301,7 @@ def main():
                                 struct.pack("<qq", iters, evals)).hexdigest()[:16]
         return dict(elapsed=elapsed, iters=iters, evals=evals, reused=reused, t_build=t_build, t_align=t_align,
                     prelaunched=pre1[0] - pre0[0], prelaunch_timeouts=pre1[2] - pre0[2], err_m=err_t, err_rad=err_r,
-                    digest=digest, lost_row_retries=ndt.lostRowRetries())
+                    digest=digest, lost_row_retries=ndt.lostRowRetries(), auto_streams=ndt.autoStreamPlacement())
 
     unavailable = {}
 
@@ -427,6 +429,7 @@ def main():
             "evaluations_prelaunched_per_align": res["prelaunched"] / args.steps,
             "prelaunch_timeouts": res["prelaunch_timeouts"],
             "align_only_iterations_per_sec": iters / res["t_align"], "evaluations_per_sec": evals / res["t_align"],
+            "prelaunch_auto": {"one_stream": res["auto_streams"][0], "switches": res["auto_streams"][1]},
         })
         out["config"]["reduce"] = reduce_mode
 
@@ -685,7 +688,9 @@ def main():
                                       "ranks": n_comm, "evaluations_prelaunched_per_align": res["prelaunched"] / args.steps,
                                       "iterations_per_align": res["iters"] / args.steps, "final_error_m": res["err_m"],
                                       "answer_digest": digests[mode], "ranks_bit_identical": ranks_agree,
-                                      "lost_row_retries": res["lost_row_retries"]}
+                                      "lost_row_retries": res["lost_row_retries"],
+                                      # (NDT_PRELAUNCH_AUTO's placement of waiting kernels on this rank: 1 = one stream; switches)
+                                      "auto_one_stream": res["auto_streams"][0], "auto_switches": res["auto_streams"][1]}
                     if not sane:
                         variants[mode]["suspect"] = "final pose more than 5 cm from ground truth: not eligible as the headline"
                     elif not ranks_agree:

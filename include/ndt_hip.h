@@ -110,7 +110,11 @@ typedef enum ndt_prelaunch {
                              (~4 us of ~7) out of every evaluation but the first.  Successive kernels alternate
                              between two streams of the engine, so that the next one takes compute units as the
                              blocks of the one in flight leave.  Used when the device exposes a large BAR; a kernel
-                             that waited 20 ms gives up and the pose is evaluated through an ordinary launch. */
+                             that waited 20 ms gives up and the pose is evaluated through an ordinary launch.
+                             The two-stream placement is right for a device the engine has to itself; AUTO checks that
+                             by measurement (every 32nd align runs with the one-stream placement; one that is 15 %
+                             faster per evaluation switches the handle over, and back the same way), so a second
+                             engine or process on the same device is noticed without being told. */
   NDT_PRELAUNCH_OFF = 1,
   NDT_PRELAUNCH_ONE_STREAM = 2 /* as AUTO, but every kernel stays on the engine's one stream (the next starts when the
                              current one has ENDED).  For several engines / processes that share ONE device: a

@@ -703,25 +703,31 @@ class NormalDistributionsTransform:
 
     def prelaunchCounters(self):
         """(evaluations served by a pre-launched kernel, pre-launched kernels told to leave, time-outs)."""
-        out = (C.c_int64 * 6)()
+        out = (C.c_int64 * 8)()
         self._check(lib().ndt_debug_prelaunch_counters(self._h, out))
         return tuple(out)[:3]
 
+    def autoStreamPlacement(self):
+        """(1 if NDT_PRELAUNCH_AUTO has settled on the one-stream placement of waiting kernels, switches so far)."""
+        out = (C.c_int64 * 8)()
+        self._check(lib().ndt_debug_prelaunch_counters(self._h, out))
+        return int(out[6]), int(out[7])
+
     def lostRowRetries(self):
         """Evaluations repeated through the ticketed final sum after the summing block had given up waiting for a row."""
-        out = (C.c_int64 * 6)()
+        out = (C.c_int64 * 8)()
         self._check(lib().ndt_debug_prelaunch_counters(self._h, out))
         return int(out[5])
 
     def prelaunchOverlapped(self):
         """Pre-launched kernels that were enqueued on the other stream (resident before their predecessor ended)."""
-        out = (C.c_int64 * 6)()
+        out = (C.c_int64 * 8)()
         self._check(lib().ndt_debug_prelaunch_counters(self._h, out))
         return int(out[3])
 
     def p2pHostFinishes(self):
         """Peer-write evaluations whose cross-rank exchange the host had to finish (a peer's row was > 20 ms late)."""
-        out = (C.c_int64 * 6)()
+        out = (C.c_int64 * 8)()
         self._check(lib().ndt_debug_prelaunch_counters(self._h, out))
         return int(out[4])
 

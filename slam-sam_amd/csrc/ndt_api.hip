@@ -247,6 +247,17 @@ struct ndt_handle {
   int pre_on2 = 0;                    // ... and the stream it is on (0: stream, 1: stream2)
   int cur_on2 = 0;                    // stream of the evaluation in flight
   bool two_streams = true;            // NDT_PRELAUNCH_STREAMS != 1
+  // NDT_PRELAUNCH_AUTO decides between the two-stream and the one-stream placement of the waiting kernel BY MEASUREMENT:
+  // a waiting kernel on the other stream holds its compute units for the whole evaluation of its predecessor -- harmless
+  // on a device the engine has to itself, ruinous when another engine's kernels need those units (two ranks on one
+  // device: 0.97 against 0.59 ms per step, HISTORY section 5).  The handle keeps a running mean of the wall time per
+  // launched evaluation in the placement in use and runs every 32nd align in the other one as a probe; a probe that is
+  // 15 % faster switches the handle over (and the probing goes on from there, so it can switch back).
+  bool auto_one_stream = false;       // the placement AUTO currently uses
+  bool probing = false;               // this align runs in the other placement
+  bool streams_this_align = true;     // two-stream placement in effect for the align in flight
+  double us_eval_mean[2] = {0.0, 0.0};  // [0] two streams, [1] one stream; 0 = no sample yet
+  int64_t n_auto_aligns = 0, n_auto_switches = 0;
   DevBuf<unsigned int> arrive_ctr;    // [2] blocks of a pre-launched launch that have started (per result buffer)
   PinBuf<unsigned long long> arrived; // [2] sequence number of the launch whose blocks are all resident
   int pre_buf = 0;                    // ... and the result buffer (0 / 1) it will write
@@ -392,6 +403,12 @@ int upload_soa(ndt_handle* h, ndt_handle::UploadLane& lane, hipStream_t stream, 
 // the launch call instead, as rounds 1-2 did (adds the dispatch, ~2.4 us: the tuning scripts' older numbers).
 bool timing_brackets_launch() {
   static const bool on = [] { const char* e = getenv("NDT_TIMING_BRACKET"); return e && atoi(e) != 0; }();
+  return on;
+}
+
+// NDT_PRELAUNCH_PROBE=0: NDT_PRELAUNCH_AUTO never probes the other stream placement (A/B aid)
+bool auto_probe_enabled() {
+  static const bool on = [] { const char* e = getenv("NDT_PRELAUNCH_PROBE"); return !(e && atoi(e) == 0); }();
   return on;
 }
 
@@ -1091,7 +1108,7 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
     // starting.  The next kernel is not needed for another ~10 us, so the host can afford to watch the arrival
     // word for a few microseconds before it decides.)
     bool in_flight_resident = false;
-    if (h->two_streams && h->prm.prelaunch == NDT_PRELAUNCH_AUTO && via_mailbox) {
+    if (h->streams_this_align && via_mailbox) {
       const auto t_arr = std::chrono::steady_clock::now();
       for (unsigned spins = 0;; ++spins) {
         if (__atomic_load_n(&h->arrived.h[buf], __ATOMIC_ACQUIRE) == seq) { in_flight_resident = true; break; }
@@ -1891,8 +1908,30 @@ int ndt_align(ndt_handle* h, const float guess[16], ndt_result* out) {
   const int64_t n_total = h->n_src_global >= 0 ? h->n_src_global : (int64_t)h->n_src;
   h->prelaunch_armed = true;
   const int64_t timeouts0 = h->n_prelaunch_timeouts;
+  // placement of the waiting kernels for this align (see auto_one_stream)
+  const bool auto_mode = h->two_streams && h->prm.prelaunch == NDT_PRELAUNCH_AUTO;
+  h->probing = auto_mode && auto_probe_enabled() && (++h->n_auto_aligns % 32) == 0;
+  h->streams_this_align = auto_mode && (h->auto_one_stream == h->probing);   // two streams unless AUTO settled on one (probe: the other)
+  const int64_t used0 = h->n_prelaunch_used, launches0 = h->tm.n_eval_launches;
   rc = newton_align(h->prm, n_total, guess, fn, out, /*hessian_in_trials=*/true);
   h->prelaunch_armed = false;
+  if (auto_mode && rc == NDT_OK && h->n_prelaunch_timeouts == timeouts0) {
+    const int64_t launched = h->tm.n_eval_launches - launches0;
+    if (launched >= 8 && h->n_prelaunch_used - used0 >= launched - 2) {   // a pre-launched align of some length
+      const int which = h->streams_this_align ? 0 : 1;
+      const double us = 1e3 * out->ms_total / (double)launched;
+      double& m = h->us_eval_mean[which];
+      m = m == 0.0 ? us : 0.8 * m + 0.2 * us;
+      const int cur = h->auto_one_stream ? 1 : 0, other = 1 - cur;
+      if (h->probing && h->us_eval_mean[cur] > 0.0 && us < 0.85 * h->us_eval_mean[cur]) {
+        h->auto_one_stream = !h->auto_one_stream;
+        h->us_eval_mean[cur] = 0.0;     // the situation has changed: what was measured in it is stale
+        (void)other;
+        ++h->n_auto_switches;
+      }
+    }
+  }
+  h->probing = false;
   if (h->n_prelaunch_timeouts == timeouts0) h->prelaunch_strikes = 0;
   quit_prelaunched(h);  // the kernel enqueued for an evaluation that never came
   out->ms_device = h->tm.ms_eval_kernel_total - dev_ms0;
@@ -2249,12 +2288,14 @@ int ndt_result_covariance(const double hessian36[36], double eps, int gtsam_orde
 
 // test seam (not in the public header): evaluations served by a pre-launched kernel, pre-launched
 // kernels told to leave, mailbox time-outs
-int ndt_debug_prelaunch_counters(const ndt_handle* h, int64_t out[6]) {
+int ndt_debug_prelaunch_counters(const ndt_handle* h, int64_t out[8]) {
   if (!h || !out) return NDT_ERR_INVALID_ARG;
   out[0] = h->n_prelaunch_used; out[1] = h->n_prelaunch_quit; out[2] = h->n_prelaunch_timeouts;
   out[3] = h->n_prelaunch_overlapped;
   out[4] = h->n_p2p_host_finishes;
   out[5] = h->n_lost_row_retries;
+  out[6] = h->auto_one_stream ? 1 : 0;   // the stream placement NDT_PRELAUNCH_AUTO has settled on (1: one stream)
+  out[7] = h->n_auto_switches;
   return NDT_OK;
 }
 

@@ -108,6 +108,22 @@ def test_bench_four_ranks_on_one_device_rehearsal():
     assert "hand-off lost" not in r.stderr
 
 
+def test_prelaunch_auto_notices_a_second_engine_on_the_device():
+    """Two ranks on ONE device with the stream placement of the waiting kernels left to NDT_PRELAUNCH_AUTO: on the other
+    stream a waiting kernel holds its compute units for the whole evaluation of its predecessor -- units the other rank's
+    kernel needs (5 ms per step measured, against 0.59 with one stream; profiles/r04_prelaunch_auto_placement.txt).  AUTO
+    probes the other placement every 32nd align and must have switched both ranks to one stream by the timed steps."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NDT_RANKS_BOARD")}
+    env.update(NDT_BENCH_PROBE="0", NDT_BENCH_SINGLE_DEVICE="1", NDT_BENCH_REHEARSAL_AUTO="1", NDT_BENCH_REDUCE="shm")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "70",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
+    v = d["config"]["reduce_variants"]["shm"]
+    assert v["auto_one_stream"] == 1 and v["auto_switches"] >= 1 and v["ranks_bit_identical"]
+    assert d["ms_per_step"] < 2.0, d["ms_per_step"]
+
+
 def test_bench_forced_distributed_one_rank_runs_rccl():
     """NDT_BENCH_FORCE_DIST=1: the whole multi-rank path with ONE rank -- the only way to execute the RCCL
     leg (ncclCommInitRank + one ncclAllReduce per evaluation) on a 1-GPU box.  The line reports the
