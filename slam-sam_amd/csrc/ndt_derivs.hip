@@ -1236,7 +1236,16 @@ static int derivs_point_blocks(size_t n_src, int K, int cus) {
 
 // 1: block 0 of the grid owns no points and adds the rows (single-level grids with the fixed summer)
 static int derivs_dedicated_summer(size_t n_src, int K, int cus) {
-  return deriv_dedicated_enabled() && deriv_fixed_summer() != 0 && derivs_point_blocks(n_src, K, cus) <= deriv_single_level_max() ? 1 : 0;
+  if (!deriv_dedicated_enabled() || deriv_fixed_summer() == 0) return 0;
+  const int pb = derivs_point_blocks(n_src, K, cus);
+  if (pb > deriv_single_level_max()) return 0;
+  // The summing block needs a compute unit of its own.  A single-pose grid whose point blocks fill the machine EXACTLY
+  // -- 256 blocks of 512 threads: a 128 x 1024 Ouster scan, the size of C2 and of every C5 frame -- would push one
+  // compute unit to two point blocks (4 waves per SIMD instead of 2), and the launch waits for that unit: 15.5 us against
+  // 11.2 with block 0 doubling as the summer (profiles/r04_c2_block_shapes.txt).  Same rows, same order: the same bits.
+  const int g_compute_units = cus_or_default(cus);
+  if (K == 1 && pb <= g_compute_units && pb + 1 > g_compute_units) return 0;
+  return 1;
 }
 
 int derivs_grid_blocks(size_t n_src, int K, int cus) { return derivs_point_blocks(n_src, K, cus) + derivs_dedicated_summer(n_src, K, cus); }
