@@ -33,11 +33,13 @@ if has pmc; then     # counters in their own passes, kernel-trace only (the pool
 fi
 if has sweeps; then  # source-size sweep, per-mode numbers, replay
   timeout -k 10 300 python tools/size_sweep.py both 2>&1 | nolog > $OUT/size_sweep.txt
-  # ... and the same sweep under a FETCH_SIZE pass (own run, kernel-trace only): HBM-side bytes per launch beside each row
-  ( cd /tmp && export TMPDIR=/tmp
-    timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/sweep_pmc -- python3 $R/tools/size_sweep.py both > $OUT/sweep_pmc.log 2>&1 )
-  python3 tools/sweep_fetch.py $OUT/sweep_pmc > $OUT/size_sweep_fetch.txt 2>&1
-  find $OUT/sweep_pmc -name "*kernel_trace.csv" -delete; find $OUT/sweep_pmc -name "*agent_info.csv" -delete; find $OUT/sweep_pmc -name "*counter_collection.csv" -delete
+  # ... and the same sweep under a FETCH_SIZE pass per map (own runs, kernel-trace only): HBM-side bytes per launch beside each row
+  for m in c3 wide; do
+    ( cd /tmp && export TMPDIR=/tmp
+      timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/sweep_pmc_$m -- python3 $R/tools/size_sweep.py $m > $OUT/sweep_pmc_$m.log 2>&1 )
+    python3 tools/sweep_fetch.py $OUT/sweep_pmc_$m > $OUT/size_sweep_fetch_$m.txt 2>&1
+    rm -rf $OUT/sweep_pmc_$m
+  done
   timeout -k 10 300 python tools/modes_bench.py 2>&1 | nolog > $OUT/modes.txt
   timeout -k 10 300 python -m pytest tests/test_gpu_replay.py -m gpu -q -s 2>&1 | grep "C5" > $OUT/replay.txt
 fi
