@@ -570,7 +570,7 @@ int build_enqueue(ndt_handle* h, ndt_handle::BuildRun& br) {
     HIP_TRY(h, launch_bucket_build(x, y, z, n, br.leaf, br.inv_leaf, cap_cells, min_pts, fpb, h->gd.p, h->gdh.d, h->sort_tags.p,
                                    &h->sort_seq, h->stats.p, br.dirty_slots, h->cell2leaf.p, h->cell2leaf.cap, h->bnd.p,
                                    h->bucket_off.p, h->nleaf.p, h->tickets.p + 4, h->xyz4.p, h->leaf_sums.p, h->rec.p,
-                                   h->cent.p, h->stats.p, max_leaves, h->small.d + 8, done_tag, s));
+                                   h->cent.p, h->stats.p, max_leaves, h->small.d + 8, done_tag, s, h->n_cus));
   } else {
     launch_bounds_geometry(x, y, z, n, br.leaf, br.inv_leaf, cap_cells, passes, h->brows.p, h->tickets.p, h->gd.p, h->gdh.d,
                            optimistic ? h->stats.p : nullptr, optimistic ? br.dirty_slots : 0, h->cell2leaf.p,

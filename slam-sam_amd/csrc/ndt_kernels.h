@@ -69,7 +69,8 @@ hipError_t launch_bucket_build(const float* x, const float* y, const float* z, s
                                size_t c2l_cap, int* bnd /* 8 ints, see bucket_bounds_neutral */, int* bucket_off, int* d_nleaf,
                                unsigned int* ticket, float* pts4,
                                double* sums, VoxelRecord* rec, float* cent4 /* 4 floats per leaf slot: f32 centroid + chain link */,
-                               LeafStats* stats, int max_leaves, int* nleaf_host, int done_tag, hipStream_t s);
+                               LeafStats* stats, int max_leaves, int* nleaf_host, int done_tag, hipStream_t s,
+                               int compute_units /* of the device: the pass takes 4096-point tiles when they all fit it */);
 
 // runs of equal cell key with >= min_pts points get a leaf slot (ascending cell order);
 // block_counts / block_offsets: runs_blocks(n) ints each; d_nleaf[0] receives the total

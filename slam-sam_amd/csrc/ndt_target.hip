@@ -1333,6 +1333,10 @@ __device__ __forceinline__ uint32_t bucket_of(float fx, float fy, float fz) {
   return h >> 24;
 }
 
+// ROUNDS: points per thread = tile size / 1024.  8 (8192-point tiles: 123 blocks for 1 M points, fewer than half the
+// compute units) or 4 (4096-point tiles: 245 blocks; the same partition, stable in input order whatever the tile size,
+// so the output is bit-identical).  4 is an A/B knob (launch_bucket_build): no faster.
+template <int ROUNDS>
 __global__ void __launch_bounds__(BK_THREADS) k_bucket_pass(const float* __restrict__ x, const float* __restrict__ y,
                                                            const float* __restrict__ z, int n, float inv_leaf, int ntiles,
                                                            uint32_t* __restrict__ table, uint32_t tag, int mute_tile,
@@ -1341,11 +1345,11 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_pass(const float* __restr
                                                            int* __restrict__ cell2leaf, size_t c2l_cap,
                                                            int* __restrict__ bnd, int* __restrict__ bucket_off,
                                                            int* __restrict__ d_nleaf, float4* __restrict__ pts_out) {
-  constexpr int ROUNDS = BK_ROUNDS;
   constexpr int TILE = BK_THREADS * ROUNDS;
   __shared__ int cnt[BK_WAVES][SORT_BINS];
   // the column partial sums, and later -- once they have been folded -- the tile in bucket order
-  __shared__ float4 stage[TILE];
+  constexpr int STAGE_WORDS = TILE > 2 * BK_WAVES * SORT_BINS / 4 ? TILE : 2 * BK_WAVES * SORT_BINS / 4;  // float4s
+  __shared__ float4 stage[STAGE_WORDS];
   int (*part_total)[SORT_BINS] = reinterpret_cast<int (*)[SORT_BINS]>(stage);
   int (*part_before)[SORT_BINS] = reinterpret_cast<int (*)[SORT_BINS]>(reinterpret_cast<int*>(stage) + BK_WAVES * SORT_BINS);
   __shared__ int gbase[SORT_BINS];
@@ -2531,7 +2535,7 @@ hipError_t launch_bucket_build(const float* x, const float* y, const float* z, s
                                uint32_t* table, uint32_t* seq, const LeafStats* old_stats, int dirty_slots, int* cell2leaf,
                                size_t c2l_cap, int* bnd, int* bucket_off, int* d_nleaf, unsigned int* ticket, float* pts4,
                                double* sums, VoxelRecord* rec, float* cent4, LeafStats* stats, int max_leaves, int* nleaf_host,
-                               int done_tag, hipStream_t s) {
+                               int done_tag, hipStream_t s, int compute_units) {
   if (n == 0) return hipErrorInvalidValue;
   uint32_t tag = (*seq + 1u) & 0xffffu;
   if (tag == 0u) {  // wrapped: forget every old tag before tag 1 is handed out again
@@ -2545,10 +2549,22 @@ hipError_t launch_bucket_build(const float* x, const float* y, const float* z, s
 #else
   constexpr int mute_tile = -1;
 #endif
-  const int ntiles = bucket_build_tiles(n);
-  hipLaunchKernelGGL(k_bucket_pass, dim3((unsigned)ntiles), dim3(BK_THREADS), 0, s, x, y, z, (int)n, inv_leaf, ntiles, table,
-                     tag, mute_tile, gd, gd_host, old_stats, dirty_slots, cell2leaf, c2l_cap, bnd, bucket_off, d_nleaf,
-                     reinterpret_cast<float4*>(pts4));
+  // NDT_BUCKET_TILE=4096 (A/B knob): 4096-point tiles when they all fit the machine at once -- 245 blocks instead of 123
+  // for 1 M points.  Measured in round 4: 23.5 us against 23.2 (profiles/r04_bucket_tile_ab.txt) -- the pass is a chain of
+  // cold-start latencies, not short of parallelism -- so 8192 stays.
+  static const int tile_env = [] { const char* e = getenv("NDT_BUCKET_TILE"); return e ? atoi(e) : 0; }();
+  const int cap_tiles = compute_units < FUSED_MAX_TILES ? compute_units : FUSED_MAX_TILES;
+  const int small_tiles = (int)((n + 4095) / 4096);
+  if (tile_env == 4096 && small_tiles <= cap_tiles) {
+    hipLaunchKernelGGL(k_bucket_pass<4>, dim3((unsigned)small_tiles), dim3(BK_THREADS), 0, s, x, y, z, (int)n, inv_leaf, small_tiles,
+                       table, tag, mute_tile, gd, gd_host, old_stats, dirty_slots, cell2leaf, c2l_cap, bnd, bucket_off, d_nleaf,
+                       reinterpret_cast<float4*>(pts4));
+  } else {
+    const int ntiles = bucket_build_tiles(n);
+    hipLaunchKernelGGL(k_bucket_pass<BK_ROUNDS>, dim3((unsigned)ntiles), dim3(BK_THREADS), 0, s, x, y, z, (int)n, inv_leaf, ntiles,
+                       table, tag, mute_tile, gd, gd_host, old_stats, dirty_slots, cell2leaf, c2l_cap, bnd, bucket_off, d_nleaf,
+                       reinterpret_cast<float4*>(pts4));
+  }
   hipLaunchKernelGGL(k_bucket_leaves, dim3(BK_BUCKETS), dim3(BK_THREADS), 0, s, reinterpret_cast<const float4*>(pts4),
                      bucket_off, bnd, leaf, inv_leaf, cell_capacity, min_pts, fp, gd, gd_host, d_nleaf,
                      reinterpret_cast<unsigned long long*>(ticket) /* 8-byte aligned, zero between builds */, sums,
