@@ -209,6 +209,8 @@ def main():
     hip.set_device(local_rank)
     multi = world > 1 or force_dist
     board = R.Board(R.board_path(), rank, world) if multi else None
+    if board is not None:   # (any rank's note: rank 0 prints the line, the narrowed rank may be another one)
+        device_note = next((b.decode() for b in board.allgather((device_note or "").encode()[:250]) if b), None)
 
     pkg = ge.load_package()
     S = pkg.synth

@@ -251,7 +251,7 @@ struct ndt_handle {
   // a waiting kernel on the other stream holds its compute units for the whole evaluation of its predecessor -- harmless
   // on a device the engine has to itself, ruinous when another engine's kernels need those units (two ranks on one
   // device: 0.97 against 0.59 ms per step, HISTORY section 5).  The handle keeps a running mean of the wall time per
-  // launched evaluation in the placement in use and runs every 32nd align in the other one as a probe; a probe that is
+  // launched evaluation in the placement in use and runs the 4th, the 12th and then every 32nd align in the other one as a probe; a probe that is
   // 15 % faster switches the handle over (and the probing goes on from there, so it can switch back).
   bool auto_one_stream = false;       // the placement AUTO currently uses
   bool probing = false;               // this align runs in the other placement
@@ -1910,7 +1910,8 @@ int ndt_align(ndt_handle* h, const float guess[16], ndt_result* out) {
   const int64_t timeouts0 = h->n_prelaunch_timeouts;
   // placement of the waiting kernels for this align (see auto_one_stream)
   const bool auto_mode = h->two_streams && h->prm.prelaunch == NDT_PRELAUNCH_AUTO;
-  h->probing = auto_mode && auto_probe_enabled() && (++h->n_auto_aligns % 32) == 0;
+  ++h->n_auto_aligns;   // (probes: the 4th and 12th align of a handle, so that a shared device is noticed early, then every 32nd)
+  h->probing = auto_mode && auto_probe_enabled() && (h->n_auto_aligns == 4 || h->n_auto_aligns == 12 || h->n_auto_aligns % 32 == 0);
   h->streams_this_align = auto_mode && (h->auto_one_stream == h->probing);   // two streams unless AUTO settled on one (probe: the other)
   const int64_t used0 = h->n_prelaunch_used, launches0 = h->tm.n_eval_launches;
   rc = newton_align(h->prm, n_total, guess, fn, out, /*hessian_in_trials=*/true);
