@@ -112,7 +112,7 @@ typedef enum ndt_prelaunch {
                              blocks of the one in flight leave.  Used when the device exposes a large BAR; a kernel
                              that waited 20 ms gives up and the pose is evaluated through an ordinary launch.
                              The two-stream placement is right for a device the engine has to itself; AUTO checks that
-                             by measurement (the 4th, the 12th and then every 32nd align run with the one-stream placement; one that is 15 %
+                             by measurement (the 6th, the 14th and then every 32nd align run with the one-stream placement; one that is 15 %
                              faster per evaluation switches the handle over, and back the same way), so a second
                              engine or process on the same device is noticed without being told. */
   NDT_PRELAUNCH_OFF = 1,

@@ -250,13 +250,13 @@ struct ndt_handle {
   // NDT_PRELAUNCH_AUTO decides between the two-stream and the one-stream placement of the waiting kernel BY MEASUREMENT:
   // a waiting kernel on the other stream holds its compute units for the whole evaluation of its predecessor -- harmless
   // on a device the engine has to itself, ruinous when another engine's kernels need those units (two ranks on one
-  // device: 0.97 against 0.59 ms per step, HISTORY section 5).  The handle keeps a running mean of the wall time per
-  // launched evaluation in the placement in use and runs the 4th, the 12th and then every 32nd align in the other one as a probe; a probe that is
+  // device: 0.97 against 0.59 ms per step, HISTORY section 5).  The handle keeps the best recent wall time per
+  // launched evaluation in the placement in use and runs the 6th, the 14th and then every 32nd align in the other one as a probe; a probe that is
   // 15 % faster switches the handle over (and the probing goes on from there, so it can switch back).
   bool auto_one_stream = false;       // the placement AUTO currently uses
   bool probing = false;               // this align runs in the other placement
   bool streams_this_align = true;     // two-stream placement in effect for the align in flight
-  double us_eval_mean[2] = {0.0, 0.0};  // [0] two streams, [1] one stream; 0 = no sample yet
+  double us_eval_mean[2] = {0.0, 0.0};  // best recent wall time per launched evaluation: [0] two streams, [1] one stream; 0 = no sample yet
   int64_t n_auto_aligns = 0, n_auto_switches = 0;
   DevBuf<unsigned int> arrive_ctr;    // [2] blocks of a pre-launched launch that have started (per result buffer)
   PinBuf<unsigned long long> arrived; // [2] sequence number of the launch whose blocks are all resident
@@ -1910,8 +1910,8 @@ int ndt_align(ndt_handle* h, const float guess[16], ndt_result* out) {
   const int64_t timeouts0 = h->n_prelaunch_timeouts;
   // placement of the waiting kernels for this align (see auto_one_stream)
   const bool auto_mode = h->two_streams && h->prm.prelaunch == NDT_PRELAUNCH_AUTO;
-  ++h->n_auto_aligns;   // (probes: the 4th and 12th align of a handle, so that a shared device is noticed early, then every 32nd)
-  h->probing = auto_mode && auto_probe_enabled() && (h->n_auto_aligns == 4 || h->n_auto_aligns == 12 || h->n_auto_aligns % 32 == 0);
+  ++h->n_auto_aligns;   // (probes: the 6th and 14th align of a handle, so that a shared device is noticed early, then every 32nd)
+  h->probing = auto_mode && auto_probe_enabled() && (h->n_auto_aligns == 6 || h->n_auto_aligns == 14 || h->n_auto_aligns % 32 == 0);
   h->streams_this_align = auto_mode && (h->auto_one_stream == h->probing);   // two streams unless AUTO settled on one (probe: the other)
   const int64_t used0 = h->n_prelaunch_used, launches0 = h->tm.n_eval_launches;
   rc = newton_align(h->prm, n_total, guess, fn, out, /*hessian_in_trials=*/true);
@@ -1921,8 +1921,10 @@ int ndt_align(ndt_handle* h, const float guess[16], ndt_result* out) {
     if (launched >= 8 && h->n_prelaunch_used - used0 >= launched - 2) {   // a pre-launched align of some length
       const int which = h->streams_this_align ? 0 : 1;
       const double us = 1e3 * out->ms_total / (double)launched;
+      // the BEST recent sample of a placement, slowly forgotten (+2 % per align): a host hiccup can only make a
+      // sample slower, so it can neither inflate the figure a probe is compared with nor pass for a fast probe
       double& m = h->us_eval_mean[which];
-      m = m == 0.0 ? us : 0.8 * m + 0.2 * us;
+      m = m == 0.0 ? us : std::min(m * 1.02, us);
       const int cur = h->auto_one_stream ? 1 : 0, other = 1 - cur;
       if (h->probing && h->us_eval_mean[cur] > 0.0 && us < 0.85 * h->us_eval_mean[cur]) {
         h->auto_one_stream = !h->auto_one_stream;
