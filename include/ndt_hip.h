@@ -331,6 +331,14 @@ int ndt_clear_regularization_pose(ndt_handle* h);
  * test_svn_ndt.cpp:171).  Blocks until the result is on the host. */
 int ndt_align(ndt_handle* h, const float guess_colmajor[16], ndt_result* out);
 
+/* pclomp::NdtResult's per-iteration arrays [RECALLED: tier4 ndt_omp's transformation_array,
+ * transform_probability_array, nearest_voxel_transformation_likelihood_array; the reference's drivers read none of them]
+ * of the LAST ndt_align on this handle: entry 0 is the initial guess with the scores of the first evaluation, then one
+ * entry per Newton iteration (the transform after it, the scores of its accepted evaluation).  Any output may be NULL;
+ * at most `cap` entries are written; returns the number of entries available (iterations + 1) or < 0. */
+int ndt_get_iteration_history(const ndt_handle* h, float* transforms16_colmajor, double* transform_probability,
+                              double* nearest_voxel_transformation_likelihood, int cap);
+
 /* Derivatives at K poses in one call (computeDerivatives; and Stage 1 of
  * svn_ndt::align, ref: svn_ndt_impl.hpp:758-781).  poses6: K x 6 doubles.
  * transforms: optional K x 16 floats (column-major) applied to the source;

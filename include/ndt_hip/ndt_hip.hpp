@@ -161,6 +161,10 @@ struct NdtResult {
   float transform_probability = 0.0f;
   float nearest_voxel_transformation_likelihood = 0.0f;
   int iteration_num = 0;
+  // [RECALLED: tier4 ndt_omp] entry 0 = the initial guess, then one entry per iteration (no driver reads them)
+  std::vector<Matrix4f> transformation_array;
+  std::vector<float> transform_probability_array;
+  std::vector<float> nearest_voxel_transformation_likelihood_array;
   Matrix6d hessian{};  // of the maximised score: the drivers form cov = -(hessian + 1e-6 I)^-1
   // that covariance, optionally in the block order the drivers hand to GTSAM
   // (ref: run/pipeline.cpp:594-603, src/registercallback.cpp:170-186); false if singular
@@ -360,6 +364,17 @@ class NormalDistributionsTransform
     r.nearest_voxel_transformation_likelihood = (float)res_.nearest_voxel_transformation_likelihood;
     r.iteration_num = res_.iterations;
     r.hessian = detail::from_rowmajor<Matrix6d>(res_.hessian, 6, 6);
+    const int n = h_ ? ndt_get_iteration_history(h_, nullptr, nullptr, nullptr, 0) : 0;
+    if (n > 0) {
+      std::vector<float> T((size_t)n * 16);
+      std::vector<double> tp((size_t)n), nv((size_t)n);
+      ndt_get_iteration_history(h_, T.data(), tp.data(), nv.data(), n);
+      for (int i = 0; i < n; ++i) {
+        r.transformation_array.push_back(detail::from_colmajor<Matrix4f>(T.data() + 16 * (size_t)i, 4, 4));
+        r.transform_probability_array.push_back((float)tp[(size_t)i]);
+        r.nearest_voxel_transformation_likelihood_array.push_back((float)nv[(size_t)i]);
+      }
+    }
     return r;
   }
 

@@ -149,7 +149,7 @@ ABI_SYMBOLS = [
     "ndt_xy_covariance_multi_ndt_score", "ndt_source_changed", "ndt_comm_rank_count", "ndt_comm_p2p_handle", "ndt_comm_init_p2p",
     "ndt_set_record_format", "ndt_get_record_format",
     "ndt_set_handoff_mode", "ndt_get_handoff_mode", "ndt_wait", "ndt_get_handoff_timing",
-    "ndt_voxel_downsample_device", "ndt_voxel_downsample",
+    "ndt_voxel_downsample_device", "ndt_voxel_downsample", "ndt_get_iteration_history",
 ]
 
 _lib = None
@@ -237,6 +237,7 @@ def lib():
                                                   C.POINTER(C.c_size_t)]
         L.ndt_voxel_downsample.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_long, C.c_float, vp, C.c_size_t,
                                            C.POINTER(C.c_size_t)]
+        L.ndt_get_iteration_history.argtypes = [vp, fp, dp, dp, C.c_int]
         L.ndt_set_handoff_mode.argtypes = [vp, C.c_int]
         L.ndt_get_handoff_mode.argtypes = [vp]
         L.ndt_wait.argtypes = [vp]
@@ -612,6 +613,18 @@ class NormalDistributionsTransform:
         r = dict(self._result)
         r["iteration_num"] = r["iterations"]
         return r
+
+    def getIterationHistory(self):
+        """pclomp::NdtResult's per-iteration arrays [RECALLED] of the last align: (transformation_array [n,4,4],
+        transform_probability_array [n], nearest_voxel_transformation_likelihood_array [n]); entry 0 = the guess."""
+        n = lib().ndt_get_iteration_history(self._h, None, None, None, 0)
+        if n < 0:
+            raise NdtError(n, "ndt_get_iteration_history")
+        T = np.zeros((n, 16), np.float32)
+        tp, nv = np.zeros(n), np.zeros(n)
+        if n:
+            lib().ndt_get_iteration_history(self._h, _fp(T), _dp(tp), _dp(nv), n)
+        return T.reshape(n, 4, 4).transpose(0, 2, 1).astype(np.float64), tp, nv
 
     def evalDerivatives(self, poses6, transforms=None, compute_hessian=True):
         """computeDerivatives at K poses (K x 6); returns a list of dicts."""

@@ -274,6 +274,7 @@ struct ndt_handle {
 
   bool have_reg = false;
   float reg_pose[16];
+  IterHistory history;                // per-iteration transforms / scores of the last ndt_align (ndt_get_iteration_history)
 
   Reducer red;
 
@@ -1914,7 +1915,7 @@ int ndt_align(ndt_handle* h, const float guess[16], ndt_result* out) {
   h->probing = auto_mode && auto_probe_enabled() && (h->n_auto_aligns == 6 || h->n_auto_aligns == 14 || h->n_auto_aligns % 32 == 0);
   h->streams_this_align = auto_mode && (h->auto_one_stream == h->probing);   // two streams unless AUTO settled on one (probe: the other)
   const int64_t used0 = h->n_prelaunch_used, launches0 = h->tm.n_eval_launches;
-  rc = newton_align(h->prm, n_total, guess, fn, out, /*hessian_in_trials=*/true);
+  rc = newton_align(h->prm, n_total, guess, fn, out, /*hessian_in_trials=*/true, &h->history);
   h->prelaunch_armed = false;
   if (auto_mode && rc == NDT_OK && h->n_prelaunch_timeouts == timeouts0) {
     const int64_t launched = h->tm.n_eval_launches - launches0;
@@ -1939,6 +1940,16 @@ int ndt_align(ndt_handle* h, const float guess[16], ndt_result* out) {
   quit_prelaunched(h);  // the kernel enqueued for an evaluation that never came
   out->ms_device = h->tm.ms_eval_kernel_total - dev_ms0;
   return rc;
+}
+
+int ndt_get_iteration_history(const ndt_handle* h, float* transforms16, double* transform_probability, double* nvtl, int cap) {
+  if (!h || cap < 0) return NDT_ERR_INVALID_ARG;
+  const int n = (int)h->history.size();
+  const int m = n < cap ? n : cap;
+  if (transforms16 && m) std::memcpy(transforms16, h->history.transforms.data(), (size_t)m * 16 * sizeof(float));
+  if (transform_probability && m) std::memcpy(transform_probability, h->history.transform_probability.data(), (size_t)m * sizeof(double));
+  if (nvtl && m) std::memcpy(nvtl, h->history.nvtl.data(), (size_t)m * sizeof(double));
+  return n;
 }
 
 int ndt_score_transform(ndt_handle* h, const float T[16], ndt_score* out) {

@@ -430,8 +430,13 @@ class Solver {
 }  // namespace
 
 int newton_align(const ndt_params& prm, int64_t n_source_total, const float guess[16],
-                 const EvalFn& fn, ndt_result* out, bool hessian_in_trials) {
+                 const EvalFn& fn, ndt_result* out, bool hessian_in_trials, IterHistory* history) {
   const auto t0 = std::chrono::steady_clock::now();
+  if (history) history->clear();
+  auto record = [&](const float* T, const Eval& e) {
+    if (history)
+      history->push(T, n_source_total > 0 ? e.score / (double)n_source_total : 0.0, e.n_with > 0 ? e.nvtl_sum / e.n_with : 0.0);
+  };
   std::memset(out, 0, sizeof(*out));
   std::memcpy(out->final_transformation, guess, sizeof(float) * 16);
   Solver sv(prm, fn, hessian_in_trials);
@@ -444,6 +449,7 @@ int newton_align(const ndt_params& prm, int64_t n_source_total, const float gues
   double score = sv.cur_.score, g[6], H[36];
   std::memcpy(g, sv.cur_.g, sizeof(g));
   std::memcpy(H, sv.cur_.H, sizeof(H));
+  record(guess, sv.cur_);
 
   int iters = 0;
   bool converged = false;
@@ -466,6 +472,7 @@ int newton_align(const ndt_params& prm, int64_t n_source_total, const float gues
     std::memcpy(g, sv.cur_.g, sizeof(g));
     for (int i = 0; i < 6; ++i) p[i] += dp[i] * a;
     std::memcpy(out->final_transformation, sv.T_, sizeof(float) * 16);
+    record(sv.T_, sv.cur_);
     const bool stop = iters > prm.max_iterations || (iters && std::fabs(a) < prm.trans_epsilon);
     ++iters;
     if (stop) { converged = true; break; }

@@ -4,6 +4,7 @@
 #pragma once
 
 #include <functional>
+#include <vector>
 
 #include "../../include/ndt_hip.h"
 
@@ -35,11 +36,25 @@ void finish_eval(const ndt_params& prm, const float* reg_pose, const double p[6]
 // fn(pose6, T, need_hessian, out) -> 0 on success
 using EvalFn = std::function<int(const double*, const float*, bool, Eval*)>;
 
+// pclomp::NdtResult's per-iteration arrays [RECALLED: tier4 ndt_omp, absent submodule]: entry 0 is the initial guess
+// (transform only: its score arrays hold the first evaluation), one entry per Newton iteration after it
+struct IterHistory {
+  std::vector<float> transforms;            // 16 floats per entry, column-major
+  std::vector<double> transform_probability, nvtl;
+  void clear() { transforms.clear(); transform_probability.clear(); nvtl.clear(); }
+  void push(const float T[16], double tp, double nv) {
+    transforms.insert(transforms.end(), T, T + 16);
+    transform_probability.push_back(tp);
+    nvtl.push_back(nv);
+  }
+  size_t size() const { return transform_probability.size(); }
+};
+
 // hessian_in_trials: ask for the Hessian in every line-search trial instead of one extra
 // evaluation at the accepted step (same numbers -- the extra evaluation is at the pose of
 // the last trial -- one launch fewer per Newton iteration that needed trials).
 int newton_align(const ndt_params& prm, int64_t n_source_total, const float guess[16],
-                 const EvalFn& fn, ndt_result* out, bool hessian_in_trials = false);
+                 const EvalFn& fn, ndt_result* out, bool hessian_in_trials = false, IterHistory* history = nullptr);
 
 // cov = -(H + eps I)^-1, optionally with the [rotation, translation] block order of a GTSAM
 // Pose3 noise model (ref: run/pipeline.cpp:594-596, src/registercallback.cpp:170-186).

@@ -633,3 +633,26 @@ def test_packed_voxel_records(pkg, O, S):
             x, y = a.evalDerivatives(pg)[0], b.evalDerivatives(pg)[0]
             assert x["n_pairs"] == y["n_pairs"] and y["score"] == pytest.approx(x["score"], rel=1e-6) and y["score"] != x["score"]
             a.close(); b.close()
+
+
+def test_iteration_history_of_an_align(pkg, S):
+    """pclomp::NdtResult's per-iteration arrays [RECALLED: tier4 ndt_omp transformation_array / score arrays]: entry 0 is
+    the initial guess, one entry per Newton iteration after it; the last entry is the result."""
+    cfg = S.config_c2()
+    ndt = _ndt(pkg)
+    ndt.setInputTarget(cfg["target"]); ndt.setInputSource(cfg["source"])
+    T = ndt.align(cfg["guess"])
+    r = ndt.getResult()
+    Ts, tp, nv = ndt.getIterationHistory()
+    assert len(Ts) == r["iterations"] + 1 == len(tp) == len(nv)
+    assert np.array_equal(Ts[0], np.asarray(cfg["guess"], np.float32).astype(np.float64)) and np.array_equal(Ts[-1], T)
+    assert tp[-1] == r["transform_probability"] and nv[-1] == r["nvtl"]
+    # the score climbs from the guess to the optimum, and every entry is the score of the source under ITS transform
+    assert tp[-1] > tp[0] and nv[-1] > nv[0]
+    for k in (0, len(Ts) // 2, len(Ts) - 1):
+        sc = ndt.scoreTransform(Ts[k])
+        assert abs(sc["transform_probability"] - tp[k]) <= 1e-9 * abs(tp[k]) and abs(sc["nvtl"] - nv[k]) <= 1e-9 * abs(nv[k])
+    # a second align replaces the history
+    ndt.setMaximumIterations(2)
+    ndt.align(cfg["guess"])
+    assert len(ndt.getIterationHistory()[1]) == ndt.getFinalNumIteration() + 1 <= 5   # (the loop stops when iters > max: max + 2 iterations)
