@@ -51,6 +51,7 @@ if has soak; then    # determinism soaks of the hand-offs
   timeout -k 10 300 python tools/soak.py 2>&1 | nolog | tail -8 > $OUT/soak.txt
   timeout -k 10 200 python tools/mbox_stress.py 3000 2>&1 | nolog | tail -3 > $OUT/mbox_stress.txt
   timeout -k 10 300 python tools/build_stress.py 150 2>&1 | nolog | tail -3 > $OUT/build_stress.txt
+  timeout -k 10 500 python tools/handoff_stress.py 2000 2>&1 | nolog | tail -3 > $OUT/handoff_stress.txt
 fi
 if has stamps; then  # in-kernel 100 MHz stamps (diagnostic build, removed afterwards)
   make -C slam-sam_amd/csrc VARIANT=stamps -j8 > /dev/null 2>&1
