@@ -354,7 +354,10 @@ int upload_soa(ndt_handle* h, ndt_handle::UploadLane& lane, hipStream_t stream, 
   HIP_TRY(h, dz.ensure(n));
   lane.tm = ndt_handoff_lane_timing{};
   if (n == 0) return NDT_OK;
-  HIP_TRY(h, lane.stage.ensure(StageJob::stage_floats(n)));
+  {  // (grown with slack: a stream of slightly growing clouds must not re-pin its staging buffer scan after scan)
+    const size_t need = StageJob::stage_floats(n);
+    if (need > lane.stage.cap) HIP_TRY(h, lane.stage.ensure(need + need / 8 + 4096));
+  }
   if (!lane.done) {
     HIP_TRY(h, hipEventCreateWithFlags(&lane.done, hipEventDisableTiming));
     HIP_TRY(h, hipEventCreate(&lane.t0));

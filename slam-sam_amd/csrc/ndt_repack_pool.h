@@ -17,6 +17,7 @@
 #include <functional>
 #include <memory>
 #include <mutex>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -82,6 +83,7 @@ struct RepackPool {
     std::lock_guard<std::mutex> lk(m);
     while (th.size() < n) {
       const unsigned long born = gen.load(std::memory_order_relaxed);
+      try {
       th.emplace_back([this, born] {
         unsigned long seen = born;
         for (;;) {
@@ -104,6 +106,9 @@ struct RepackPool {
           }
         }
       });
+      } catch (const std::system_error&) {
+        break;   // no more threads to be had (a process / thread limit): the hand-off goes on with the workers it has
+      }          // -- none at all is fine too, the calling thread repacks every piece itself -- and nothing crosses the C-ABI
     }
   }
   // every worker runs f once (f claims pieces from a shared counter); returns at once.  Must be
