@@ -35,6 +35,7 @@ def test_bench_line_schema():
     assert abs(rb["achieved"] - rb["algorithmic_bytes"] / (rb["ms_device"] * 1e-3) / 1e9) < 1e-6 * rb["achieved"]
     hc = d["host_cloud"]
     assert hc["unit"] == "iterations/s" and 0 < hc["value"] < d["value"] and hc["ms_scan"] > d["ms_per_step"]
+    assert 0 < hc["median"]["ms_scan"] <= hc["median"]["ms_scan_max"] and hc["median"]["ms_set_source"] > 0
     bd = hc["breakdown"]
     assert bd["ms_repack_target"] > 0 and bd["ms_repack_source"] > 0 and bd["ms_align_waited_for_build"] >= 0
     assert bd["ms_transfer_target"] > 0 and bd["pcie_gb_per_s_target"] > 1 and bd["bytes_over_pcie_target"] == 12 * d["config"]["n_target"]
