@@ -301,7 +301,8 @@ int ndt_set_target_from_keyframes(ndt_handle* h, const int64_t* ids, const doubl
                                   int n_keyframes);
 /* setInputSource(archive[id]): the scan that was just archived is also the one to register
  * (ref: run/pipeline.cpp:558 registers pointsBody, :784 archives the same cloud) -- one upload
- * serves both */
+ * serves both.  The source VIEWS the archived scan (no copy): erasing or replacing that keyframe
+ * unsets the source (NDT_ERR_NO_SOURCE until one is set again). */
 int ndt_set_source_from_keyframe(ndt_handle* h, int64_t id);
 
 /* pcl::VoxelGrid downsample on the device (ref: run/pipeline_ins_map_distribution.cpp:324-340: the accumulated map

@@ -219,6 +219,9 @@ struct ndt_handle {
     size_t n = 0;
   };
   std::unordered_map<int64_t, Keyframe> keyframes;
+  // buffers of erased keyframes, reused by the next ndt_keyframe_put (a sliding window erases one keyframe and archives
+  // one per scan: hipMalloc / hipFree of three arrays each cost more than the upload they frame); at most 4 are kept
+  std::vector<Keyframe> keyframe_pool;
 
   // multi-grid target [RECALLED] (tier4 MultiGridNormalDistributionsTransform): the valid leaves of
   // every separately voxelised cloud, on the host (adding a map tile is not a per-scan operation);
@@ -1361,6 +1364,8 @@ int ndt_destroy(ndt_handle* h) {
   h->brows.release(); h->tickets.release(); h->gd.release(); h->gdh.release();
   for (auto& kv : h->keyframes) { kv.second.x.release(); kv.second.y.release(); kv.second.z.release(); }
   h->keyframes.clear();
+  for (auto& kf : h->keyframe_pool) { kf.x.release(); kf.y.release(); kf.z.release(); }
+  h->keyframe_pool.clear();
   h->sx.release(); h->sy.release(); h->sz.release();
   h->ox.release(); h->oy.release(); h->oz.release(); h->skeys.release(); h->skeys2.release();
   h->svals.release(); h->svals2.release(); h->ssort_tmp.release(); h->splan.release();
@@ -1713,8 +1718,24 @@ int ndt_keyframe_put(ndt_handle* h, int64_t id, const float* xyz, size_t n, size
   if (!h || (!xyz && n) || stride_bytes < 12 || stride_bytes % 4) return NDT_ERR_INVALID_ARG;
   int rc = bind_device(h);
   if (rc) return rc;
+  const bool fresh = h->keyframes.find(id) == h->keyframes.end();
   ndt_handle::Keyframe& kf = h->keyframes[id];
-  rc = upload_soa(h, h->lane_t, h->stream, xyz, nullptr, nullptr, nullptr, n, stride_bytes, kf.x, kf.y, kf.z, true);
+  if (fresh) {   // the buffers of an erased keyframe that are large enough, if any (the stream orders their reuse)
+    for (size_t i = 0; i < h->keyframe_pool.size(); ++i)
+      if (h->keyframe_pool[i].x.cap >= n && h->keyframe_pool[i].y.cap >= n && h->keyframe_pool[i].z.cap >= n) {
+        kf = h->keyframe_pool[i];
+        h->keyframe_pool.erase(h->keyframe_pool.begin() + (long)i);
+        break;
+      }
+  }
+  if (kf.x.p && h->vx == kf.x.p) {   // the keyframe being replaced is the viewed source: it has to be set again
+    h->vx = h->vy = h->vz = nullptr;
+    h->n_src = 0;
+  }
+  // like a host hand-off: the caller's cloud is consumed when the call returns, the transfer runs behind it on the
+  // engine's stream, where everything that reads the archive is enqueued too
+  rc = upload_soa(h, h->lane_t, h->stream, xyz, nullptr, nullptr, nullptr, n, stride_bytes, kf.x, kf.y, kf.z,
+                  h->handoff_mode != NDT_HANDOFF_ASYNC);
   if (rc) return rc;
   kf.n = n;
   return NDT_OK;
@@ -1725,7 +1746,9 @@ int ndt_set_source_from_keyframe(ndt_handle* h, int64_t id) {
   auto it = h->keyframes.find(id);
   if (it == h->keyframes.end()) return fail(h, NDT_ERR_INVALID_ARG, "unknown keyframe id");
   const ndt_handle::Keyframe& kf = it->second;
-  return ndt_set_source_device(h, kf.x.p, kf.y.p, kf.z.p, kf.n);
+  // a VIEW of the archived scan, not a copy (it stays the source until the keyframe is erased or replaced, which
+  // unsets it): the archive is the engine's own memory and is written on the stream the evaluations run on
+  return ndt_set_source_device_view(h, kf.x.p, kf.y.p, kf.z.p, kf.n);
 }
 
 int ndt_keyframe_erase(ndt_handle* h, int64_t id) {
@@ -1733,7 +1756,18 @@ int ndt_keyframe_erase(ndt_handle* h, int64_t id) {
   auto it = h->keyframes.find(id);
   if (it == h->keyframes.end()) return NDT_ERR_INVALID_ARG;
   (void)hipSetDevice(h->device);
-  it->second.x.release(); it->second.y.release(); it->second.z.release();
+  if (it->second.x.p && h->vx == it->second.x.p) {   // the viewed source goes with its keyframe
+    h->vx = h->vy = h->vz = nullptr;
+    h->n_src = 0;
+  }
+  if (h->keyframe_pool.size() < 4 && it->second.x.p) {
+    // (whatever still reads these arrays was enqueued on the engine's stream before this call; the next put writes
+    // them on the same stream, behind it)
+    it->second.n = 0;
+    h->keyframe_pool.push_back(it->second);
+  } else {
+    it->second.x.release(); it->second.y.release(); it->second.z.release();
+  }
   h->keyframes.erase(it);
   return NDT_OK;
 }

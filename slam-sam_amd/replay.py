@@ -33,8 +33,8 @@ def run_lidar_odometry(engine, stream, mode="ndt", svn_seed=0, priors=None):
     reference's lo_svn driver passes, run/pipeline_lo_svn.cpp:388); default = constant-velocity
     prediction.  Returns dict(poses, ms, hz, iterations)."""
     poses = [stream[0][1].copy()]
-    ms, iters = [], []
-    t_all = time.perf_counter()
+    ms, iters, ms_engine = [], [], []   # ms_engine: the registration calls alone (set target / source, align), without the
+    t_all = time.perf_counter()         # loop's own NumPy transform of the previous scan (the drivers' pcl::transformPointCloud)
     for k in range(1, len(stream)):
         scan, _ = stream[k]
         prev_scan = stream[k - 1][0]
@@ -47,6 +47,7 @@ def run_lidar_odometry(engine, stream, mode="ndt", svn_seed=0, priors=None):
             guess = poses[k - 1] @ np.linalg.inv(poses[k - 2]) @ poses[k - 1]
         else:
             guess = poses[k - 1].copy()
+        t_e = time.perf_counter()
         if mode == "ndt_keyframes":
             # device-resident variant: every scan crosses PCIe once, as a keyframe;
             # the target is keyframe k-1 moved by its pose ON the device, the source is keyframe k
@@ -61,6 +62,7 @@ def run_lidar_odometry(engine, stream, mode="ndt", svn_seed=0, priors=None):
                 engine.eraseKeyframe(k - 2)
             poses.append(np.asarray(T, dtype=np.float64))
             ms.append(1e3 * (time.perf_counter() - t0))
+            ms_engine.append(1e3 * (time.perf_counter() - t_e))
             continue
         engine.setInputTarget(target)                                # :557
         if mode == "ndt":
@@ -73,8 +75,9 @@ def run_lidar_odometry(engine, stream, mode="ndt", svn_seed=0, priors=None):
             iters.append(r["iterations"])
         poses.append(np.asarray(T, dtype=np.float64))
         ms.append(1e3 * (time.perf_counter() - t0))
+        ms_engine.append(1e3 * (time.perf_counter() - t_e))
     wall = time.perf_counter() - t_all
-    return dict(poses=poses, ms=np.array(ms), hz=(len(stream) - 1) / wall, iterations=iters)
+    return dict(poses=poses, ms=np.array(ms), ms_engine=np.array(ms_engine), hz=(len(stream) - 1) / wall, iterations=iters)
 
 
 def trajectory_errors(poses, stream):

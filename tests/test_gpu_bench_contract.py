@@ -50,6 +50,7 @@ def test_bench_line_schema():
     assert "error" not in c5
     for leg in ("ndt_host_clouds", "ndt_device_keyframes", "svn_k20"):
         assert c5[leg]["hz"] > 0 and c5[leg]["ms_per_frame"] > 0 and "final_error_vs_ground_truth" in c5[leg], leg
+        assert 0 < c5[leg]["ms_engine_per_frame"] <= c5[leg]["ms_per_frame"] and c5[leg]["hz_engine"] >= c5[leg]["hz"] * 0.99, leg
     assert c5["ndt_host_clouds"]["max_error_m"] < 0.05 and c5["ndt_device_keyframes"]["max_error_m"] < 0.05
     st = c5["svn_k20"]["stage1"]
     assert st["poses_per_launch"] == 20 and st["ms_per_launch"] > 0 and 0 < st["frac"] < 1 and st["launches_timed"] >= 1

@@ -53,3 +53,33 @@ def test_sliding_window_target_matches_host_assembly(pkg, O, S):
     assert ndt.keyframeCount() == 5 and ndt.getGridInfo()["n_leaves"] > 100
     with pytest.raises(pkg.NdtError):
         ndt.setInputTargetFromKeyframes([100], [np.eye(4)])        # erased id
+
+
+def test_source_from_keyframe_is_a_view_of_the_archive(pkg, S):
+    """setInputSourceFromKeyframe registers the archived scan in place (no copy): same result as handing the scan over
+    from the host; erasing or replacing that keyframe unsets the source instead of leaving a dangling view."""
+    cfg = S.config_c2()
+    kw = dict(device_id=0, resolution=1.0, step_size=0.1, trans_epsilon=1e-4, max_iterations=35)
+    ref = pkg.NormalDistributionsTransform(**kw)
+    ref.setInputTarget(cfg["target"]); ref.setInputSource(cfg["source"])
+    T0 = ref.align(cfg["guess"]); r0 = ref.getResult()
+    ndt = pkg.NormalDistributionsTransform(**kw)
+    ndt.setInputTarget(cfg["target"])
+    src = cfg["source"].copy()
+    ndt.putKeyframe(7, src); src[:] = np.nan          # (consumed when the call returns)
+    ndt.setInputSourceFromKeyframe(7)
+    for _ in range(2):
+        T = ndt.align(cfg["guess"]); r = ndt.getResult()
+        assert np.array_equal(T, T0) and r["score"] == r0["score"] and np.array_equal(r["hessian"], r0["hessian"])
+    ndt.putKeyframe(8, cfg["source"][::2])              # another keyframe: the view stays
+    assert np.array_equal(ndt.align(cfg["guess"]), T0)
+    ndt.eraseKeyframe(7)
+    with pytest.raises(pkg.NdtError) as ei:
+        ndt.align(cfg["guess"])
+    assert ei.value.code == -5                          # NDT_ERR_NO_SOURCE
+    ndt.putKeyframe(9, cfg["source"]); ndt.setInputSourceFromKeyframe(9)
+    assert np.array_equal(ndt.align(cfg["guess"]), T0)
+    ndt.putKeyframe(9, cfg["source"][::3])              # replaced under the view: unset, not stale
+    with pytest.raises(pkg.NdtError) as ei:
+        ndt.align(cfg["guess"])
+    assert ei.value.code == -5
