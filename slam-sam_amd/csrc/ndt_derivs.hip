@@ -533,13 +533,18 @@ __device__ __forceinline__ void point_pairs_kd(PairAcc& a, float x, float y, flo
     // cell, nine cells in flight at a time): a point has 9-11 occupied cells around it but only 3-4
     // centroids within one leaf size, and the wave runs max-over-lanes(listed) full pair updates --
     // 7 instead of 15 on C3.  Same f32 test on the same operands, same (cell) order: the same pairs.
+#ifndef NDT_KD_BATCH
+#define NDT_KD_BATCH 9   // centroids in flight per lane (A/B: 14 = two round trips instead of three)
+#endif
+    constexpr int KB = NDT_KD_BATCH;
 #pragma unroll
-    for (int n0 = 0; n0 < KD_CELLS; n0 += 9) {
-      float4 m[9];   // the f32 centroids (one 16-byte load per cell; two loads of the record's f64 mean before round 3)
+    for (int n0 = 0; n0 < KD_CELLS; n0 += KB) {
+      float4 m[KB];   // the f32 centroids (one 16-byte load per cell; two loads of the record's f64 mean before round 3)
 #pragma unroll
-      for (int q = 0; q < 9; ++q) m[q] = cent[slot[n0 + q] >= 0 ? slot[n0 + q] : 0];
+      for (int q = 0; q < KB; ++q) m[q] = cent[(n0 + q < KD_CELLS && slot[n0 + q < KD_CELLS ? n0 + q : 0] >= 0) ? slot[n0 + q < KD_CELLS ? n0 + q : 0] : 0];
 #pragma unroll
-      for (int q = 0; q < 9; ++q) {
+      for (int q = 0; q < KB; ++q) {
+        if (n0 + q >= KD_CELLS) break;
         const float ex = xt - m[q].x, ey = yt - m[q].y, ez = zt - m[q].z;
         float d = ex * ex;
         d = d + ey * ey;
