@@ -473,23 +473,6 @@ __device__ __forceinline__ void point_pairs_kd(PairAcc& a, float x, float y, flo
   // ints beyond either end (IndexGrid, ndt_api.hip) and those lanes are masked.  Cell n = (dx+1) + 3 (dy+1) + 9 (dz+1),
   // as before: the listing order, hence the summation order, is unchanged.
   int slot[KD_CELLS];
-#ifdef NDT_KD_ROWS_OLD
-  {
-    const bool xin0 = i0 - 1 >= 0 && i0 - 1 < g.div_b[0], xin1 = i0 >= 0 && i0 < g.div_b[0], xin2 = i0 + 1 >= 0 && i0 + 1 < g.div_b[0];
-    const bool xany = xin0 || xin1 || xin2;
-    struct alignas(4) Int3 { int a, b, c; };
-#pragma unroll
-    for (int r = 0; r < 9; ++r) {
-      const int c1 = i1 + (r % 3) - 1, c2 = i2 + (r / 3) - 1;
-      const bool rowok = xany && c1 >= 0 && c1 < g.div_b[1] && c2 >= 0 && c2 < g.div_b[2];
-      const int base = rowok ? (i0 - 1) + c1 * g.mul1 + c2 * g.mul2 : 0;
-      const Int3 v = *reinterpret_cast<const Int3*>(cell2leaf + base);
-      slot[3 * r + 0] = (rowok && xin0) ? v.a : -1;
-      slot[3 * r + 1] = (rowok && xin1) ? v.b : -1;
-      slot[3 * r + 2] = (rowok && xin2) ? v.c : -1;
-    }
-  }
-#else
   {
     // (unsigned compares: one instruction per range test; bitwise `&` on the flags: the short-circuit form compiles to an
     // exec-mask split per row; the row offsets differ by +-mul1 / +-mul2 from ONE base: two integer multiplies, not 18)
@@ -510,76 +493,6 @@ __device__ __forceinline__ void point_pairs_kd(PairAcc& a, float x, float y, flo
       slot[3 * r + 2] = (rowok & xin2) ? v.c : -1;
     }
   }
-#endif
-#ifdef NDT_KD_MASK
-  if (!CHAIN) {
-    // Round 4: the neighbours of a lane as a 27-bit MASK (bit n = cell n is a neighbour) instead of a compacted list.
-    // The 27 slots go to the lane's own LDS row as they are (seven wide stores at fixed offsets, stride 27 words: odd,
-    // conflict-free), the mask is built without a branch (compare -> select -> or), and a trip takes the lowest set bit
-    // (v_ffbl), reads that one slot and clears the bit: ascending cell order, as the list had it -- the same pairs in the
-    // same order, the same bits.  The wave leaves when no lane has a bit left (one ballot per trip; the six-step
-    // max-over-lanes of the list form is gone).  Before: ~30 instructions and two exec-mask splits per cell to list it.
-    int* row = lds_list + (int)threadIdx.x * KD_CELLS;
-#pragma unroll
-    for (int n = 0; n < KD_CELLS; ++n) row[n] = slot[n];
-    unsigned int mask = 0u;
-    if (RADIUS) {
-#ifndef NDT_KD_BATCH
-#define NDT_KD_BATCH 9   // centroids in flight per lane (14 or 27: no difference, profiles/r04_kd_batch_ab.txt)
-#endif
-      constexpr int KB = NDT_KD_BATCH;
-#pragma unroll
-      for (int n0 = 0; n0 < KD_CELLS; n0 += KB) {
-        float4 m[KB];   // the f32 centroids, one 16-byte load per cell; an absent cell reads centroid 0 and is masked
-#pragma unroll
-        for (int q = 0; q < KB; ++q) {
-          const int nn = n0 + q < KD_CELLS ? n0 + q : 0;
-          m[q] = cent[slot[nn] >= 0 ? slot[nn] : 0];
-        }
-#pragma unroll
-        for (int q = 0; q < KB; ++q) {
-          if (n0 + q >= KD_CELLS) break;
-          const float ex = xt - m[q].x, ey = yt - m[q].y, ez = zt - m[q].z;
-          float d = ex * ex;
-          d = d + ey * ey;
-          d = d + ez * ez;
-          // (bitwise, not `&&`: a short circuit turns every cell into a branch around its distance arithmetic)
-          mask |= ((unsigned int)(slot[n0 + q] >= 0) & (unsigned int)(d < ec.kd_radius2)) << (n0 + q);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int n = 0; n < KD_CELLS; ++n) mask |= (unsigned int)(slot[n] >= 0) << n;
-    }
-    // (the lanes of a wave read only their own row, written by themselves: no barrier)
-#ifdef NDT_KD_PIPE   // A/B: the record of trip j + 1 requested before trip j is worked on
-    bool have = mask != 0u;
-    int sl = have ? row[have ? __builtin_ctz(mask) : 0] : 0;
-    mask &= mask - 1u;
-    VoxelRecord rn = rec[sl];
-    while (__ballot(have) != 0ull) {
-      const VoxelRecord r = rn;
-      const bool hv = have;
-      have = mask != 0u;
-      sl = have ? row[have ? __builtin_ctz(mask) : 0] : 0;
-      mask &= mask - 1u;
-      rn = rec[sl];
-      __builtin_amdgcn_sched_barrier(0);
-      pair_update<MODE>(a, r, xt, yt, zt, ec, hv);
-    }
-#else
-    while (__ballot(mask != 0u) != 0ull) {
-      const bool have = mask != 0u;
-      const int b = have ? __builtin_ctz(mask) : 0;
-      mask &= mask - 1u;
-      const int sl = have ? row[b] : 0;
-      const VoxelRecord r = rec[sl];
-      pair_update<MODE>(a, r, xt, yt, zt, ec, have);
-    }
-#endif
-    return;
-  }
-#endif
   // column `threadIdx.x` of lds_list[KD_CELLS][blockDim.x]: conflict-free for a wave
   const int stride = (int)blockDim.x;
   int count = 0;
@@ -641,16 +554,17 @@ __device__ __forceinline__ void point_pairs_kd(PairAcc& a, float x, float y, flo
         float d = ex * ex;
         d = d + ey * ey;
         d = d + ez * ez;
-        if (slot[n0 + q] >= 0 && d < ec.kd_radius2) {
-          lds_list[count * stride + (int)threadIdx.x] = slot[n0 + q];
-          ++count;
-        }
+        // (no branch: the slot is stored at position `count` whether it is a neighbour or not -- the next cell overwrites
+        // a position that was not taken, and positions >= count are never read; KDTREE -0.2 ... -0.5 us per launch)
+        const int in = (int)((unsigned int)(slot[n0 + q] >= 0) & (unsigned int)(d < ec.kd_radius2));
+        lds_list[count * stride + (int)threadIdx.x] = slot[n0 + q];
+        count += in;
       }
     }
   } else {
 #pragma unroll
     for (int n = 0; n < KD_CELLS; ++n) {
-      if (slot[n] >= 0) {
+      if (slot[n] >= 0) {   // (DIRECT26 keeps the branch: 27 unconditional stores cost it 0.5 us, profiles/r04_kd_mask_ab.txt)
         lds_list[count * stride + (int)threadIdx.x] = slot[n];
         ++count;
       }
