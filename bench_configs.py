@@ -29,7 +29,7 @@ def c2_block(pkg, hip, steps=20, warmup=5):
 
     def step():
         t0 = time.perf_counter()
-        ndt.setInputTargetDevice(tptr[0], tptr[1], tptr[2], n_t)
+        ndt.setInputTargetDeviceDeferred(tptr[0], tptr[1], tptr[2], n_t)   # (enqueued; finished inside the step, as bench.py's)
         t1 = time.perf_counter()
         ndt.setInputSourceDeviceView(sptr[0], sptr[1], sptr[2], n_s)
         ndt.align(guess, return_transform=False)

@@ -246,6 +246,13 @@ int ndt_set_target(ndt_handle* h, const float* xyz, size_t n, size_t stride_byte
 int ndt_set_target_soa(ndt_handle* h, const float* x, const float* y, const float* z, size_t n);
 /* SoA arrays already resident in device memory (consumed during the call) */
 int ndt_set_target_device(ndt_handle* h, const float* dx, const float* dy, const float* dz, size_t n);
+/* As ndt_set_target_device, but under NDT_HANDOFF_ASYNC a steady-state build is only ENQUEUED on the engine's stream:
+ * the arrays must stay valid and unchanged until the first call that needs the grid (ndt_align, ndt_get_grid_info,
+ * ndt_wait, ...) has returned, and a failed build is reported by that call.  What it buys: the align that follows
+ * enqueues its first derivative evaluation BEHIND the build while it still runs (the kernel reads the grid geometry
+ * from device memory), so the launch is not paid after the build's verdict -- as for every deferred build: host
+ * clouds under NDT_HANDOFF_ASYNC, ndt_set_target_from_keyframes. */
+int ndt_set_target_device_deferred(ndt_handle* h, const float* dx, const float* dy, const float* dz, size_t n);
 /* setInputSource (ref: run/pipeline.cpp:558) */
 int ndt_set_source(ndt_handle* h, const float* xyz, size_t n, size_t stride_bytes);
 int ndt_set_source_soa(ndt_handle* h, const float* x, const float* y, const float* z, size_t n);

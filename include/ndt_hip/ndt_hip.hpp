@@ -432,8 +432,11 @@ class NormalDistributionsTransform
   // ---- clouds that are already in HBM (SoA float arrays on this engine's device) ----
   // the target arrays are consumed by the build; the source arrays are viewed in place until the source
   // is replaced (setInputSource's shared_ptr contract) -- or copied with copy = true
-  void setInputTargetDevice(const float* dx, const float* dy, const float* dz, size_t n) {
-    status_ = h_ ? ndt_set_target_device(h_, dx, dy, dz, n) : NDT_ERR_NO_DEVICE;
+  // (deferred = true: the build is only enqueued -- the arrays must stay unchanged until align() / wait() has returned --
+  // and the align's first evaluation goes onto the stream behind it: ndt_set_target_device_deferred)
+  void setInputTargetDevice(const float* dx, const float* dy, const float* dz, size_t n, bool deferred = false) {
+    if (!h_) { status_ = NDT_ERR_NO_DEVICE; return; }
+    status_ = deferred ? ndt_set_target_device_deferred(h_, dx, dy, dz, n) : ndt_set_target_device(h_, dx, dy, dz, n);
   }
   void setInputSourceDevice(const float* dx, const float* dy, const float* dz, size_t n, bool copy = false) {
     if (!h_) { status_ = NDT_ERR_NO_DEVICE; return; }

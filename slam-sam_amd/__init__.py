@@ -134,7 +134,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
 ABI_SYMBOLS = [
     "ndt_abi_version", "ndt_default_params", "ndt_create", "ndt_destroy", "ndt_set_params",
     "ndt_get_params", "ndt_last_error", "ndt_backend_info", "ndt_set_target", "ndt_set_target_soa",
-    "ndt_set_target_device", "ndt_set_source", "ndt_set_source_soa", "ndt_set_source_device", "ndt_set_source_device_view",
+    "ndt_set_target_device", "ndt_set_target_device_deferred", "ndt_set_source", "ndt_set_source_soa", "ndt_set_source_device", "ndt_set_source_device_view",
     "ndt_set_regularization_pose", "ndt_clear_regularization_pose", "ndt_align",
     "ndt_eval_derivatives", "ndt_unpack_eval", "ndt_transform_source", "ndt_get_grid_info",
     "ndt_export_leaves", "ndt_newton_align", "ndt_shard_range", "ndt_comm_unique_id",
@@ -176,6 +176,7 @@ def lib():
         L.ndt_set_target.argtypes = [vp, vp, C.c_size_t, C.c_size_t]
         L.ndt_set_target_soa.argtypes = [vp, vp, vp, vp, C.c_size_t]
         L.ndt_set_target_device.argtypes = [vp, vp, vp, vp, C.c_size_t]
+        L.ndt_set_target_device_deferred.argtypes = [vp, vp, vp, vp, C.c_size_t]
         L.ndt_set_source.argtypes = [vp, vp, C.c_size_t, C.c_size_t]
         L.ndt_set_source_soa.argtypes = [vp, vp, vp, vp, C.c_size_t]
         L.ndt_set_source_device.argtypes = [vp, vp, vp, vp, C.c_size_t]
@@ -244,6 +245,8 @@ def lib():
         L.ndt_get_handoff_timing.argtypes = [vp, C.POINTER(HandoffTiming)]
         L.ndt_debug_prelaunch_counters.argtypes = [vp, C.POINTER(C.c_int64)]  # test seam, not in the header
         L.ndt_debug_build_counters.argtypes = [vp, C.POINTER(C.c_int64)]  # test seam, not in the header
+        L.ndt_debug_speculation_counters.argtypes = [vp, C.POINTER(C.c_int64)]  # test seam, not in the header
+        L.ndt_debug_set_speculation.argtypes = [vp, C.c_int]  # tuning aid, not in the header
         L.ndt_debug_sort_pairs.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, vp]  # test seam, not in the header
         _lib = L
     return _lib
@@ -419,6 +422,12 @@ class NormalDistributionsTransform:
     def setInputTargetDevice(self, dx, dy, dz, n):
         """dx/dy/dz: integer device addresses of SoA float32 arrays already in HBM."""
         self._check(lib().ndt_set_target_device(self._h, dx, dy, dz, n))
+
+    def setInputTargetDeviceDeferred(self, dx, dy, dz, n):
+        """As setInputTargetDevice, but the voxel-grid build is only ENQUEUED (a steady-state build under the
+        asynchronous hand-off): the arrays must stay valid and unchanged until the first call that needs the grid --
+        align(), getGridInfo(), wait() ... -- has returned; a failed build is reported by that call."""
+        self._check(lib().ndt_set_target_device_deferred(self._h, dx, dy, dz, n))
 
     def setInputSourceDevice(self, dx, dy, dz, n):
         self._check(lib().ndt_set_source_device(self._h, dx, dy, dz, n))
@@ -725,6 +734,16 @@ class NormalDistributionsTransform:
         out = (C.c_int64 * 8)()
         self._check(lib().ndt_debug_prelaunch_counters(self._h, out))
         return int(out[6]), int(out[7])
+
+    def speculationCounters(self):
+        """First evaluations of an align enqueued behind a build still in flight: (kept, discarded)."""
+        out = (C.c_int64 * 2)()
+        self._check(lib().ndt_debug_speculation_counters(self._h, out))
+        return int(out[0]), int(out[1])
+
+    def setSpeculation(self, on):
+        """Tuning aid: the first-evaluation-behind-the-build short cut on / off for this handle."""
+        self._check(lib().ndt_debug_set_speculation(self._h, 1 if on else 0))
 
     def lostRowRetries(self):
         """Evaluations repeated through the ticketed final sum after the summing block had given up waiting for a row."""

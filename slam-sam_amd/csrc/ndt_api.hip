@@ -272,6 +272,13 @@ struct ndt_handle {
   bool pre_need_h = false;
   int64_t n_prelaunch_used = 0, n_prelaunch_quit = 0, n_prelaunch_timeouts = 0;
   int64_t n_lost_row_retries = 0;      // evaluations repeated through the ticketed final sum after a row was lost
+  // The first evaluation of an align that follows a DEFERRED build is enqueued behind that build, before its verdict is
+  // known (evaluate()): spec_first is set by ndt_align for its first evaluate() call.
+  bool spec_first = false;
+  bool spec_enabled = true;            // (ndt_debug_set_speculation: in-process A/B)
+  int prev_n_valid = 0;                // valid voxels of the grid the build in flight replaces
+  bool spec_build_failed = false;      // the deferred build's failure surfaced inside that first evaluation
+  int64_t n_spec_used = 0, n_spec_discarded = 0;
   int64_t n_p2p_host_finishes = 0;     // peer-write evaluations whose exchange the host finished (a peer was late)
   int64_t n_prelaunch_overlapped = 0; // pre-launches that went to the other stream (resident before their predecessor ended)
 
@@ -459,6 +466,7 @@ int neutral_bounds(ndt_handle* h) {
 
 // everything of a build that does not depend on the attempt: state reset, allocations, constants
 int build_begin(ndt_handle* h, const float* x, const float* y, const float* z, size_t n, ndt_handle::BuildRun& br) {
+  h->prev_n_valid = h->have_grid && !h->multi_active ? h->n_valid : 0;   // (first_eval_behind_build's size guess)
   h->have_grid = false;
   h->multi_active = false;
   h->src_sorted = false;
@@ -880,6 +888,30 @@ int maybe_sort_source(ndt_handle* h, const float T[16]) {
   return NDT_OK;
 }
 
+// would maybe_sort_source() sort this source for a grid of n_valid leaves?
+static bool source_sort_wanted(const ndt_handle* h, int n_valid) {
+  if (h->src_sorted || h->n_src == 0) return false;
+  const int mode = h->prm.source_order;
+  if (mode == NDT_SOURCE_ORDER_KEEP) return false;
+  if (mode == NDT_SOURCE_ORDER_AUTO && ((size_t)n_valid * sizeof(VoxelRecord) <= (size_t)6 << 20 || h->n_src < 32768)) return false;
+  return true;
+}
+
+// An align whose target's build is still in flight (asynchronous hand-off, keyframe assembly, ndt_set_target_device_deferred)
+// enqueues its first evaluation BEHIND that build instead of first waiting for the verdict and then paying a launch: the
+// kernel takes the grid geometry from the build's device-side BuildGeom (launch_derivatives, d_geom) and leaves at once
+// after a refused build.  The launch call and the dispatch run under the build (the first evaluation of an align cost 26 us
+// against 16 for the later ones, tools/first_eval_cost.py).  Only where nothing else depends on the verdict: results
+// polled from pinned slots, f64 records, no cross-rank exchange inside the kernel, a source that needs no re-ordering
+// for a grid of the size of the previous one (checked again once the verdict is in: a mismatch discards the launch).
+// NDT_SPECULATE_FIRST=0 in the environment: off.
+static bool first_eval_behind_build(const ndt_handle* h) {
+  static const bool off = [] { const char* e = getenv("NDT_SPECULATE_FIRST"); return e && atoi(e) == 0; }();
+  return !off && h->spec_enabled && h->build_pending && h->prev_n_valid > 0 && h->n_src > 0 && !h->timing &&
+         h->prm.wait_mode == NDT_WAIT_SPIN && !h->red.wants_device_buffer() && h->red.mode() != NDT_REDUCE_P2P &&
+         h->record_format != NDT_RECORDS_PACKED48 && !source_sort_wanted(h, h->prev_n_valid);
+}
+
 // Launch sequence numbers tag every partial / result slot the derivative kernel writes; they
 // must never repeat within the process (a freed partials buffer of one handle can become
 // another's), hence one counter for all handles, starting at 1 (zeroed memory never matches).
@@ -997,6 +1029,20 @@ void quit_prelaunched(ndt_handle* h) {
 int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, Eval* out, bool score_only = false,
              bool safe_retry = false) {
   hipStream_t s = h->stream;
+  bool speculate = false;
+  if (h->spec_first) {   // ndt_align left the pending build's verdict to this call
+    h->spec_first = false;
+    speculate = first_eval_behind_build(h) && !score_only && !safe_retry && h->pre_seq == 0;
+    if (!speculate) {
+      int rc = ready_for_eval(h);
+      if (rc) { h->spec_build_failed = true; return rc; }
+      rc = maybe_sort_source(h, T);
+      if (rc) return rc;
+    } else {
+      int rc = settle_source(h);   // the engine's streams ordered behind the source's transfer
+      if (rc) return rc;
+    }
+  }
   PoseConsts pc;
   fill_pose_consts(p, T, &pc);
   EvalConsts ec = make_eval_consts(h, need_h);
@@ -1086,9 +1132,28 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
     launch_derivatives(px, py, pz, h->n_src, h->geom, h->cell2leaf.p, records, h->cent.p, pc, nullptr, 1, ec, h->partials.p,
                        h->counters.p, d_out, s, spin ? h->flag.d + (size_t)buf * 2 * EV_WORDS : nullptr, seq, nullptr,
                        xinfo, xround, nullptr, nullptr, h->timing && !bracket ? h->ev0 : nullptr,
-                       h->timing && !bracket ? h->ev1 : nullptr);
+                       h->timing && !bracket ? h->ev1 : nullptr, speculate ? h->gd.p : nullptr);
     HIP_TRY(h, hipGetLastError());
     if (bracket) HIP_TRY(h, hipEventRecord(h->ev1, s));
+  }
+  if (speculate) {
+    // the launch is on the stream behind the build; NOW the verdict (the host had nothing else to do meanwhile)
+    const int rs = settle(h);
+    const bool keep = rs == NDT_OK && h->have_grid && h->n_valid > 0 && h->brun.attempt == 0 && !source_sort_wanted(h, h->n_valid);
+    if (!keep) {
+      // refused or repeated build (the kernel left at once, or evaluated a grid that has been rebuilt since), no valid
+      // voxel, or a grid for which the source is to be re-ordered: the launch is drained and forgotten
+      ++h->n_spec_discarded;
+      HIP_TRY(h, hipStreamSynchronize(s));
+      h->counters_zeroed = 0;
+      if (rs) { h->spec_build_failed = true; return rs; }
+      int rc = ready_for_eval(h);
+      if (rc) { h->spec_build_failed = true; return rc; }
+      rc = maybe_sort_source(h, T);
+      if (rc) return rc;
+      return evaluate(h, p, T, need_h, out, score_only);
+    }
+    ++h->n_spec_used;
   }
   if (p2p) h->red.p2p_set_round(xround);  // this evaluation's tag is spent (a fallback below gives it back)
   if (prelaunch) {
@@ -1460,6 +1525,16 @@ int ndt_set_target_device(ndt_handle* h, const float* dx, const float* dy, const
   settle_discard(h);
   h->tx.release(); h->ty.release(); h->tz.release();
   return build_grid(h, dx, dy, dz, n);
+}
+
+int ndt_set_target_device_deferred(ndt_handle* h, const float* dx, const float* dy, const float* dz, size_t n) {
+  if (!h || ((!dx || !dy || !dz) && n)) return NDT_ERR_INVALID_ARG;
+  int rc = bind_device(h);
+  if (rc) return rc;
+  settle_discard(h);
+  h->tx.release(); h->ty.release(); h->tz.release();
+  // (a first build, or one that has to wait for the geometry anyway, completes inside the call: build_grid)
+  return build_grid(h, dx, dy, dz, n, h->handoff_mode == NDT_HANDOFF_ASYNC);
 }
 
 int ndt_set_source(ndt_handle* h, const float* xyz, size_t n, size_t stride_bytes) {
@@ -1932,15 +2007,19 @@ int ndt_align(ndt_handle* h, const float guess[16], ndt_result* out) {
   if (!h || !guess || !out) return NDT_ERR_INVALID_ARG;
   int rc = bind_device(h);
   if (rc) return rc;
-  rc = ready_for_eval(h);
-  if (rc) {
-    // the reference returns the prior with converged = false (ref: svn_ndt_impl.hpp:682-702)
-    std::memset(out, 0, sizeof(*out));
-    std::memcpy(out->final_transformation, guess, sizeof(float) * 16);
-    return rc;
+  h->spec_build_failed = false;
+  h->spec_first = first_eval_behind_build(h);   // the build's verdict is then collected inside the first evaluation
+  if (!h->spec_first) {
+    rc = ready_for_eval(h);
+    if (rc) {
+      // the reference returns the prior with converged = false (ref: svn_ndt_impl.hpp:682-702)
+      std::memset(out, 0, sizeof(*out));
+      std::memcpy(out->final_transformation, guess, sizeof(float) * 16);
+      return rc;
+    }
+    rc = maybe_sort_source(h, guess);
+    if (rc) return rc;
   }
-  rc = maybe_sort_source(h, guess);
-  if (rc) return rc;
   const double dev_ms0 = h->tm.ms_eval_kernel_total;
   EvalFn fn = [h](const double* p, const float* T, bool need_h, Eval* e) { return evaluate(h, p, T, need_h, e); };
   const int64_t n_total = h->n_src_global >= 0 ? h->n_src_global : (int64_t)h->n_src;
@@ -1954,6 +2033,18 @@ int ndt_align(ndt_handle* h, const float guess[16], ndt_result* out) {
   const int64_t used0 = h->n_prelaunch_used, launches0 = h->tm.n_eval_launches;
   rc = newton_align(h->prm, n_total, guess, fn, out, /*hessian_in_trials=*/true, &h->history);
   h->prelaunch_armed = false;
+  if (h->spec_first) {   // (no evaluation was asked for: the pending build is still to be collected)
+    h->spec_first = false;
+    const int rs = ready_for_eval(h);
+    if (rs) { h->spec_build_failed = true; rc = rs; }
+  }
+  if (h->spec_build_failed) {   // as when the build's failure is found before the loop (above)
+    h->spec_build_failed = false;
+    quit_prelaunched(h);
+    std::memset(out, 0, sizeof(*out));
+    std::memcpy(out->final_transformation, guess, sizeof(float) * 16);
+    return rc;
+  }
   if (auto_mode && rc == NDT_OK && h->n_prelaunch_timeouts == timeouts0) {
     const int64_t launched = h->tm.n_eval_launches - launches0;
     if (launched >= 8 && h->n_prelaunch_used - used0 >= launched - 2) {   // a pre-launched align of some length
@@ -2347,6 +2438,21 @@ int ndt_debug_prelaunch_counters(const ndt_handle* h, int64_t out[8]) {
   out[5] = h->n_lost_row_retries;
   out[6] = h->auto_one_stream ? 1 : 0;   // the stream placement NDT_PRELAUNCH_AUTO has settled on (1: one stream)
   out[7] = h->n_auto_switches;
+  return NDT_OK;
+}
+
+// tuning aid (not in the public header): the first-evaluation short cut on / off per handle
+int ndt_debug_set_speculation(ndt_handle* h, int on) {
+  if (!h) return NDT_ERR_INVALID_ARG;
+  h->spec_enabled = on != 0;
+  return NDT_OK;
+}
+
+// test seam (not in the public header): first evaluations enqueued behind a deferred build {kept, discarded}
+int ndt_debug_speculation_counters(const ndt_handle* h, int64_t out[2]) {
+  if (!h || !out) return NDT_ERR_INVALID_ARG;
+  out[0] = h->n_spec_used;
+  out[1] = h->n_spec_discarded;
   return NDT_OK;
 }
 

@@ -936,6 +936,7 @@ struct DerivKernArgs {
   unsigned long long xround;
   unsigned int* arrive_ctr;
   unsigned long long* arrived_host;
+  const BuildGeom* geom_dev;
 };
 constexpr unsigned int KERNARG_TABLES_OFFSET = offsetof(DerivKernArgs, pose) + offsetof(PoseConsts, jang);
 static_assert(offsetof(PoseConsts, hang) == offsetof(PoseConsts, jang) + 24 * sizeof(float) &&
@@ -948,12 +949,22 @@ static_assert(offsetof(PoseConsts, hang) == offsetof(PoseConsts, jang) + 24 * si
 template <bool BATCH, int MODE, int NB, bool MBOX>
 __global__ void __launch_bounds__(MAX_BLOCK)
 k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, int n,
-              GridGeom g, const int* __restrict__ cell2leaf, const VoxelRecord* __restrict__ rec,
+              GridGeom g_arg, const int* __restrict__ cell2leaf, const VoxelRecord* __restrict__ rec,
               const float4* __restrict__ cent, PoseConsts pose_arg, const PoseConsts* __restrict__ poses, EvalConsts ec,
               double* __restrict__ partials, unsigned int* __restrict__ counters, double* __restrict__ out,
               unsigned long long* flag, unsigned long long seq, const PoseMailbox* mbox,
               const XchgInfo* __restrict__ xinfo, unsigned long long xround,
-              unsigned int* __restrict__ arrive_ctr, unsigned long long* arrived_host) {
+              unsigned int* __restrict__ arrive_ctr, unsigned long long* arrived_host,
+              const BuildGeom* __restrict__ geom_dev) {
+  // geom_dev != nullptr: the launch was enqueued BEHIND the voxel-grid build that produces its grid, before the host
+  // knew the geometry (ndt_api.hip, evaluate(): the first evaluation of an align that follows a deferred build).  The
+  // build's last block has left the geometry and its verdict in device memory; after a refused build every block leaves
+  // at once -- nobody waits for anybody, the host repeats the evaluation the ordinary way.
+  GridGeom g = g_arg;
+  if (!BATCH && !MBOX && geom_dev != nullptr) {   // uniform
+    if (geom_dev->status != BG_OK) return;
+    g = geom_dev->g;
+  }
   // R|t (12 dwords) stay in scalar registers; the 69 angle-table words are only needed
   // after the pair loop, so they are parked in LDS (81 live SGPRs would spill) and the
   // barrier that publishes them sits behind the memory-latency part of the kernel.
@@ -1268,7 +1279,7 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
                         double* d_out, hipStream_t s, unsigned long long* d_flag,
                         unsigned long long seq, const PoseMailbox* d_mbox, const XchgInfo* d_xinfo,
                         unsigned long long xround, unsigned int* d_arrive_ctr, unsigned long long* d_arrived_host,
-                        hipEvent_t ev_start, hipEvent_t ev_stop) {
+                        hipEvent_t ev_start, hipEvent_t ev_stop, const BuildGeom* d_geom) {
   const int cus = cus_or_default(ec.compute_units);
   int blocks = derivs_grid_blocks(n_src, d_poses ? K : 1, cus);
   const int threads = derivs_block_threads(n_src, d_poses ? K : 1, cus);
@@ -1318,11 +1329,11 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
     if (ev_start != nullptr)                                                                                 \
       hipExtLaunchKernelGGL((k_derivatives<B, M, NBH, MB>), dim3(blocks, GY), dim3(threads), (std::uint32_t)dyn_lds, s, ev_start, ev_stop, 0u, sx, sy, sz,  \
                             (int)n_src, g, cell2leaf, rec, reinterpret_cast<const float4*>(cent4), pose, d_poses, ecl, d_partials, d_counters, d_out,         \
-                            FLAG, SEQ, d_mbox, d_xinfo, xround, d_arrive_ctr, d_arrived_host);                \
+                            FLAG, SEQ, d_mbox, d_xinfo, xround, d_arrive_ctr, d_arrived_host, d_geom);        \
     else                                                                                                     \
       hipLaunchKernelGGL((k_derivatives<B, M, NBH, MB>), dim3(blocks, GY), dim3(threads), dyn_lds, s, sx, sy, sz,  \
                          (int)n_src, g, cell2leaf, rec, reinterpret_cast<const float4*>(cent4), pose, d_poses, ecl, d_partials, d_counters, d_out,         \
-                         FLAG, SEQ, d_mbox, d_xinfo, xround, d_arrive_ctr, d_arrived_host);                   \
+                         FLAG, SEQ, d_mbox, d_xinfo, xround, d_arrive_ctr, d_arrived_host, d_geom);           \
   } while (0)
 #define NDT_LAUNCH(B, M, NBH, GY, FLAG, SEQ)                                  \
   do {                                                                         \

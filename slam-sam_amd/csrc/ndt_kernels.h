@@ -156,7 +156,10 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
                         unsigned int* d_arrive_ctr = nullptr, unsigned long long* d_arrived_host = nullptr,
                         // kernel timing: events attached to the dispatch itself (begin / end of the kernel, as rocprofv3
                         // reports it); both or neither
-                        hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                        hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
+                        // single-pose ordinary launches enqueued behind the build of their own grid: the geometry is read
+                        // from the build's device-side BuildGeom (and nothing runs after a refused build), `g` is ignored
+                        const BuildGeom* d_geom = nullptr);
 
 // The 80-byte records of leaf slots [0, n) as 48-byte PackedRecords (f64 mean, f32 inverse covariance); a launch
 // whose EvalConsts::packed is set takes that array in place of `rec`.

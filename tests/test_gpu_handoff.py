@@ -245,3 +245,72 @@ def test_random_api_sequences_async_equals_sync(pkg, S, hipmem, seed):
             # (or, for the build after a failed one, at once as well): take the deferred verdict now
             rb = call(eng[pkg.HANDOFF_ASYNC], "wait", 0)
         assert ra == rb, (i, history[-8:], ra if not isinstance(ra, tuple) or ra[0] == "error" else "...", rb if not isinstance(rb, tuple) or rb[0] == "error" else "...")
+
+
+# ---- the first evaluation of an align enqueued BEHIND a build that is still in flight ---------------------------------
+
+def _upload3(hip, a):
+    return [hip.upload(np.ascontiguousarray(a[:, k])) for k in range(3)]
+
+
+def test_first_evaluation_behind_a_deferred_device_build_changes_no_number(pkg, hipmem, S):
+    hip = hipmem
+    """ndt_set_target_device_deferred + align against ndt_set_target_device + align, scan after scan: every answer
+    bit for bit, and the deferred handle really took the short cut (counter)."""
+    cfgs = [S.config_c2(), S.config_c1()]
+    dev = [(_upload3(hip, c["target"]), len(c["target"]), _upload3(hip, c["source"]), len(c["source"]), c["guess"]) for c in cfgs]
+    out = {}   # (hipMemcpy is synchronous: the uploads are complete)
+    for deferred in (False, True):
+        ndt = _ndt(pkg)
+        res = []
+        for rep in range(4):
+            for tp, nt, sp, ns, guess in dev:
+                (ndt.setInputTargetDeviceDeferred if deferred else ndt.setInputTargetDevice)(tp[0], tp[1], tp[2], nt)
+                ndt.setInputSourceDeviceView(sp[0], sp[1], sp[2], ns)
+                T = ndt.align(guess)
+                r = ndt.getResult()
+                res.append((T.copy(), r["iterations"], r["n_evaluations"], r["score"], r["hessian"].copy()))
+        out[deferred] = res
+        kept, discarded = ndt.speculationCounters()
+        if deferred:
+            assert kept >= 6 and discarded == 0, (kept, discarded)   # (the first build of a handle completes inside the call)
+        else:
+            assert kept == 0 and discarded == 0
+        ndt.close()
+    for a, b in zip(out[False], out[True]):
+        assert np.array_equal(a[0], b[0]) and a[1:4] == b[1:4] and np.array_equal(a[4], b[4])
+
+
+def test_first_evaluation_behind_a_build_that_is_refused_or_repeated(pkg, S):
+    """The short cut must not survive a build that does not go through as enqueued: a cloud without a finite point
+    (reported by the align, the prior returned), and a cloud the two-launch build declines (crowded voxels: repeated
+    sort-based) -- same answers as the blocking hand-off."""
+    c = S.config_c1()
+    rng = np.random.default_rng(5)
+    crowded = np.concatenate([c["target"], (rng.random((9000, 3)) * 0.9 + np.array([2.0, 2.0, 0.5])).astype(np.float32)])
+    seq = [c["target"], crowded, c["target"], np.full((500, 3), np.nan, np.float32), c["target"]]
+    out = {}
+    for mode in (pkg.HANDOFF_SYNC, pkg.HANDOFF_ASYNC):
+        ndt = _ndt(pkg)
+        ndt.setHandoffMode(mode)
+        res = []
+        for t in seq:
+            try:
+                ndt.setInputTarget(t)
+                ndt.setInputSource(c["source"])
+                T = ndt.align(c["guess"])
+                r = ndt.getResult()
+                res.append(("ok", T.copy(), r["iterations"], r["score"]))
+            except pkg.NdtError as e:
+                res.append(("err", e.code))
+        out[mode] = res
+        if mode == pkg.HANDOFF_ASYNC:
+            kept, discarded = ndt.speculationCounters()
+            assert kept >= 1 and discarded >= 1, (kept, discarded)
+        ndt.close()
+    assert [r[0] for r in out[pkg.HANDOFF_SYNC]] == [r[0] for r in out[pkg.HANDOFF_ASYNC]] == ["ok", "ok", "ok", "err", "ok"]
+    for a, b in zip(out[pkg.HANDOFF_SYNC], out[pkg.HANDOFF_ASYNC]):
+        if a[0] == "ok":
+            assert np.array_equal(a[1], b[1]) and a[2:] == b[2:]
+        else:
+            assert a[1] == b[1] == -4   # NDT_ERR_NO_TARGET

@@ -17,8 +17,9 @@ tp = [hip.upload(cfg["target"][:, a]) for a in range(3)]; sp = [hip.upload(cfg["
 hip.synchronize()
 g = pkg.ColMajor4f(cfg["guess"])
 nt, ns = len(cfg["target"]), len(cfg["source"])
+set_target = ndt.setInputTargetDeviceDeferred if os.environ.get("NDT_STEP_AB_DEFERRED") == "1" else ndt.setInputTargetDevice
 def step():
-    t0 = time.perf_counter(); ndt.setInputTargetDevice(tp[0], tp[1], tp[2], nt)
+    t0 = time.perf_counter(); set_target(tp[0], tp[1], tp[2], nt)
     t1 = time.perf_counter(); ndt.setInputSourceDeviceView(sp[0], sp[1], sp[2], ns)
     t2 = time.perf_counter(); ndt.align(g, return_transform=False)
     t3 = time.perf_counter(); return t1 - t0, t2 - t1, t3 - t2
@@ -33,6 +34,6 @@ t1 = ndt.getTiming(); ndt.enableKernelTiming(False)
 k_us = 1e3 * (t1["ms_eval_kernel_total"] - t0["ms_eval_kernel_total"]) / (t1["n_timed_evals"] - t0["n_timed_evals"])
 med = lambda v: 1e3 * float(np.median(v))
 pre = ndt.prelaunchCounters() + (ndt.prelaunchOverlapped(),)
-print("%-22s step %.3f ms = build %.3f (device %.3f) + source %.3f + align %.3f | it %d ev %d reused %d -> %.2f us/eval wall, kernel %.2f us | %.0f it/s | score %.9f | prelaunch %s"
+print("%-26s step %.3f ms = build %.3f (device %.3f) + source %.3f + align %.3f | it %d ev %d reused %d -> %.2f us/eval wall, kernel %.2f us | %.0f it/s | score %.9f | prelaunch %s"
       % (tag, med(B) + med(Sx) + med(A), med(B), float(np.median(dev_build)), med(Sx), med(A), r["iterations"], r["n_evaluations"],
          r["n_evaluations_reused"], 1e3 * med(A) / r["n_evaluations"], k_us, r["iterations"] / (np.median(B) + np.median(Sx) + np.median(A)), r["score"], pre), flush=True)
