@@ -127,6 +127,11 @@ def c5_block(pkg, n_frames=8):
     perr = [S.pose_error(p, gt)[0] for p, (_, gt) in zip(priors, sv_stream)]
     sv["mean_error_m"] = float(np.mean([e[0] for e in replay.trajectory_errors(res["poses"], sv_stream)][1:]))
     sv["mean_prior_error_m"] = float(np.mean(perr[1:]))
+    # SVN iterations per second of the registration calls, beside the only timing the reference publishes (BASELINE.md 2:
+    # its own pipeline_lo_svn log, output/output.txt -- other hardware, an older revision, <= 65 536 points per scan)
+    sv["svn_iterations_per_sec"] = float(sum(res["iterations"]) / (res["ms_engine"].sum() * 1e-3))
+    sv["reference_log"] = {"svn_iterations_per_sec": 13.6, "ms_per_iteration": 73.5,
+                           "source": "BASELINE.md section 2 (output/output.txt: K = 20, CPU/OpenMP, unstated machine, scan <= 65 536 points)"}
     # Stage-1 launch: the batched kernel's own duration and ITS algorithmic fraction (K poses x B_eval per launch)
     svn.enableKernelTiming(True)
     tm0 = svn.getTiming()

@@ -55,6 +55,7 @@ def test_bench_line_schema():
     st = c5["svn_k20"]["stage1"]
     assert st["poses_per_launch"] == 20 and st["ms_per_launch"] > 0 and 0 < st["frac"] < 1 and st["launches_timed"] >= 1
     assert c5["svn_k20"]["mean_error_m"] < c5["svn_k20"]["mean_prior_error_m"]
+    assert c5["svn_k20"]["svn_iterations_per_sec"] > 100 * c5["svn_k20"]["reference_log"]["svn_iterations_per_sec"]
     assert d["evaluations_reused_per_align"] >= 0 and d["config"]["rccl"]["version"] > 20000
     assert 0 <= d["evaluations_prelaunched_per_align"] < d["evaluations_per_align"] and d["prelaunch_timeouts"] == 0
     cb = d["cpu_baseline"]
