@@ -1,6 +1,7 @@
-"""In-process interleaved A/B of the first evaluation enqueued behind a deferred build (tuning aid, not collected by
-pytest): steps alternate between the short cut on and off on ONE handle, so box-to-box and run-to-run drift cancel.
-C3 and C2 with device-resident clouds (ndt_set_target_device_deferred), C2 with host clouds (asynchronous hand-off)."""
+"""In-process interleaved A/B of a per-handle switch (tuning aid, not collected by pytest): steps alternate between
+off and on on ONE handle, so box-to-box and run-to-run drift cancel; paired differences resolve < 1 us per step.
+Usage: python tools/toggle_ab.py speculation.  C3 and C2 with device-resident clouds
+(ndt_set_target_device_deferred), C2 with host clouds (asynchronous hand-off)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,6 +9,8 @@ import __graft_entry__ as ge
 pkg = ge.load_package(); S = pkg.synth
 hip = pkg.ranks.Hip(0)
 N = int(os.environ.get("NDT_AB_STEPS", "300"))
+FEATURE = sys.argv[1] if len(sys.argv) > 1 else "speculation"
+SETTER = {"speculation": "setSpeculation"}[FEATURE]   # (add a setter here for the next switch to be A/B-ed)
 
 def run(name, cfg, res, host):
     ndt = pkg.NormalDistributionsTransform(device_id=0, resolution=res, step_size=0.1, trans_epsilon=1e-4, max_iterations=35)
@@ -27,12 +30,12 @@ def run(name, cfg, res, host):
     for _ in range(10): step()
     t = {0: [], 1: []}
     for i in range(2 * N):
-        ndt.setSpeculation(i & 1)
+        getattr(ndt, SETTER)(i & 1)
         t[i & 1].append(step())
     k = ndt.speculationCounters()
     a, b = 1e6 * np.array(t[0]), 1e6 * np.array(t[1])
-    print("%-28s off: median %.1f mean %.1f us | on: median %.1f mean %.1f us | on - off: median %+.2f, mean of pairs %+.2f +- %.2f us | kept %d discarded %d"
-          % (name, np.median(a), a.mean(), np.median(b), b.mean(), np.median(b) - np.median(a), (b - a).mean(),
+    print("%-12s %-24s off: median %.1f mean %.1f us | on: median %.1f mean %.1f us | on - off: median %+.2f, mean of pairs %+.2f +- %.2f us | kept %d discarded %d"
+          % (FEATURE, name, np.median(a), a.mean(), np.median(b), b.mean(), np.median(b) - np.median(a), (b - a).mean(),
              (b - a).std() / np.sqrt(len(a)), k[0], k[1]), flush=True)
     ndt.close()
 
