@@ -121,6 +121,9 @@ def usable_cpus():
     return n
 
 
+WAKE_STEPS = int(os.environ.get("NDT_BENCH_WAKE_STEPS", "60"))
+
+
 def cpu_baseline(cfg, params, seconds):
     """The oracle timed on this box's host cores; step = grid build + align, like the GPU step.
     Two thread settings: every core this job may use, and the 8 of config/register_config.json:3."""
@@ -265,7 +268,10 @@ def main():
         reports an infinite time, so every rank sees the variant as failed and moves on."""
         failed = None
         try:
-            for _ in range(args.warmup):
+            # (device wake-up, untimed, in front of the W warm-up steps: after an idle period -- the seconds of cloud
+            # synthesis before this point -- an MI355X needs ~30 ms of work to be back at its clocks; W = 5 steps are
+            # 2.6 ms.  tools/warmup_probe.py: steps 5..24 after 5 s of idling average 0.576 ms, steps 45.. 0.52.)
+            for _ in range(WAKE_STEPS + args.warmup):
                 step()
         except pkg.NdtError as e:
             if not multi:
@@ -390,6 +396,7 @@ def main():
                        "grid_cells": int(gi["n_cells"]), "mean_neighbors": nbar, "sharding": "source/%d" % world,
                        "reduce": reduce_mode, "reduce_variants": variants},
             "ms_target_build_device": gi["ms_build"],
+            "device_wake_steps": WAKE_STEPS,   # untimed steps in front of the W warm-up steps of every timed region (clock ramp after idling)
             "final_error_vs_ground_truth": {"m": err_t, "rad": err_r},
             # `bound`: what the evidence shows limits this launch (DESIGN 4.1 / HISTORY 4.1: half of the 200 k-point launch is a
             # fixed latency chain, the rest VALU issue); `roof`: the roofline `achieved` / `peak` / `frac` are
