@@ -279,6 +279,17 @@ def test_first_evaluation_behind_a_deferred_device_build_changes_no_number(pkg, 
         ndt.close()
     for a, b in zip(out[False], out[True]):
         assert np.array_equal(a[0], b[0]) and a[1:4] == b[1:4] and np.array_equal(a[4], b[4])
+    # under the blocking hand-off the deferred call IS the blocking one: nothing is left in flight for the align
+    ndt = _ndt(pkg)
+    ndt.setHandoffMode(pkg.HANDOFF_SYNC)
+    for rep in range(3):
+        tp, nt, sp, ns, guess = dev[0]
+        ndt.setInputTargetDeviceDeferred(tp[0], tp[1], tp[2], nt)
+        ndt.setInputSourceDeviceView(sp[0], sp[1], sp[2], ns)
+        T = ndt.align(guess)
+        assert np.array_equal(T, out[False][0][0])
+    assert ndt.speculationCounters() == (0, 0)
+    ndt.close()
 
 
 def test_first_evaluation_behind_a_build_that_is_refused_or_repeated(pkg, S):
