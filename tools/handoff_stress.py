@@ -50,5 +50,6 @@ for i in range(n):
     if not (np.array_equal(T, want[k][0]) and r["iterations"] == want[k][1] and r["score"] == want[k][2]):
         bad += 1; print("MISMATCH at scan %d case %d" % (i, k), flush=True)
 stop = True
-print("%d scans through the asynchronous hand-off under host contention in %.1f s: %d failures, %d mismatches; prelaunch counters %s"
-      % (n, time.perf_counter() - t0, fails, bad, ndt.prelaunchCounters()), flush=True)
+print("%d scans through the asynchronous hand-off under host contention in %.1f s: %d failures, %d mismatches; prelaunch counters %s; "
+      "first evaluations behind a running build (kept, discarded) %s"
+      % (n, time.perf_counter() - t0, fails, bad, ndt.prelaunchCounters(), ndt.speculationCounters()), flush=True)
