@@ -22,3 +22,11 @@ for pause in (0.0, 0.5, 5.0, 20.0):
     t = [step() for _ in range(80)]
     print("after %4.1f s idle: steps 0-4 %.3f | 5-24 %.3f | 25-44 %.3f | 45-79 %.3f ms (means); first five: %s"
           % (pause, np.mean(t[:5]), np.mean(t[5:25]), np.mean(t[25:45]), np.mean(t[45:]), " ".join("%.3f" % v for v in t[:5])), flush=True)
+# a 10 Hz driver: one step every 100 ms
+for rep in range(2):
+    for _ in range(5): step()
+    t = []
+    for _ in range(40):
+        time.sleep(0.1)
+        t.append(step())
+    print("one step every 100 ms: median %.3f  p10 %.3f  p90 %.3f ms" % (np.median(t), np.percentile(t, 10), np.percentile(t, 90)), flush=True)
