@@ -235,7 +235,9 @@ typedef enum ndt_handoff_mode { NDT_HANDOFF_ASYNC = 0, NDT_HANDOFF_SYNC = 1 } nd
 int ndt_set_handoff_mode(ndt_handle* h, int mode);
 int ndt_get_handoff_mode(const ndt_handle* h);
 /* Blocks until every hand-off in flight is complete on the device; returns the status of a deferred build that
- * failed (and keeps it for the next call that needs the grid), NDT_OK otherwise. */
+ * failed, NDT_OK otherwise.  A deferred failure is reported once -- by this call or by the first call that needs the
+ * grid, whichever comes first; after that the handle is where a failed blocking ndt_set_target leaves it (no target:
+ * NDT_ERR_NO_TARGET from the calls that need one). */
 int ndt_wait(ndt_handle* h);
 
 /* setInputTarget (ref: run/pipeline.cpp:557): uploads and builds the voxel grid.

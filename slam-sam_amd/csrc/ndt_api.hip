@@ -198,7 +198,7 @@ struct ndt_handle {
   };
   BuildRun brun;
   bool build_pending = false;
-  int deferred_rc = 0;               // status of a deferred build that failed, until a call that needs the grid has reported it
+  int deferred_rc = 0;               // status of a deferred build that failed, until a call that needs the grid (or ndt_wait) has reported it
   std::string deferred_msg;
   double ms_settle_wait = 0;         // time the collecting call waited for the pending build's verdict
   PinBuf<double> result;             // evaluation results (K * EV_WORDS)
@@ -787,11 +787,21 @@ int source_behind_target_transfer(ndt_handle* h, bool async) {
   return NDT_OK;
 }
 
+// A deferred build's failure is reported ONCE, by the first call that needs the grid (or by ndt_wait); from then on the
+// handle is where a failed blocking ndt_set_target leaves it: no grid (NDT_ERR_NO_TARGET for consumers), nothing pending.
+int report_deferred(ndt_handle* h) {
+  const int rc = h->deferred_rc;
+  const std::string msg = h->deferred_msg;
+  h->deferred_rc = 0;
+  h->deferred_msg.clear();
+  return fail(h, rc, msg);
+}
+
 // for calls that need the grid: a deferred build's failure is theirs to report
 int settle(ndt_handle* h) {
   (void)settle_build(h);
   int rs = settle_source(h);
-  if (!h->have_grid && h->deferred_rc) return fail(h, h->deferred_rc, h->deferred_msg);
+  if (!h->have_grid && h->deferred_rc) return report_deferred(h);
   return rs;
 }
 
@@ -2522,7 +2532,7 @@ int ndt_wait(ndt_handle* h) {
   if (rc) return rc;
   rc = lane_wait(h, h->lane_s);
   if (rc) return rc;
-  if (!h->have_grid && h->deferred_rc) return fail(h, h->deferred_rc, h->deferred_msg);
+  if (!h->have_grid && h->deferred_rc) return report_deferred(h);
   return NDT_OK;
 }
 

@@ -2,6 +2,8 @@
 pcl::PointCloud<PointXYZI>, ref: run/pipeline.cpp:554-561): the calls return once the caller's memory has been
 consumed, copies and build finish behind them, the first call that needs them waits.  Nothing about the RESULTS may
 depend on the mode: every number here is compared bit for bit with the blocking hand-off of rounds 1-3."""
+import os
+
 import numpy as np
 import pytest
 
@@ -92,10 +94,22 @@ def test_deferred_build_failure_is_reported_by_the_first_consumer(pkg, S):
     with pytest.raises(pkg.NdtError) as ei:
         ndt.align(cfg["guess"])
     assert ei.value.code == -4 and "finite" in str(ei.value)
-    for call in (ndt.getGridInfo, ndt.getLeaves, ndt.wait):
+    # reported once; from then on the handle is where a failed BLOCKING setInputTarget leaves it: no target for the
+    # calls that need one, nothing in flight for wait()
+    for call in (ndt.getGridInfo, ndt.getLeaves):
         with pytest.raises(pkg.NdtError) as ei:
             call()
         assert ei.value.code == -4
+    ndt.wait()
+    ndt.setInputTarget(cfg["target"]); ndt.wait()
+    ndt.setInputTarget(bad)       # deferred again; this time wait() is the first to hear of it -- and the only one
+    with pytest.raises(pkg.NdtError) as ei:
+        ndt.wait()
+    assert ei.value.code == -4 and "finite" in str(ei.value)
+    ndt.wait()
+    with pytest.raises(pkg.NdtError) as ei:
+        ndt.align(cfg["guess"])
+    assert ei.value.code == -4
     # the build after a failed one starts from a cleared index grid and waits for its geometry like a handle's
     # first build: it completes inside the call, so its failure is reported there
     with pytest.raises(pkg.NdtError) as ei:
@@ -160,7 +174,7 @@ def test_handoff_timing_reports_dma_rate(pkg, S):
     assert t["source"]["ms_dma"] > 0 and t["source"]["ms_repack"] > 0
 
 
-@pytest.mark.parametrize("seed", [11, 12, 13])
+@pytest.mark.parametrize("seed", [11, 12, 13] + list(range(100, 100 + int(os.environ.get("NDT_FUZZ_EXTRA_SEEDS", "0")))))
 def test_random_api_sequences_async_equals_sync(pkg, S, hipmem, seed):
     """Differential fuzz of the asynchronous hand-off's bookkeeping: two engines, one blocking, one asynchronous, are fed
     the SAME random sequence of calls (targets and sources through every entry point, consumers of every kind, keyframes,
@@ -192,6 +206,8 @@ def test_random_api_sequences_async_equals_sync(pkg, S, hipmem, seed):
                 e.setInputTargetSoA(*[np.ascontiguousarray(clouds[k % 4][:, ax]) for ax in range(3)]); return "ok"
             if op == "target_dev":
                 d = dev[k % 4]; e.setInputTargetDevice(d[0], d[1], d[2], len(clouds[k % 4])); return "ok"
+            if op == "target_dev_deferred":   # (enqueued under the asynchronous hand-off; the arrays are never touched here)
+                d = dev[k % 4]; e.setInputTargetDeviceDeferred(d[0], d[1], d[2], len(clouds[k % 4])); return "ok"
             if op == "target_bad":
                 e.setInputTarget(bad); return "ok"
             if op == "source":
@@ -230,8 +246,8 @@ def test_random_api_sequences_async_equals_sync(pkg, S, hipmem, seed):
 
     ops = ["target", "target_xyzi", "target_soa", "target_dev", "source", "source_soa", "source_dev", "source_view",
            "align", "align", "eval", "score", "grid", "leaves", "step", "resolution", "keyframe", "downsample", "wait",
-           "target_bad"]
-    weights = np.array([4, 3, 2, 2, 4, 2, 1, 1, 5, 5, 3, 2, 2, 1, 2, 1, 1, 1, 1, 1], float)
+           "target_bad", "target_dev_deferred"]
+    weights = np.array([4, 3, 2, 2, 4, 2, 1, 1, 5, 5, 3, 2, 2, 1, 2, 1, 1, 1, 1, 1, 3], float)
     weights /= weights.sum()
     history = []
     for i in range(400):
@@ -244,7 +260,9 @@ def test_random_api_sequences_async_equals_sync(pkg, S, hipmem, seed):
             # the blocking hand-off reports a failed build at once, the asynchronous one at the first consumer
             # (or, for the build after a failed one, at once as well): take the deferred verdict now
             rb = call(eng[pkg.HANDOFF_ASYNC], "wait", 0)
-        assert ra == rb, (i, history[-8:], ra if not isinstance(ra, tuple) or ra[0] == "error" else "...", rb if not isinstance(rb, tuple) or rb[0] == "error" else "...")
+        assert ra == rb, "step %d, last calls %s: blocking %s, asynchronous %s" % (
+            i, " ".join("%s(%d)" % h for h in history[-10:]), ra if not isinstance(ra, tuple) or ra[0] == "error" else "...",
+            rb if not isinstance(rb, tuple) or rb[0] == "error" else "...")
 
 
 # ---- the first evaluation of an align enqueued BEHIND a build that is still in flight ---------------------------------
