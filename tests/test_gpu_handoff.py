@@ -190,7 +190,9 @@ def test_random_api_sequences_async_equals_sync(pkg, S, hipmem, seed):
     dsrc = {k: [hipmem.upload(np.ascontiguousarray(c[:, ax])) for ax in range(3)] for k, c in enumerate(sources)}
     eng = {}
     for mode in (pkg.HANDOFF_SYNC, pkg.HANDOFF_ASYNC):
-        e = _ndt(pkg)
+        # (the blocking engine is also the plainest one: every evaluation an ordinary launch; the asynchronous one has
+        # everything on -- pre-launched kernels, both streams, the first evaluation behind a running build)
+        e = _ndt(pkg, prelaunch=pkg.PRELAUNCH_OFF if mode == pkg.HANDOFF_SYNC else pkg.PRELAUNCH_AUTO)
         e.setHandoffMode(mode)
         e.setInputTarget(clouds[0]); e.setInputSource(sources[0]); e.align(guesses[0])
         eng[mode] = e
@@ -234,6 +236,15 @@ def test_random_api_sequences_async_equals_sync(pkg, S, hipmem, seed):
                 e.setStepSize(0.1 if k % 2 else 0.05); return "ok"
             if op == "resolution":
                 e.setResolution(1.0 if k % 2 else 1.5); return "ok"
+            if op == "search":
+                e.setNeighborhoodSearchMethod((pkg.DIRECT7, pkg.DIRECT1, pkg.KDTREE, pkg.DIRECT26)[k % 4]); return "ok"
+            if op == "hessian":
+                e.setParams(hessian_mode=pkg.HESSIAN_GAUSS_NEWTON if k % 2 else pkg.HESSIAN_FULL); return "ok"
+            if op == "maxit":
+                e.setMaximumIterations((35, 2, 0, 12)[k % 4]); return "ok"
+            if op == "evalbatch":
+                P = np.array([[0.3, 0.05, 0.0, 0.0, 0.01, 0.02 * j] for j in range(1 + k % 5)])
+                return tuple((ev["score"], ev["n_pairs"], ev["hessian"].tobytes()) for ev in e.evalDerivatives(P))
             if op == "keyframe":
                 e.putKeyframe(7, sources[k % 3]); e.setInputSourceFromKeyframe(7); return "ok"
             if op == "downsample":
@@ -246,8 +257,8 @@ def test_random_api_sequences_async_equals_sync(pkg, S, hipmem, seed):
 
     ops = ["target", "target_xyzi", "target_soa", "target_dev", "source", "source_soa", "source_dev", "source_view",
            "align", "align", "eval", "score", "grid", "leaves", "step", "resolution", "keyframe", "downsample", "wait",
-           "target_bad", "target_dev_deferred"]
-    weights = np.array([4, 3, 2, 2, 4, 2, 1, 1, 5, 5, 3, 2, 2, 1, 2, 1, 1, 1, 1, 1, 3], float)
+           "target_bad", "target_dev_deferred", "search", "hessian", "maxit", "evalbatch"]
+    weights = np.array([4, 3, 2, 2, 4, 2, 1, 1, 5, 5, 3, 2, 2, 1, 2, 1, 1, 1, 1, 1, 3, 2, 1, 1, 2], float)
     weights /= weights.sum()
     history = []
     for i in range(400):
