@@ -32,6 +32,9 @@ def hog():
 hogs = [threading.Thread(target=hog, daemon=True) for _ in range(3)]
 for h in hogs: h.start()
 bad = fails = 0
+def rss_mb():
+    return int(open('/proc/self/statm').read().split()[1]) * os.sysconf('SC_PAGE_SIZE') / 2**20
+rss0 = None
 t0 = time.perf_counter()
 def xyzi(c):
     o = np.zeros((len(c), 8), np.float32); o[:, :3] = c; return o
@@ -47,9 +50,10 @@ for i in range(n):
         fails += 1; print("FAIL at scan %d: %s" % (i, e), flush=True)
         if fails > 5: break
         continue
+    if i == 200: rss0 = rss_mb()   # (allocations settle during the first scans)
     if not (np.array_equal(T, want[k][0]) and r["iterations"] == want[k][1] and r["score"] == want[k][2]):
         bad += 1; print("MISMATCH at scan %d case %d" % (i, k), flush=True)
 stop = True
 print("%d scans through the asynchronous hand-off under host contention in %.1f s: %d failures, %d mismatches; prelaunch counters %s; "
-      "first evaluations behind a running build (kept, discarded) %s"
-      % (n, time.perf_counter() - t0, fails, bad, ndt.prelaunchCounters(), ndt.speculationCounters()), flush=True)
+      "first evaluations behind a running build (kept, discarded) %s; resident set %.0f MB after 200 scans, %.0f MB at the end"
+      % (n, time.perf_counter() - t0, fails, bad, ndt.prelaunchCounters(), ndt.speculationCounters(), rss0 or 0.0, rss_mb()), flush=True)
