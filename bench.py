@@ -189,6 +189,7 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     # rehearsal knob for a 1-GPU box: every rank on device 0 (RCCL refuses two ranks on one device)
     rehearsal = os.environ.get("NDT_BENCH_SINGLE_DEVICE", "0") == "1"
+    rehearsal_tuning = {}
     if rehearsal:
         local_rank = 0
         if world > 2:
@@ -197,8 +198,7 @@ def main():
             # compute units together, each waits out its 50 ms time-out and falls back (0.2-0.6 s per step with four
             # ranks, profiles/r03_4on1_rehearsal.txt).  A rehearsal of that shape takes the launch-per-phase passes, which
             # never wait inside a kernel.  One rank per device -- the deployment -- is not affected.
-            os.environ.setdefault("NDT_BUCKET_BUILD", "0")
-            os.environ.setdefault("NDT_FUSED_SORT", "0")
+            rehearsal_tuning = {"bucket_build": 0, "fused_sort": 0}   # (ndt_set_tuning below: the library reads no such variables)
     # stdout carries ONE JSON line and nothing else: native libraries write there too (librccl prints
     # "RCCL version : ..." on its first communicator), so file descriptor 1 is pointed at stderr for the
     # life of the rank and the line goes out through a private copy of the original descriptor
@@ -216,6 +216,8 @@ def main():
         device_note = next((b.decode() for b in board.allgather((device_note or "").encode()[:250]) if b), None)
 
     pkg = ge.load_package()
+    if rehearsal_tuning:
+        pkg.set_tuning(**rehearsal_tuning)
     S = pkg.synth
     cfg = S.config_c3()
     params = dict(resolution=float(cfg["resolution"]), step_size=0.1, trans_epsilon=1e-4, max_iterations=35)

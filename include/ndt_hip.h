@@ -232,6 +232,42 @@ int ndt_backend_info(char* buf, size_t cap);
  * NDT_HANDOFF_SYNC: both calls block until the device has everything (rounds 1-3 behaviour; also NDT_HANDOFF=sync
  * in the environment). */
 typedef enum ndt_handoff_mode { NDT_HANDOFF_ASYNC = 0, NDT_HANDOFF_SYNC = 1 } ndt_handoff_mode;
+/* Tuning and A/B switches (round 5).  The production library reads NONE of these from the environment -- a library
+ * linked into somebody else's process is not steered by variables that process never heard of.  The environment is
+ * left with four documented OPERATIONAL knobs: NDT_HANDOFF=sync (blocking hand-off), NDT_UPLOAD_THREADS (repack
+ * workers), NDT_COMM_TIMEOUT_S (multi-rank reduce time-out), NDT_PRELAUNCH=0 (no pre-launched kernels).  Everything
+ * else is this struct: process-wide, read at the launches and handle creations that FOLLOW the call; every field has
+ * the default ndt_get_tuning() reports in a fresh process.  Results do not depend on any of them (same rows, same
+ * order, same bits), only timings do -- except deriv_block / deriv_single_level_max, which change the partition of
+ * the scan and with it the last bits of the floating-point sums.
+ * (The diagnostic library variants -- make VARIANT=ab|seams|stamps -- still take the historical NDT_* variables as
+ * initial values of these fields; the tuning programs under tools/ use ndt_set_tuning.) */
+typedef struct ndt_tuning {
+  int deriv_block;            /* 0: chosen per launch (default); else threads per block of k_derivatives, multiple of 64, 64..1024 */
+  int deriv_summer;           /* 1: a fixed block adds the partial rows by polling their tags (default); 0: ticket, last block adds */
+  int deriv_dedicated;        /* 1: that block owns no points where a compute unit is spare (default); 0: block 0 doubles */
+  int deriv_single_level_max; /* rows one block adds directly (default 2048); larger grids go through 32 group rows */
+  int deriv_xcd;              /* 0: chunk = block id; 1: XCD-aware chunks on resident single-pose grids (default); 2: stripes too */
+  int bucket_build;           /* 1: steady-state builds in two launches (default); 0: launch-per-phase sort pipeline */
+  int bucket_tile;            /* 0: chosen from the cloud size (default); 4096 | 8192 points per tile of k_bucket_pass */
+  int fused_sort;             /* 1: one launch per sort digit where the cloud allows it (default); 0: classic passes */
+  int bounds_blocks;          /* blocks of the bounds pass (default 256) */
+  int bounds_unroll;          /* 8 (default) | 4 */
+  int finalize_threads;       /* 256 (default) | 64 */
+  int build_events;           /* -1: HIP events around a build only while kernel timing is on (default); 0 | 1: never | always */
+  int build_wait_sync;        /* 0: the host polls the build's done tag (default); 1: hipStreamSynchronize */
+  int mbox_tagged;            /* 1: poses reach pre-launched kernels as tagged 8-byte granules (default); 0: words + sequence */
+  int mbox_preload;           /* 0 (default); 1: a pre-launched kernel fetches its point before the pose arrives */
+  int prelaunch_streams;      /* 2: pre-launched kernels on the engine's second stream (default); 1: one stream */
+  int prelaunch_probe;        /* 1: the automatic stream placement probes the other placement (default); 0: never */
+  int speculate_first;        /* 1: first evaluation of an align enqueued behind a running build (default); 0: off */
+  int timing_bracket;         /* 0: kernel-timing events attached to the dispatch (default); 1: recorded around the launch call */
+  int reserved[13];           /* zero */
+} ndt_tuning;
+int ndt_get_tuning(ndt_tuning* out);
+/* NDT_ERR_INVALID_ARG (nothing changed) when a field is outside its documented values. */
+int ndt_set_tuning(const ndt_tuning* t);
+
 int ndt_set_handoff_mode(ndt_handle* h, int mode);
 int ndt_get_handoff_mode(const ndt_handle* h);
 /* Blocks until every hand-off in flight is complete on the device; returns the status of a deferred build that

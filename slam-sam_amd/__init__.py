@@ -126,6 +126,62 @@ class SvnResult(C.Structure):
                 ("ms_stage3", C.c_double)]
 
 
+class Tuning(C.Structure):
+    """ndt_tuning (include/ndt_hip.h): the engine's A/B switches.  The library reads none of them from the environment."""
+    _fields_ = [(k, C.c_int) for k in (
+        "deriv_block", "deriv_summer", "deriv_dedicated", "deriv_single_level_max", "deriv_xcd", "bucket_build",
+        "bucket_tile", "fused_sort", "bounds_blocks", "bounds_unroll", "finalize_threads", "build_events",
+        "build_wait_sync", "mbox_tagged", "mbox_preload", "prelaunch_streams", "prelaunch_probe", "speculate_first",
+        "timing_bracket")] + [("reserved", C.c_int * 13)]
+
+
+# the variables the tuning programs under tools/ (and bench.py's rehearsals) have always used, mapped onto ndt_tuning by
+# apply_env_tuning() -- in Python, on request: the C library itself does not look at them
+TUNING_ENV = {
+    "NDT_DERIV_BLOCK": "deriv_block", "NDT_DERIV_SUMMER": "deriv_summer", "NDT_DERIV_DEDICATED": "deriv_dedicated",
+    "NDT_DERIV_SINGLE_LEVEL_MAX": "deriv_single_level_max", "NDT_DERIV_XCD": "deriv_xcd",
+    "NDT_BUCKET_BUILD": "bucket_build", "NDT_BUCKET_TILE": "bucket_tile", "NDT_FUSED_SORT": "fused_sort",
+    "NDT_BOUNDS_BLOCKS": "bounds_blocks", "NDT_BOUNDS_UNROLL": "bounds_unroll",
+    "NDT_FINALIZE_THREADS": "finalize_threads", "NDT_BUILD_EVENTS": "build_events",
+    "NDT_MBOX_TAGGED": "mbox_tagged", "NDT_MBOX_PRELOAD": "mbox_preload",
+    "NDT_PRELAUNCH_STREAMS": "prelaunch_streams", "NDT_PRELAUNCH_PROBE": "prelaunch_probe",
+    "NDT_SPECULATE_FIRST": "speculate_first", "NDT_TIMING_BRACKET": "timing_bracket",
+}
+
+
+def get_tuning():
+    t = Tuning()
+    rc = lib().ndt_get_tuning(C.byref(t))
+    if rc:
+        raise NdtError(rc, "ndt_get_tuning")
+    return {k: getattr(t, k) for k, _ in Tuning._fields_ if k != "reserved"}
+
+
+def set_tuning(**fields):
+    """ndt_set_tuning with the named fields changed; applies to the handles created and the launches made afterwards."""
+    t = Tuning()
+    rc = lib().ndt_get_tuning(C.byref(t))
+    if rc:
+        raise NdtError(rc, "ndt_get_tuning")
+    for k, v in fields.items():
+        if k == "reserved" or not hasattr(t, k):
+            raise KeyError(k)
+        setattr(t, k, int(v))
+    rc = lib().ndt_set_tuning(C.byref(t))
+    if rc:
+        raise NdtError(rc, "ndt_set_tuning(%s)" % fields)
+    return get_tuning()
+
+
+def apply_env_tuning(environ=None):
+    """For tuning programs and test harnesses: NDT_* variables of the historical names -> ndt_set_tuning."""
+    env = os.environ if environ is None else environ
+    fields = {f: int(env[k]) for k, f in TUNING_ENV.items() if env.get(k, "") != ""}
+    if env.get("NDT_BUILD_WAIT", "") != "":
+        fields["build_wait_sync"] = 1 if env["NDT_BUILD_WAIT"] == "sync" else 0
+    return set_tuning(**fields) if fields else get_tuning()
+
+
 EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float), C.c_int,
                       C.POINTER(C.c_double))
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
@@ -150,6 +206,7 @@ ABI_SYMBOLS = [
     "ndt_set_record_format", "ndt_get_record_format",
     "ndt_set_handoff_mode", "ndt_get_handoff_mode", "ndt_wait", "ndt_get_handoff_timing",
     "ndt_voxel_downsample_device", "ndt_voxel_downsample", "ndt_get_iteration_history",
+    "ndt_get_tuning", "ndt_set_tuning",
 ]
 
 _lib = None
@@ -165,6 +222,8 @@ def lib():
         L = C.CDLL(LIB_PATH)
         fp, dp, vp = C.POINTER(C.c_float), C.POINTER(C.c_double), C.c_void_p
         L.ndt_abi_version.restype = C.c_int
+        L.ndt_get_tuning.argtypes = [C.POINTER(Tuning)]
+        L.ndt_set_tuning.argtypes = [C.POINTER(Tuning)]
         L.ndt_default_params.argtypes = [C.POINTER(Params)]
         L.ndt_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
         L.ndt_destroy.argtypes = [vp]

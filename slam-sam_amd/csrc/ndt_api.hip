@@ -28,6 +28,7 @@
 #include "ndt_kernels.h"
 #include "ndt_newton.h"
 #include "ndt_repack_pool.h"
+#include "ndt_tuning.h"
 
 using namespace ndt;
 
@@ -413,18 +414,12 @@ int upload_soa(ndt_handle* h, ndt_handle::UploadLane& lane, hipStream_t stream, 
 // outgrew the buffers: the host waits for the geometry once, allocates, and goes on (as
 // before).  A refused optimistic build (BG_CAPACITY / BG_PASSES) is repeated that way.
 // Kernel timing (ndt_enable_kernel_timing): the two events are attached to the derivative kernel's dispatch, so their
-// difference is the kernel's own duration -- the figure rocprofv3 reports.  NDT_TIMING_BRACKET=1 records them around
-// the launch call instead, as rounds 1-2 did (adds the dispatch, ~2.4 us: the tuning scripts' older numbers).
-bool timing_brackets_launch() {
-  static const bool on = [] { const char* e = getenv("NDT_TIMING_BRACKET"); return e && atoi(e) != 0; }();
-  return on;
-}
+// difference is the kernel's own duration -- the figure rocprofv3 reports.  ndt_tuning::timing_bracket = 1 records them
+// around the launch call instead, as rounds 1-2 did (adds the dispatch, ~2.4 us: the tuning scripts' older numbers).
+bool timing_brackets_launch() { return tuning().timing_bracket != 0; }
 
-// NDT_PRELAUNCH_PROBE=0: NDT_PRELAUNCH_AUTO never probes the other stream placement (A/B aid)
-bool auto_probe_enabled() {
-  static const bool on = [] { const char* e = getenv("NDT_PRELAUNCH_PROBE"); return !(e && atoi(e) == 0); }();
-  return on;
-}
+// ndt_tuning::prelaunch_probe = 0: the automatic stream placement never probes the other placement (A/B aid)
+bool auto_probe_enabled() { return tuning().prelaunch_probe != 0; }
 
 // (re)writes the packed copy of the record table; `wait`: the caller is about to launch on another stream
 int pack_records(ndt_handle* h, bool wait) {
@@ -546,12 +541,11 @@ int build_begin(ndt_handle* h, const float* x, const float* y, const float* z, s
   // device time of the build by HIP events when kernel timing is on (ndt_enable_kernel_timing; bench.py's
   // instrumented pass); otherwise ms_build is the wall time from the build's enqueue to its verdict and the two
   // event records, the event query and the elapsed-time call (3-4 us of host time) are saved
-  static const int events_env = [] { const char* e = getenv("NDT_BUILD_EVENTS"); return e ? atoi(e) : -1; }();
-  br.build_events = events_env >= 0 ? events_env != 0 : h->timing;
+  const int events_tuned = tuning().build_events;
+  br.build_events = events_tuned >= 0 ? events_tuned != 0 : h->timing;
   br.t0 = std::chrono::steady_clock::now();
   if (br.build_events) HIP_TRY(h, hipEventRecord(h->ev0, s));
-  static const bool poll_env = [] { const char* e = getenv("NDT_BUILD_WAIT"); return !(e && std::strcmp(e, "sync") == 0); }();
-  br.poll_done = poll_env && h->prm.wait_mode == NDT_WAIT_SPIN;
+  br.poll_done = tuning().build_wait_sync == 0 && h->prm.wait_mode == NDT_WAIT_SPIN;
   br.attempt = 0;
   return NDT_OK;
 }
@@ -914,10 +908,9 @@ static bool source_sort_wanted(const ndt_handle* h, int n_valid) {
 // against 16 for the later ones, tools/first_eval_cost.py).  Only where nothing else depends on the verdict: results
 // polled from pinned slots, f64 records, no cross-rank exchange inside the kernel, a source that needs no re-ordering
 // for a grid of the size of the previous one (checked again once the verdict is in: a mismatch discards the launch).
-// NDT_SPECULATE_FIRST=0 in the environment: off.
+// ndt_tuning::speculate_first = 0: off.
 static bool first_eval_behind_build(const ndt_handle* h) {
-  static const bool off = [] { const char* e = getenv("NDT_SPECULATE_FIRST"); return e && atoi(e) == 0; }();
-  return !off && h->spec_enabled && h->build_pending && h->prev_n_valid > 0 && h->n_src > 0 && !h->timing &&
+  return tuning().speculate_first != 0 && h->spec_enabled && h->build_pending && h->prev_n_valid > 0 && h->n_src > 0 && !h->timing &&
          h->prm.wait_mode == NDT_WAIT_SPIN && !h->red.wants_device_buffer() && h->red.mode() != NDT_REDUCE_P2P &&
          h->record_format != NDT_RECORDS_PACKED48 && !source_sort_wanted(h, h->prev_n_valid);
 }
@@ -1390,18 +1383,14 @@ int ndt_create(const ndt_params* p, ndt_handle** out) {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) h->n_cus = cus;
   }
-  {  // A/B knobs of the pose hand-over to pre-launched kernels (profiles/r02_mailbox_ab.txt)
-    const char* t = getenv("NDT_MBOX_TAGGED");
-    const char* q = getenv("NDT_MBOX_PRELOAD");
-    h->mbox_tagged = !(t && atoi(t) == 0);
-    h->mbox_preload = q && atoi(q) != 0;
+  {  // A/B switches of the pose hand-over to pre-launched kernels (ndt_tuning; profiles/r02_mailbox_ab.txt)
+    const ndt_tuning& tn = tuning();
+    h->mbox_tagged = tn.mbox_tagged != 0;
+    h->mbox_preload = tn.mbox_preload != 0;
+    h->two_streams = tn.prelaunch_streams != 1;
   }
   {
-    const char* e = getenv("NDT_PRELAUNCH_STREAMS");
-    h->two_streams = !(e && atoi(e) == 1);
-  }
-  {
-    const char* e = getenv("NDT_HANDOFF");  // A/B aid: "sync" = the blocking hand-off of rounds 1-3
+    const char* e = getenv("NDT_HANDOFF");  // operational knob: "sync" = the blocking hand-off of rounds 1-3
     if (e && std::strcmp(e, "sync") == 0) h->handoff_mode = NDT_HANDOFF_SYNC;
   }
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
@@ -2479,6 +2468,7 @@ int ndt_debug_build_counters(const ndt_handle* h, int64_t out[3]) {
 // diagnostic builds only (-DNDT_STAMPS): 8 x 100 MHz stamps per block of the last launch
 int ndt_debug_read_stamps(unsigned long long* out, int nblocks) { return derivs_read_stamps(out, nblocks); }
 int ndt_debug_read_build_stamps(unsigned long long* out) { return build_read_stamps(out); }
+int ndt_debug_read_wave_stamps(unsigned long long* out, int nblocks) { return derivs_read_wave_stamps(out, nblocks); }
 
 // test seam (not in the public header): the voxel build's radix sort on caller-supplied keys;
 // vals_out receives the stable sorting permutation.  Host arrays.

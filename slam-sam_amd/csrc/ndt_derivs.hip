@@ -20,6 +20,7 @@
 // Compiled with -ffp-contract=off; the transform and the index arithmetic must
 // round exactly as written to classify points into the same voxels as the ref.
 #include "ndt_kernels.h"
+#include "ndt_tuning.h"
 
 #include <hip/hip_ext.h>
 
@@ -197,26 +198,6 @@ __device__ __forceinline__ VoxelRecord fetch_record(const VoxelRecord* __restric
   return rec[i];
 }
 
-// Record fetch of the DIRECT7 pair loop.  Two timing-only ablations (wrong results; `make VARIANT=ab EXTRA=-DNDT_ABL=..`):
-// 4: every lane reads record 0 (35 coalesced instead of 35 divergent 16-byte loads per lane) -- what divergence costs;
-// 5: 48 of the 80 bytes (three 16-byte loads instead of five) -- what a packed 48-byte record could save.
-#if defined(NDT_ABL) && NDT_ABL == 4
-#define NDT_LOAD_REC(s) rec[0]
-#elif defined(NDT_ABL) && NDT_ABL == 5
-__device__ __forceinline__ VoxelRecord load_rec48(const VoxelRecord* __restrict__ rec, int i) {
-  const double2* p = reinterpret_cast<const double2*>(rec + i);
-  const double2 a = p[0], b = p[1], c = p[2];
-  VoxelRecord r;
-  r.mean[0] = a.x; r.mean[1] = a.y; r.mean[2] = b.x;
-  r.icov[0] = b.y; r.icov[1] = c.x; r.icov[2] = c.y; r.icov[3] = b.y; r.icov[4] = c.x; r.icov[5] = c.y;
-  r.pad = 0.0;
-  return r;
-}
-#define NDT_LOAD_REC(s) load_rec48(rec, (s) >= 0 ? (s) : 0)
-#else
-#define NDT_LOAD_REC(s) fetch_record(rec, (s) >= 0 ? (s) : 0, PACKED)
-#endif
-
 // Phase 1 of a point: transform, neighbour lookup, pair sums.  Needs only R|t.
 // D7: DIRECT7 (centre + 6 face neighbours); otherwise DIRECT1 (the point's own voxel only).
 // PACKED: the record table is PackedRecord[] (compile time here: as a run-time choice the seven pipelined fetches
@@ -282,41 +263,8 @@ __device__ __forceinline__ void point_pairs(PairAcc& a, float x, float y, float 
     return;
   }
   int slot[7];
-#ifdef NDT_XROW
-  // The centre cell and its two x-neighbours are adjacent ints of the index grid: ONE 12-byte load instead of three
-  // 4-byte ones (five vector-memory instructions per point instead of seven; the grid is readable four ints beyond
-  // either end, IndexGrid in ndt_api.hip).  The +-x probes are classified on their own (same f32 arithmetic as ever),
-  // so a probe whose cell is not the one next to the centre's -- rounding at a voxel face, or a centre outside the
-  // box -- still takes its own load.
-  {
-    struct alignas(4) Int3 { int a, b, c; };
-    const bool row = finite && cell[0] >= 0;
-    Int3 v;
-    v.a = v.b = v.c = -1;
-    if (row) v = *reinterpret_cast<const Int3*>(cell2leaf + (cell[0] - 1));
-    slot[0] = row ? v.b : -1;
-#pragma unroll
-    for (int k = 1; k < 3; ++k) {
-      const int off = cell[k] - (cell[0] - 1);
-      const bool have = finite && cell[k] >= 0;
-      const bool in_row = row && have && off >= 0 && off <= 2;
-      slot[k] = in_row ? (off == 0 ? v.a : (off == 1 ? v.b : v.c)) : -1;
-      if (have && !in_row) slot[k] = cell2leaf[cell[k]];
-    }
-#pragma unroll
-    for (int k = 3; k < 7; ++k) slot[k] = (finite && cell[k] >= 0) ? cell2leaf[cell[k]] : -1;
-  }
-#else
 #pragma unroll
   for (int k = 0; k < 7; ++k) slot[k] = (finite && cell[k] >= 0) ? cell2leaf[cell[k]] : -1;
-#endif
-#if defined(NDT_ABL) && NDT_ABL == 1  // ablation: grid loads kept, no records / pair math
-#pragma unroll
-  for (int k = 0; k < 7; ++k) slot[k] = slot[k] == 0x7fffffff ? 0 : -1;
-#elif defined(NDT_ABL) && NDT_ABL == 2  // ablation: no grid loads either
-#pragma unroll
-  for (int k = 0; k < 7; ++k) slot[k] = cell[k] == 0x7fffffff ? 0 : -1;
-#endif
   // Fully predicated: an absent neighbour reads record 0 (a wave-wide broadcast) and is
   // masked out, so the unrolled pairs carry no exec-mask splits and no accumulator merges.
   // Records are fetched in two batches (4 + 3) so a point pays two L2 round trips for its
@@ -327,100 +275,25 @@ __device__ __forceinline__ void point_pairs(PairAcc& a, float x, float y, float 
   // profiles/r03_step_ab_summer_depth.txt: no difference in wall time per evaluation, 0.7 us less per
   // ordinary launch by HIP events).  The scheduling fences keep the compiler from sinking the loads
   // back to their first use (it otherwise serialises seven L2 round trips per point).
-#if defined(NDT_LDS_STAGE)
-  // EXPERIMENT (north_star's "LDS staging of neighbour-voxel covariances", per wave): the 64 points of a wave are
-  // neighbours along the scan, so for a given probe k their 64 leaf slots take only a handful of distinct values.
-  // The wave lists the distinct ones (up to 12 per probe), fetches each record ONCE -- one global_load_lds_dwordx4
-  // per probe, lane 5 j + c carrying the c-th 16-byte piece of the j-th listed record straight into the wave's LDS
-  // stage -- and every lane then reads its neighbours' records from LDS: 7 vector-memory instructions per wave on
-  // 7 x ~6 distinct lines instead of 35 on 35 x ~6.  Same records, same order of pair updates: the same bits.
-  if (!PACKED) {
-    typedef __attribute__((address_space(1))) const void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
-    constexpr int CAPR = 12;
-    __shared__ __align__(16) unsigned char lds_stage[(MAX_BLOCK / 64) * 7 * CAPR * 80];
-    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
-    unsigned char* wbase = lds_stage + (size_t)wave * (7 * CAPR * 80);
-    int idx[7], nk[7];
-    const int jrec = lane / 5, piece = lane - 5 * jrec;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-      const int my = slot[k];
-      int id = -1, n = 0, vlist = 0;
-      unsigned long long todo = __ballot(my >= 0);
-      while (todo != 0ull && n < CAPR) {   // wave-uniform
-        const int leader = __ffsll((long long)todo) - 1;
-        const int val = __builtin_amdgcn_readlane(my, leader);
-        const bool mine = my == val;
-        id = mine ? n : id;
-        vlist = lane == n ? val : vlist;
-        todo &= ~__ballot(mine);
-        ++n;
-      }
-      idx[k] = id;
-      nk[k] = n;
-      const int rj = __shfl(vlist, jrec);
-      if (lane < 5 * n) {
-        const char* g = reinterpret_cast<const char*>(rec + rj) + 16 * piece;
-        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(wbase + k * (CAPR * 80)), 16, 0, 0);
-      }
-    }
-    __builtin_amdgcn_s_waitcnt(0);   // every staged record has landed in this wave's LDS
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-      if (nk[k] == 0) continue;      // uniform: no lane of the wave has this neighbour
-      const bool present = slot[k] >= 0;
-      VoxelRecord r;
-      if (present && idx[k] < 0) {   // more than CAPR distinct leaves in the wave for this probe: own fetch
-        r = rec[slot[k]];
-      } else {
-        r = *reinterpret_cast<const VoxelRecord*>(wbase + k * (CAPR * 80) + (idx[k] > 0 ? idx[k] : 0) * 80);
-      }
-      pair_update<MODE>(a, r, xt, yt, zt, ec, present);
-    }
-    return;
-  }
-#endif
-#ifndef NDT_PAIR_DEPTH4
-  const VoxelRecord r0 = NDT_LOAD_REC(slot[0]);
-  const VoxelRecord r1 = NDT_LOAD_REC(slot[1]);
-  const VoxelRecord r2 = NDT_LOAD_REC(slot[2]);
+  const VoxelRecord r0 = fetch_record(rec, slot[0] >= 0 ? slot[0] : 0, PACKED);
+  const VoxelRecord r1 = fetch_record(rec, slot[1] >= 0 ? slot[1] : 0, PACKED);
+  const VoxelRecord r2 = fetch_record(rec, slot[2] >= 0 ? slot[2] : 0, PACKED);
   __builtin_amdgcn_sched_barrier(0);
   pair_update<MODE>(a, r0, xt, yt, zt, ec, slot[0] >= 0);
-  const VoxelRecord r3 = NDT_LOAD_REC(slot[3]);
+  const VoxelRecord r3 = fetch_record(rec, slot[3] >= 0 ? slot[3] : 0, PACKED);
   __builtin_amdgcn_sched_barrier(0);
   pair_update<MODE>(a, r1, xt, yt, zt, ec, slot[1] >= 0);
-  const VoxelRecord r4 = NDT_LOAD_REC(slot[4]);
+  const VoxelRecord r4 = fetch_record(rec, slot[4] >= 0 ? slot[4] : 0, PACKED);
   __builtin_amdgcn_sched_barrier(0);
   pair_update<MODE>(a, r2, xt, yt, zt, ec, slot[2] >= 0);
-  const VoxelRecord r5 = NDT_LOAD_REC(slot[5]);
+  const VoxelRecord r5 = fetch_record(rec, slot[5] >= 0 ? slot[5] : 0, PACKED);
   __builtin_amdgcn_sched_barrier(0);
   pair_update<MODE>(a, r3, xt, yt, zt, ec, slot[3] >= 0);
-  const VoxelRecord r6 = NDT_LOAD_REC(slot[6]);
+  const VoxelRecord r6 = fetch_record(rec, slot[6] >= 0 ? slot[6] : 0, PACKED);
   __builtin_amdgcn_sched_barrier(0);
   pair_update<MODE>(a, r4, xt, yt, zt, ec, slot[4] >= 0);
   pair_update<MODE>(a, r5, xt, yt, zt, ec, slot[5] >= 0);
   pair_update<MODE>(a, r6, xt, yt, zt, ec, slot[6] >= 0);
-#else  // four in flight (rounds 1-2): 8-12 bytes of scratch per lane in the full-Hessian / Gauss-Newton DIRECT7 kernels
-  const VoxelRecord r0 = rec[slot[0] >= 0 ? slot[0] : 0];
-  const VoxelRecord r1 = rec[slot[1] >= 0 ? slot[1] : 0];
-  const VoxelRecord r2 = rec[slot[2] >= 0 ? slot[2] : 0];
-  const VoxelRecord r3 = rec[slot[3] >= 0 ? slot[3] : 0];
-  __builtin_amdgcn_sched_barrier(0);
-  pair_update<MODE>(a, r0, xt, yt, zt, ec, slot[0] >= 0);
-  const VoxelRecord r4 = rec[slot[4] >= 0 ? slot[4] : 0];
-  __builtin_amdgcn_sched_barrier(0);
-  pair_update<MODE>(a, r1, xt, yt, zt, ec, slot[1] >= 0);
-  const VoxelRecord r5 = rec[slot[5] >= 0 ? slot[5] : 0];
-  __builtin_amdgcn_sched_barrier(0);
-  pair_update<MODE>(a, r2, xt, yt, zt, ec, slot[2] >= 0);
-  const VoxelRecord r6 = rec[slot[6] >= 0 ? slot[6] : 0];
-  __builtin_amdgcn_sched_barrier(0);
-  pair_update<MODE>(a, r3, xt, yt, zt, ec, slot[3] >= 0);
-  pair_update<MODE>(a, r4, xt, yt, zt, ec, slot[4] >= 0);
-  pair_update<MODE>(a, r5, xt, yt, zt, ec, slot[5] >= 0);
-  pair_update<MODE>(a, r6, xt, yt, zt, ec, slot[6] >= 0);
-#endif
 }
 
 // FLANN's L2_Simple in f32, accumulated x, y, z, strict `<` (ref: radiusSearch,
@@ -538,10 +411,7 @@ __device__ __forceinline__ void point_pairs_kd(PairAcc& a, float x, float y, flo
     // cell, nine cells in flight at a time): a point has 9-11 occupied cells around it but only 3-4
     // centroids within one leaf size, and the wave runs max-over-lanes(listed) full pair updates --
     // 7 instead of 15 on C3.  Same f32 test on the same operands, same (cell) order: the same pairs.
-#ifndef NDT_KD_BATCH
-#define NDT_KD_BATCH 9   // centroids in flight per lane (A/B: 14 = two round trips instead of three)
-#endif
-    constexpr int KB = NDT_KD_BATCH;
+    constexpr int KB = 9;   // centroids in flight per lane (14 = two round trips instead of three: no faster, profiles/r04_kd_batch_ab.txt)
 #pragma unroll
     for (int n0 = 0; n0 < KD_CELLS; n0 += KB) {
       float4 m[KB];   // the f32 centroids (one 16-byte load per cell; two loads of the record's f64 mean before round 3)
@@ -659,15 +529,52 @@ __device__ unsigned long long g_mstamps[4096 * 2];  // pre-launched launches tha
       g_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime();               \
     }                                                                                  \
   } while (0)
+// ... and per WAVE (round 5): lane 0 of every wave of the first WS_BLOCKS blocks keeps WS_N stamps in LDS (a ds_write
+// per stamp, no vector-memory traffic, no wait on outstanding loads or stores unless the stamp asks for it) and
+// flushes them to the side buffer once, behind the block's row store.  Stamps: 0 entry, 1 xyz loaded, 2 pairs done,
+// 3 angle tables visible (barrier), 4 expanded, 5 wave reduce-scatter done, 6 cross-wave barrier passed,
+// 7 row store issued (wave 0) / leaving (others), 8 row store acknowledged (wave 0).  The summing block: 5 polling
+// starts, 6 this wave has all its slots, 7 barrier passed, 8 result store issued, 9 acknowledged; and per poll trip of
+// its wave 0 {time, lanes still missing a slot}.
+constexpr int WS_BLOCKS = 512, WS_WAVES = 16, WS_N = 10, WS_TRIPS = 64;
+__device__ unsigned long long g_wstamps[WS_BLOCKS * WS_WAVES * WS_N];
+__device__ unsigned int g_whwid[WS_BLOCKS * WS_WAVES];
+__device__ unsigned long long g_sumtrips[WS_TRIPS * 2 + 1];
+__device__ __forceinline__ unsigned long long* ws_row() {
+  __shared__ unsigned long long s_ws[WS_WAVES][WS_N];
+  return s_ws[threadIdx.x >> 6];
+}
+#define NDT_WSTAMP(k)                                                                  \
+  do {                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    if ((threadIdx.x & 63u) == 0 && blockIdx.y == 0) ws_row()[(k)] = __builtin_amdgcn_s_memrealtime(); \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+  } while (0)
+#define NDT_WSTAMP_DRAINED(k) do { __builtin_amdgcn_s_waitcnt(0); NDT_WSTAMP(k); } while (0)
+__device__ __forceinline__ void ws_flush() {
+  if ((threadIdx.x & 63u) == 0 && blockIdx.y == 0 && blockIdx.x < WS_BLOCKS) {
+    const unsigned long long* r = ws_row();
+    unsigned long long* o = g_wstamps + ((size_t)blockIdx.x * WS_WAVES + (threadIdx.x >> 6)) * WS_N;
+#pragma unroll
+    for (int k = 0; k < WS_N; ++k) o[k] = r[k];
+    g_whwid[blockIdx.x * WS_WAVES + (threadIdx.x >> 6)] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+  }
+}
+__device__ __forceinline__ void ws_clear() {
+  if ((threadIdx.x & 63u) == 0) {
+    unsigned long long* r = ws_row();
+#pragma unroll
+    for (int k = 0; k < WS_N; ++k) r[k] = 0ull;
+  }
+}
 #else
 #define NDT_STAMP(k) do {} while (0)
+#define NDT_WSTAMP(k) do {} while (0)
+#define NDT_WSTAMP_DRAINED(k) do {} while (0)
 #endif
 
-#ifndef NDT_DERIV_SUMMER_DEFAULT
-#define NDT_DERIV_SUMMER_DEFAULT 1
-#endif
 constexpr int NGROUPS = 32;          // second-level fan-in (only for grids above SINGLE_LEVEL_MAX rows)
-constexpr int SINGLE_LEVEL_MAX_DEFAULT = 2048;  // rows one block adds directly
+// (rows one block adds directly: ndt_tuning::deriv_single_level_max, default 2048)
 constexpr int COUNTERS_PER_POSE = 1 + NGROUPS;
 constexpr int MAX_WAVES = MAX_BLOCK / 64;
 constexpr int MAX_COLS = MAX_BLOCK / 32;  // row-parallel lanes of the final sum
@@ -775,6 +682,9 @@ __device__ __forceinline__ void sum_rows(__amdgpu_buffer_rsrc_t rows, unsigned i
       if (b0 + k * ncols < end) missing |= 1u << k;
     }
     const unsigned long long t_wait0 = __builtin_amdgcn_s_memrealtime();
+#ifdef NDT_STAMPS
+    int ws_trip = 0;
+#endif
     for (;;) {
       // EVERY load of a slot sits behind this clobber, inside the loop: with a copy of the first batch in front of
       // the loop the compiler took the in-loop load of slot 0 for the same value and never re-read it (the
@@ -787,6 +697,17 @@ __device__ __forceinline__ void sum_rows(__amdgpu_buffer_rsrc_t rows, unsigned i
 #pragma unroll
       for (int k = 0; k < SUM_BATCH; ++k)
         if (t[k].x == tag_lo && t[k].y == tag_hi) missing &= ~(1u << k);
+#ifdef NDT_STAMPS
+      if (threadIdx.x < 64 && blockIdx.y == 0 && b0 == first + c) {   // wave 0 of the summing block, per poll trip
+        const unsigned long long still = __ballot(missing != 0u);
+        if (threadIdx.x == 0 && ws_trip < WS_TRIPS) {
+          g_sumtrips[2 * ws_trip] = __builtin_amdgcn_s_memrealtime();
+          g_sumtrips[2 * ws_trip + 1] = (unsigned long long)__popcll(still);
+          g_sumtrips[2 * WS_TRIPS] = (unsigned long long)(ws_trip + 1);
+        }
+        ++ws_trip;
+      }
+#endif
       if (missing == 0u) break;
       if (__builtin_amdgcn_s_memrealtime() - t_wait0 > SUM_TIMEOUT_TICKS) {
         // a row that never comes (its block left without computing: a pre-launched grid whose blocks
@@ -801,8 +722,10 @@ __device__ __forceinline__ void sum_rows(__amdgpu_buffer_rsrc_t rows, unsigned i
     for (int k = 0; k < SUM_BATCH; ++k)
       s += (missing & (1u << k)) ? 0.0 : __longlong_as_double((long long)(((unsigned long long)t[k].w << 32) | t[k].z));
   }
+  NDT_WSTAMP(6);
   lds_c[c][v] = s;
   __syncthreads();
+  NDT_WSTAMP(7);
   if (threadIdx.x < EV_WORDS) {
     double t = 0.0;
     for (int k = 0; k < ncols; ++k) t += lds_c[k][threadIdx.x];
@@ -816,6 +739,7 @@ __device__ __forceinline__ void sum_rows(__amdgpu_buffer_rsrc_t rows, unsigned i
     if (plain_dst) plain_dst[threadIdx.x] = t;
     else store_slot(dst, dst_off + threadIdx.x * 16u, seq, t, dst_system);
   }
+  NDT_WSTAMP(8);
 }
 
 // Block sum of the 32 accumulator words -> one tagged row per block; the rows are added INSIDE
@@ -841,7 +765,9 @@ __device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], double
   if (threadIdx.x == 0) s_fail = 0;
   wave_reduce_scatter32(acc, lane);
   if ((lane & 1) == 0) lds_w[wave][lane >> 1] = acc[0];
+  NDT_WSTAMP(5);
   __syncthreads();
+  NDT_WSTAMP(6);
   const __amdgpu_buffer_rsrc_t rrows = slots_rsrc(rows);
   if (threadIdx.x < EV_WORDS) {
     double sum = 0.0;
@@ -852,7 +778,12 @@ __device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], double
 #endif
     store_slot(rrows, ((unsigned int)my_row * EV_WORDS + threadIdx.x) * 16u, seq, sum, false);
   }
+  NDT_WSTAMP(7);
   NDT_STAMP(4);
+#ifdef NDT_STAMPS
+  if (wave == 0) NDT_WSTAMP_DRAINED(8);
+  ws_flush();
+#endif
   if (dedicated) return;  // the summing block (summer_finish) polls the rows; this block is done
   int ngroups = 1;
   const __amdgpu_buffer_rsrc_t rgroups = slots_rsrc(group_rows);
@@ -905,10 +836,15 @@ __device__ __forceinline__ void summer_finish(double* __restrict__ rows, double*
   if (threadIdx.x == 0) s_fail = 0;
   __syncthreads();
   NDT_STAMP(5);
+  NDT_WSTAMP(5);
   sum_rows(slots_rsrc(rows), 0u, 0, nrows, seq, lds_c, slots_rsrc(host_slots), 0u, true, host_slots ? nullptr : out, &s_fail,
            xi, xround);
   NDT_STAMP(6);
   NDT_STAMP(7);
+#ifdef NDT_STAMPS
+  NDT_WSTAMP_DRAINED(9);
+  ws_flush();
+#endif
 }
 
 // The explicit arguments of k_derivatives as the kernel-argument segment lays them out
@@ -970,6 +906,8 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
   // barrier that publishes them sits behind the memory-latency part of the kernel.
   NDT_STAMP(0);
 #ifdef NDT_STAMPS
+  ws_clear();
+  NDT_WSTAMP(0);
   if (threadIdx.x == 0 && blockIdx.x < 4096 && blockIdx.y == 0) {
     g_hwid[blockIdx.x * 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
     g_hwid[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); // HW_REG_XCC_ID
@@ -1120,29 +1058,26 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
     extern __shared__ int lds_kd_list[];  // KD_CELLS x blockDim.x leaf indices
     if (!(MBOX && ec.mbox_preload) && i < n) { x = sx[i]; y = sy[i]; z = sz[i]; }
     NDT_STAMP(1);
+    NDT_WSTAMP_DRAINED(1);
     point_pairs_kd<MODE, NB == 2 || NB == 4, NB == 4>(a, x, y, z, g, cell2leaf, rec, cent, rt, ec, lds_kd_list, i < n);
   } else if (i < n) {
     if (!(MBOX && ec.mbox_preload)) { x = sx[i]; y = sy[i]; z = sz[i]; }
     NDT_STAMP(1);
-#if !(defined(NDT_ABL) && NDT_ABL == 3)
+    NDT_WSTAMP_DRAINED(1);
     point_pairs<MODE, NB == 1 || NB == 6, NB >= 5>(a, x, y, z, g, cell2leaf, rec, rt, ec);
-#endif
   }
   NDT_STAMP(2);
+  NDT_WSTAMP(2);
   if (!MBOX) {  // (a pre-launched kernel has had its tables in LDS since it was released)
     if (threadIdx.x < 69) tab.jang[threadIdx.x] = tab_word;  // runs on into hang[]: the two arrays are contiguous
     __syncthreads();  // angle tables visible
   }
+  NDT_WSTAMP(3);
   double acc[EV_WORDS];
-#if defined(NDT_ABL) && NDT_ABL == 3  // ablation: launch + reduction only
-#pragma unroll
-  for (int v = 0; v < EV_WORDS; ++v) acc[v] = 0.0;
-  acc[0] = (double)(x + rt.R[0] + tab.jang[3]);
-#else
   if (a.npairs == 0) { x = 0.0f; y = 0.0f; z = 0.0f; }  // a skipped (e.g. non-finite) point must expand to exact zeros
   expand_point<MODE>(acc, a, x, y, z, tab);
-#endif
   NDT_STAMP(3);
+  NDT_WSTAMP(4);
   double* base = partials + (size_t)blockIdx.y * (gridDim.x + NGROUPS) * ROW_WORDS;
   block_reduce_finish(acc, base + (size_t)NGROUPS * ROW_WORDS, base, counters + blockIdx.y * COUNTERS_PER_POSE,
                       out + (size_t)blockIdx.y * EV_WORDS,
@@ -1184,6 +1119,22 @@ int derivs_read_stamps(unsigned long long* out, int nblocks) {
 #endif
 }
 
+// per-wave stamps of the last launch: out = [nblocks][16 waves][10 stamps] u64, then [nblocks][16] hw ids packed as u32
+// pairs, then the summing block's poll trips: 64 x {time, lanes still missing} + the trip count
+int derivs_read_wave_stamps(unsigned long long* out, int nblocks) {
+#ifdef NDT_STAMPS
+  if (nblocks > WS_BLOCKS) nblocks = WS_BLOCKS;
+  const size_t nw = (size_t)nblocks * WS_WAVES;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wstamps), sizeof(unsigned long long) * nw * WS_N) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out + nw * WS_N, HIP_SYMBOL(g_whwid), sizeof(unsigned int) * nw) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out + nw * WS_N + nw / 2, HIP_SYMBOL(g_sumtrips), sizeof(unsigned long long) * (2 * WS_TRIPS + 1)) != hipSuccess) return -1;
+  return nblocks;
+#else
+  (void)out; (void)nblocks;
+  return 0;
+#endif
+}
+
 // Threads per block.  512 (8 waves) measured best on MI355X from 50k to 4M points: with
 // 126 VGPRs two such blocks fill a CU (4 waves/SIMD); smaller blocks multiply the partial
 // rows of the in-kernel final sum, larger ones make every wave wait on wider barriers
@@ -1192,40 +1143,21 @@ int derivs_read_stamps(unsigned long long* out, int nblocks) {
 // the grid is at most one block per CU (256 CUs) -- 200 000 points: 832 threads, 241 blocks --
 // which keeps every CU at <= 4 waves/SIMD and leaves <= 256 rows for the final sum
 // (profiles/r02_block_sweep.txt: 16.6 us at 832, 17.2 at 1024, 20.3 at 512).
-// NDT_DERIV_BLOCK overrides it for tuning.
+// ndt_tuning::deriv_block overrides it for tuning.
 // (the compute units of the handle's device come in as `cus`: two engines on differently partitioned devices in one
 // process must not share a block shape)
 static inline int cus_or_default(int cus) { return cus > 0 ? cus : 256; }
 
 namespace {
-int deriv_single_level_max() {
-  static const int slm = [] {
-    const char* e = getenv("NDT_DERIV_SINGLE_LEVEL_MAX");  // tuning knob
-    int v = e ? atoi(e) : 0;
-    return v > 0 ? v : SINGLE_LEVEL_MAX_DEFAULT;
-  }();
-  return slm;
-}
-int deriv_fixed_summer() {
-  static const int summer = [] {
-    const char* e = getenv("NDT_DERIV_SUMMER");  // A/B knob: 0 = ticket + last block, 1 = a fixed block polls the rows
-    return e ? atoi(e) : NDT_DERIV_SUMMER_DEFAULT;
-  }();
-  return summer;
-}
-bool deriv_dedicated_enabled() {
-  static const bool on = [] { const char* e = getenv("NDT_DERIV_DEDICATED"); return !(e && atoi(e) == 0); }();  // A/B knob
-  return on;
-}
+// (ndt_tuning, include/ndt_hip.h: A/B switches, none of them read from the environment by the production library)
+int deriv_single_level_max() { return tuning().deriv_single_level_max; }
+int deriv_fixed_summer() { return tuning().deriv_summer; }       // 0 = ticket + last block, 1 = a fixed block polls the rows
+bool deriv_dedicated_enabled() { return tuning().deriv_dedicated != 0; }
 }  // namespace
 
 int derivs_block_threads(size_t n_src, int K, int cus) {
   const int g_compute_units = cus_or_default(cus);
-  static const int forced = [] {
-    const char* e = getenv("NDT_DERIV_BLOCK");  // multiple of 64, 64..1024
-    int v = e ? atoi(e) : 0;
-    return (v >= 64 && v <= MAX_BLOCK && v % 64 == 0) ? v : 0;
-  }();
+  const int forced = tuning().deriv_block;  // multiple of 64, 64..1024 (checked by ndt_set_tuning)
   if (forced) return forced;
   // (one compute unit is left to the dedicated summing block)
   const size_t kCUs = (size_t)std::max(2, g_compute_units - (deriv_dedicated_enabled() && deriv_fixed_summer() ? 1 : 0));
@@ -1297,12 +1229,12 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
   }
   // XCD-aware chunk assignment (xcd_chunk, ndt_device.h).  gfx950 has 32 compute units per XCD: 8 XCDs on a whole MI355X,
   // one in a CPX partition (nothing to do there).  Grids that are resident at once (at most one block per compute unit)
-  // take the whole row as one stripe.  NDT_DERIV_XCD: 0 = off, 1 = resident single-pose grids only (default), 2 = also
+  // take the whole row as one stripe.  ndt_tuning::deriv_xcd: 0 = off, 1 = resident single-pose grids only (default), 2 = also
   // larger grids and batched launches, in stripes of one residency round (blocks per CU from the block size: 16 waves
   // per CU).  Measured in round 4 (profiles/r04_xcd_stripes_ab.txt): the stripes LOSE -- C3 400 k / 800 k points 25.8 /
   // 40.7 us against 24.1 / 39.1 with chunk = block id, C3-wide 30.0 / 48.9 against 28.1 / 46.1, the SVN Stage-1 launch
   // (20 poses x 131 k points) 87.7 against 83.3 -- so they stay a knob.
-  static const int xcd_mode = [] { const char* e = getenv("NDT_DERIV_XCD"); return e ? atoi(e) : 1; }();  // A/B knob
+  const int xcd_mode = tuning().deriv_xcd;
   const int nxcd = std::max(1, cus / 32);
   const int point_blocks = blocks - ecl.dedicated_summer;
   const int per_cu = std::max(1, 1024 / threads);

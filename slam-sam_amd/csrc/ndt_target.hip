@@ -22,6 +22,7 @@
 //                      cell -> leaf index.
 // Compiled with -ffp-contract=off: f32 index arithmetic must round as written.
 #include "ndt_kernels.h"
+#include "ndt_tuning.h"
 
 #include <climits>
 #include <cstdlib>
@@ -2322,29 +2323,23 @@ void launch_transform_append(const float* x, const float* y, const float* z, siz
                      ox, oy, oz);
 }
 
-// Launch shapes of the build kernels that end in a "last block finishes the job" ticket; the
-// environment overrides are A/B knobs (profiles/r02_build_tickets.txt).
+// Launch shapes of the build kernels that end in a "last block finishes the job" ticket: A/B switches of ndt_tuning
+// (include/ndt_hip.h; profiles/r02_build_tickets.txt), none of them read from the environment by the production library.
 struct BuildTuning {
-  int bounds_blocks;     // NDT_BOUNDS_BLOCKS   (<= BOUNDS_BLOCKS)
-  int bounds_unroll;     // NDT_BOUNDS_UNROLL   4 | 8 (16 measured: no change)
-  int finalize_threads;  // NDT_FINALIZE_THREADS 64 | 256
-  int fused_sort;        // NDT_FUSED_SORT      0 | 1: one launch per sort digit where the cloud allows it
+  int bounds_blocks;     // <= BOUNDS_BLOCKS
+  int bounds_unroll;     // 4 | 8 (16 measured: no change)
+  int finalize_threads;  // 64 | 256
+  int fused_sort;        // 0 | 1: one launch per sort digit where the cloud allows it
 };
-const BuildTuning& build_tuning() {
-  static const BuildTuning t = [] {
-    auto env = [](const char* name, int dflt) {
-      const char* e = getenv(name);
-      return e && *e ? atoi(e) : dflt;
-    };
-    BuildTuning b;
-    b.bounds_blocks = env("NDT_BOUNDS_BLOCKS", 256);
-    if (b.bounds_blocks < 1 || b.bounds_blocks > BOUNDS_BLOCKS) b.bounds_blocks = BOUNDS_BLOCKS;
-    b.bounds_unroll = env("NDT_BOUNDS_UNROLL", 8) == 4 ? 4 : 8;
-    b.finalize_threads = env("NDT_FINALIZE_THREADS", 256) == 64 ? 64 : 256;
-    b.fused_sort = env("NDT_FUSED_SORT", 1) != 0 ? 1 : 0;
-    return b;
-  }();
-  return t;
+BuildTuning build_tuning() {
+  const ndt_tuning& t = tuning();
+  BuildTuning b;
+  b.bounds_blocks = t.bounds_blocks;
+  if (b.bounds_blocks < 1 || b.bounds_blocks > BOUNDS_BLOCKS) b.bounds_blocks = BOUNDS_BLOCKS;
+  b.bounds_unroll = t.bounds_unroll == 4 ? 4 : 8;
+  b.finalize_threads = t.finalize_threads == 64 ? 64 : 256;
+  b.fused_sort = t.fused_sort != 0 ? 1 : 0;
+  return b;
 }
 
 int bounds_rows(size_t n) {
@@ -2511,10 +2506,7 @@ hipError_t sort_cloud_fused(const float* x, const float* y, const float* z, size
 }
 
 // ---- bucketed build (two launches) ----
-bool bucket_build_enabled() {
-  static const bool on = [] { const char* e = getenv("NDT_BUCKET_BUILD"); return !(e && *e && atoi(e) == 0); }();
-  return on;
-}
+bool bucket_build_enabled() { return tuning().bucket_build != 0; }
 int bucket_build_tiles(size_t n) { return (int)((n + BK_MAXP - 1) / BK_MAXP); }
 void bucket_bounds_neutral(int out[8]) {
   for (int k = 0; k < 3; ++k) { out[k] = INT_MAX; out[3 + k] = INT_MIN; }
@@ -2549,10 +2541,10 @@ hipError_t launch_bucket_build(const float* x, const float* y, const float* z, s
 #else
   constexpr int mute_tile = -1;
 #endif
-  // NDT_BUCKET_TILE=4096 (A/B knob): 4096-point tiles when they all fit the machine at once -- 245 blocks instead of 123
+  // ndt_tuning::bucket_tile = 4096 (A/B switch): 4096-point tiles when they all fit the machine at once -- 245 blocks instead of 123
   // for 1 M points.  Measured in round 4: 23.5 us against 23.2 (profiles/r04_bucket_tile_ab.txt) -- the pass is a chain of
   // cold-start latencies, not short of parallelism -- so 8192 stays.
-  static const int tile_env = [] { const char* e = getenv("NDT_BUCKET_TILE"); return e ? atoi(e) : 0; }();
+  const int tile_env = tuning().bucket_tile;
   const int cap_tiles = compute_units < FUSED_MAX_TILES ? compute_units : FUSED_MAX_TILES;
   const int small_tiles = (int)((n + 4095) / 4096);
   if (tile_env == 4096 && small_tiles <= cap_tiles) {

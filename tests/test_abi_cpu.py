@@ -30,6 +30,45 @@ def test_library_exports_every_declared_symbol(pkg):
     assert L.ndt_abi_version() == 3
 
 
+def test_production_library_is_not_steered_by_the_environment(pkg):
+    """the production library reads four documented OPERATIONAL variables and nothing else --
+    every tuning / A-B switch is ndt_tuning (ndt_set_tuning), every fault-injection seam lives in the seams variant."""
+    import subprocess
+    out = subprocess.run(["strings", os.path.join(ROOT, "slam-sam_amd", "libndt_hip.so")], capture_output=True, text=True).stdout
+    names = sorted({ln for ln in out.splitlines() if re.fullmatch(r"NDT_[A-Z0-9_]+", ln)})
+    assert names == ["NDT_COMM_TIMEOUT_S", "NDT_HANDOFF", "NDT_PRELAUNCH", "NDT_UPLOAD_THREADS"], names
+    for src in ("ndt_api.hip", "ndt_derivs.hip", "ndt_target.hip", "ndt_comm.cpp", "ndt_repack_pool.h", "ndt_newton.cpp", "ndt_svn.cpp"):
+        txt = open(os.path.join(ROOT, "slam-sam_amd", "csrc", src)).read()
+        for m in re.finditer(r'getenv\("(NDT_[A-Z0-9_]+)"\)', txt):
+            assert m.group(1) in names or m.group(1).startswith("NDT_DEBUG_"), (src, m.group(1))
+    # (the NDT_DEBUG_* seams are compiled only with -DNDT_TEST_SEAMS)
+    seams = subprocess.run(["strings", os.path.join(ROOT, "slam-sam_amd", "libndt_hip_seams.so")], capture_output=True, text=True).stdout
+    assert "NDT_DEBUG_MUTE_ROW_AT" in seams and "NDT_DEBUG_MUTE_ROW_AT" not in out
+
+
+def test_tuning_round_trip_and_validation(pkg):
+    t0 = pkg.get_tuning()
+    assert t0["deriv_block"] == 0 and t0["deriv_summer"] == 1 and t0["deriv_dedicated"] == 1 and t0["deriv_xcd"] == 1
+    assert t0["bucket_build"] == 1 and t0["fused_sort"] == 1 and t0["speculate_first"] == 1 and t0["prelaunch_streams"] == 2
+    try:
+        assert pkg.set_tuning(deriv_block=512, fused_sort=0)["deriv_block"] == 512
+        assert pkg.get_tuning()["fused_sort"] == 0
+        for bad in (dict(deriv_block=100), dict(deriv_block=2048), dict(deriv_xcd=3), dict(bounds_unroll=5),
+                    dict(finalize_threads=128), dict(prelaunch_streams=3), dict(bucket_tile=1000), dict(deriv_single_level_max=0)):
+            with pytest.raises(pkg.NdtError):
+                pkg.set_tuning(**bad)
+        assert pkg.get_tuning()["deriv_block"] == 512       # a refused call changes nothing
+        # the environment does NOT reach the production library ...
+        os.environ["NDT_DERIV_BLOCK"] = "256"
+        assert pkg.get_tuning()["deriv_block"] == 512
+        # ... unless a harness asks the Python mirror to translate it
+        assert pkg.apply_env_tuning()["deriv_block"] == 256
+    finally:
+        os.environ.pop("NDT_DERIV_BLOCK", None)
+        pkg.set_tuning(**t0)
+    assert pkg.get_tuning() == t0
+
+
 def test_abi_signatures_have_no_torch_types():
     txt = open(os.path.join(ROOT, "include", "ndt_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)  # declarations only

@@ -428,6 +428,7 @@ import sys, numpy as np, hashlib
 sys.path.insert(0, %r)
 import __graft_entry__ as ge
 pkg = ge.load_package(); S = pkg.synth
+pkg.apply_env_tuning()   # (NDT_FUSED_SORT etc. -> ndt_set_tuning: the library itself does not read them)
 cfg = getattr(S, %r)()
 ndt = pkg.NormalDistributionsTransform(device_id=0, resolution=%r, step_size=0.1, trans_epsilon=1e-4, max_iterations=35)
 h = hashlib.sha256()

@@ -301,7 +301,7 @@ def test_first_evaluation_behind_a_deferred_device_build_changes_no_number(pkg, 
                 res.append((T.copy(), r["iterations"], r["n_evaluations"], r["score"], r["hessian"].copy()))
         out[deferred] = res
         kept, discarded = ndt.speculationCounters()
-        if deferred and os.environ.get("NDT_SPECULATE_FIRST") != "0":
+        if deferred and pkg.get_tuning()["speculate_first"] != 0:
             assert kept >= 6 and discarded == 0, (kept, discarded)   # (the first build of a handle completes inside the call)
         else:
             assert kept == 0 and discarded == 0
@@ -344,7 +344,7 @@ def test_first_evaluation_behind_a_build_that_is_refused_or_repeated(pkg, S):
             except pkg.NdtError as e:
                 res.append(("err", e.code))
         out[mode] = res
-        if mode == pkg.HANDOFF_ASYNC and os.environ.get("NDT_SPECULATE_FIRST") != "0":
+        if mode == pkg.HANDOFF_ASYNC and pkg.get_tuning()["speculate_first"] != 0:
             kept, discarded = ndt.speculationCounters()
             assert kept >= 1 and discarded >= 1, (kept, discarded)
         ndt.close()

@@ -7,7 +7,7 @@ import os, sys, time
 sys.path.insert(0, %r)
 import numpy as np
 import __graft_entry__ as ge
-pkg = ge.load_package(); S = pkg.synth
+pkg = ge.load_package(); pkg.apply_env_tuning(); S = pkg.synth
 hip = pkg.ranks.Hip(0)
 cfg = S.config_c3()
 ndt = pkg.NormalDistributionsTransform(device_id=0, resolution=0.5, step_size=0.1, trans_epsilon=1e-4, max_iterations=35)

@@ -3,7 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import __graft_entry__ as ge
-pkg = ge.load_package(); S = pkg.synth
+pkg = ge.load_package(); pkg.apply_env_tuning(); S = pkg.synth
 for cname, cfg in (("C2", S.config_c2()), ("C3", S.config_c3())):
     for mode in ("DIRECT7", "DIRECT1", "KDTREE", "DIRECT26", "MULTIGRID"):
         ndt = pkg.NormalDistributionsTransform(device_id=0, resolution=float(cfg["resolution"]), step_size=0.1,

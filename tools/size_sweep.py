@@ -4,7 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import __graft_entry__ as ge
-pkg = ge.load_package(); S = pkg.synth
+pkg = ge.load_package(); pkg.apply_env_tuning(); S = pkg.synth
 which = sys.argv[1] if len(sys.argv) > 1 else "both"
 for name, cfg in (("C3", S.config_c3() if which in ("c3", "both") else None),
                   ("C3-wide", S.config_c3_wide() if which in ("wide", "both") else None)):

@@ -3,7 +3,7 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import __graft_entry__ as ge
-pkg = ge.load_package(); S = pkg.synth
+pkg = ge.load_package(); pkg.apply_env_tuning(); S = pkg.synth
 cfg = S.config_c3()
 ndt = pkg.NormalDistributionsTransform(device_id=0, resolution=0.5, step_size=0.1, trans_epsilon=1e-4, max_iterations=0)
 ndt.setInputTarget(cfg["target"])

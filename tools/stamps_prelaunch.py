@@ -5,7 +5,7 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import __graft_entry__ as ge
-pkg = ge.load_package(); S = pkg.synth
+pkg = ge.load_package(); pkg.apply_env_tuning(); S = pkg.synth
 cfg = S.config_c3()
 if os.environ.get("NDT_STAMPS_NSRC"):   # a rank's share of the scan
     cfg["source"] = cfg["source"][:int(os.environ["NDT_STAMPS_NSRC"])]

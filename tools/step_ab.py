@@ -6,7 +6,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import __graft_entry__ as ge
-pkg = ge.load_package(); S = pkg.synth
+pkg = ge.load_package(); pkg.apply_env_tuning(); S = pkg.synth
 tag = sys.argv[1] if len(sys.argv) > 1 else ""
 hip = pkg.ranks.Hip(0)
 cfg = S.config_c3()
