@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <random>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -819,6 +820,18 @@ void fill_pose_consts(const double p[6], const float T[16], PoseConsts* pc) {
   angle_tables(p, pc->jang, pc->hang);
 }
 
+// Per-process random bits for the LDS tags of k_derivatives (ndt_derivs.hip, "finishing waves"): two processes that
+// share a device count their launch sequence numbers from the same start.
+unsigned long long process_item_salt() {
+  static const unsigned long long salt = [] {
+    std::random_device rd;
+    unsigned long long v = ((unsigned long long)rd() << 32) ^ (unsigned long long)rd();
+    v ^= (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() * 0x9E3779B97F4A7C15ull;
+    return v;
+  }();
+  return salt;
+}
+
 EvalConsts make_eval_consts(const ndt_handle* h, bool need_h) {
   EvalConsts ec{};
   gauss_constants((double)h->prm.resolution, h->prm.outlier_ratio, &ec.d1, &ec.d2);
@@ -833,6 +846,7 @@ EvalConsts make_eval_consts(const ndt_handle* h, bool need_h) {
   ec.mbox_tagged = h->mbox_tagged ? 1 : 0;
   ec.mbox_preload = h->mbox_preload ? 1 : 0;
   ec.compute_units = h->n_cus;   // block shapes and the XCD count are those of THIS handle's device (CPX partitions: 32)
+  ec.item_salt = process_item_salt();
   return ec;
 }
 
@@ -2469,6 +2483,12 @@ int ndt_debug_build_counters(const ndt_handle* h, int64_t out[3]) {
 int ndt_debug_read_stamps(unsigned long long* out, int nblocks) { return derivs_read_stamps(out, nblocks); }
 int ndt_debug_read_build_stamps(unsigned long long* out) { return build_read_stamps(out); }
 int ndt_debug_read_wave_stamps(unsigned long long* out, int nblocks) { return derivs_read_wave_stamps(out, nblocks); }
+// test seam (not in the public header): the finishing-wave tables of a block shape (k_derivatives)
+int ndt_debug_item_owners(int threads, unsigned int* owners, unsigned int* fin_waves) {
+  if (threads < 64 || threads > 1024 || threads % 64 != 0 || !owners || !fin_waves) return NDT_ERR_INVALID_ARG;
+  derivs_item_owners(threads, owners, fin_waves);
+  return NDT_OK;
+}
 
 // test seam (not in the public header): the voxel build's radix sort on caller-supplied keys;
 // vals_out receives the stable sorting permutation.  Host arrays.

@@ -95,6 +95,16 @@ __device__ __forceinline__ void pair_update(PairAcc& a, const VoxelRecord& r, fl
   }
 }
 
+// The running sums of a point are where the code says they are after every pair: without this the compiler is free to
+// postpone  S += f * icov  of all seven pairs to the end of the pair phase (it did, for the Gauss-Newton kernels, once S
+// was first used in another basic block: 42 f64 of seven records stayed live and the kernel spilled).  No instructions.
+template <int MODE>
+__device__ __forceinline__ void pin_sums(PairAcc& a) {
+  if (MODE == 1 || MODE == 2)
+    asm volatile("" : "+v"(a.S[0]), "+v"(a.S[1]), "+v"(a.S[2]), "+v"(a.S[3]), "+v"(a.S[4]), "+v"(a.S[5]));
+  if (MODE != 3) asm volatile("" : "+v"(a.w[0]), "+v"(a.w[1]), "+v"(a.w[2]));
+}
+
 __device__ __forceinline__ float dot3f(const float* m, float x, float y, float z) {
   return m[0] * x + m[1] * y + m[2] * z;
 }
@@ -106,76 +116,142 @@ struct AngleTables {
   float hang[45];  // 15x3
 };
 
-template <int MODE>
-__device__ __forceinline__ void expand_point(double acc[EV_WORDS], const PairAcc& a, float x, float y,
-                                             float z, const AngleTables& P) {
-#pragma clang fp contract(fast)
+// Where an expansion takes a point's pair sums from: the wave's own registers, or another wave's hand-over area in LDS.
+// The LDS source fetches a word WHEN it is used (volatile: neither hoisted to the top nor merged with the other use of
+// the same word) -- a finishing wave holds 32 running sums in registers across the items it expands, and 22 more
+// registers of pair sums fetched up front made a third of the kernel's instantiations spill.
+struct RegSource {
+  const PairAcc& a;
+  float x, y, z;
+  __device__ __forceinline__ double score() const { return a.score; }
+  __device__ __forceinline__ double best() const { return a.best; }
+  __device__ __forceinline__ int npairs() const { return a.npairs; }
+  __device__ __forceinline__ double w(int k) const { return a.w[k]; }
+  __device__ __forceinline__ double S(int k) const { return a.S[k]; }
+  __device__ __forceinline__ void point(float& px, float& py, float& pz) const { px = x; py = y; pz = z; }
+};
+
+// ACCUM: the words are ADDED to acc (a finishing wave expands several waves' points, see k_derivatives).
+// T: the 69 angle-table words (jang[24] then hang[45]) -- wave-uniform values the finishing waves hold in SCALAR
+// registers (angle_tables_to_sgprs), so that an expansion has no LDS reads in its dependency chains: a finishing wave
+// works on the last item of its SIMD alone, with nobody to hide a round trip behind.
+// Every product-sum is written as an explicit fma chain and contraction is OFF here: the pre-launched, the ordinary and
+// the batched instantiations must round identically (their results are compared bit for bit), which "the compiler fuses
+// what it likes" does not promise across separately compiled instantiations.
+template <int MODE, bool ACCUM, class Src>
+__device__ __forceinline__ void expand_point(double acc[EV_WORDS], const Src& src, const float* T) {
+#pragma clang fp contract(off)
+#define NDT_PUT(k, v) do { if (ACCUM) acc[(k)] += (v); else acc[(k)] = (v); } while (0)
+  // a b (+ acc)            /  a b + c d (+ acc)  /  a b + c d + e f (+ acc)
+#define NDT_T1(k, a, b) do { acc[(k)] = ACCUM ? __builtin_fma((a), (b), acc[(k)]) : (a) * (b); } while (0)
+#define NDT_T2(k, a, b, c, d) do { acc[(k)] = __builtin_fma((a), (b), ACCUM ? __builtin_fma((c), (d), acc[(k)]) : (c) * (d)); } while (0)
+#define NDT_T3(k, a, b, c, d, e, f) \
+  do { acc[(k)] = __builtin_fma((a), (b), __builtin_fma((c), (d), ACCUM ? __builtin_fma((e), (f), acc[(k)]) : (e) * (f))); } while (0)
+  // ... always added to a word that exists already
+#define NDT_A1(k, a, b) do { acc[(k)] = __builtin_fma((a), (b), acc[(k)]); } while (0)
+#define NDT_A2(k, a, b, c, d) do { acc[(k)] = __builtin_fma((a), (b), __builtin_fma((c), (d), acc[(k)])); } while (0)
+#define NDT_A3(k, a, b, c, d, e, f) \
+  do { acc[(k)] = __builtin_fma((a), (b), __builtin_fma((c), (d), __builtin_fma((e), (f), acc[(k)]))); } while (0)
   // Written for every thread: a point without neighbours (ref :592) has w = S = 0 and
   // contributes exact zeros, so no divergent skip (and no per-path zero-fill) is needed.
-  acc[EV_SCORE] = a.score;
-  acc[EV_NVTL] = a.best;
-  acc[EV_NWITH] = a.npairs > 0 ? 1.0 : 0.0;
-  acc[EV_NPAIRS] = (double)a.npairs;
-  acc[31] = 0.0;
+  {
+    const int np = src.npairs();
+    NDT_PUT(EV_SCORE, src.score());
+    NDT_PUT(EV_NVTL, src.best());
+    NDT_PUT(EV_NWITH, np > 0 ? 1.0 : 0.0);
+    NDT_PUT(EV_NPAIRS, (double)np);
+  }
+  if (!ACCUM) acc[31] = 0.0;
   if (MODE == 3) {
+    if (!ACCUM) {
 #pragma unroll
-    for (int k = 0; k < 27; ++k) acc[EV_G + k] = 0.0;
+      for (int k = 0; k < 27; ++k) acc[EV_G + k] = 0.0;
+    }
     return;
   }
 
   // point Jacobian, angular block A (3x3) from the ORIGINAL point (ref :339-363)
-  double A10 = (double)dot3f(P.jang + 0, x, y, z), A20 = (double)dot3f(P.jang + 3, x, y, z);
-  double A01 = (double)dot3f(P.jang + 6, x, y, z), A11 = (double)dot3f(P.jang + 9, x, y, z);
-  double A21 = (double)dot3f(P.jang + 12, x, y, z);
-  double A02 = (double)dot3f(P.jang + 15, x, y, z), A12 = (double)dot3f(P.jang + 18, x, y, z);
-  double A22 = (double)dot3f(P.jang + 21, x, y, z);
-  const double w0 = a.w[0], w1 = a.w[1], w2 = a.w[2];
-  acc[EV_G + 0] = w0;
-  acc[EV_G + 1] = w1;
-  acc[EV_G + 2] = w2;
-  acc[EV_G + 3] = A10 * w1 + A20 * w2;
-  acc[EV_G + 4] = A01 * w0 + A11 * w1 + A21 * w2;
-  acc[EV_G + 5] = A02 * w0 + A12 * w1 + A22 * w2;
+  float x, y, z;
+  src.point(x, y, z);
+  const float* J = T;
+  const double A10 = (double)dot3f(J + 0, x, y, z), A20 = (double)dot3f(J + 3, x, y, z);
+  const double A01 = (double)dot3f(J + 6, x, y, z), A11 = (double)dot3f(J + 9, x, y, z);
+  const double A21 = (double)dot3f(J + 12, x, y, z);
+  const double A02 = (double)dot3f(J + 15, x, y, z), A12 = (double)dot3f(J + 18, x, y, z);
+  const double A22 = (double)dot3f(J + 21, x, y, z);
+  {
+    const double w0 = src.w(0), w1 = src.w(1), w2 = src.w(2);
+    NDT_PUT(EV_G + 0, w0);
+    NDT_PUT(EV_G + 1, w1);
+    NDT_PUT(EV_G + 2, w2);
+    NDT_T2(EV_G + 3, A10, w1, A20, w2);
+    NDT_T3(EV_G + 4, A01, w0, A11, w1, A21, w2);
+    NDT_T3(EV_G + 5, A02, w0, A12, w1, A22, w2);
+  }
   if (MODE == 0) {
+    if (!ACCUM) {
 #pragma unroll
-    for (int k = 0; k < 21; ++k) acc[EV_H + k] = 0.0;
+      for (int k = 0; k < 21; ++k) acc[EV_H + k] = 0.0;
+    }
     return;
   }
 
-  const double Sxx = a.S[0], Sxy = a.S[1], Sxz = a.S[2], Syy = a.S[3], Syz = a.S[4], Szz = a.S[5];
-  // B = S * A
-  double B00 = Sxy * A10 + Sxz * A20, B01 = Sxx * A01 + Sxy * A11 + Sxz * A21,
-         B02 = Sxx * A02 + Sxy * A12 + Sxz * A22;
-  double B10 = Syy * A10 + Syz * A20, B11 = Sxy * A01 + Syy * A11 + Syz * A21,
-         B12 = Sxy * A02 + Syy * A12 + Syz * A22;
-  double B20 = Syz * A10 + Szz * A20, B21 = Sxz * A01 + Syz * A11 + Szz * A21,
-         B22 = Sxz * A02 + Syz * A12 + Szz * A22;
-  double* H = acc + EV_H;
-  // row 0: H00..H05 ; row 1: H11..H15 ; row 2: H22..H25
-  H[0] = Sxx; H[1] = Sxy; H[2] = Sxz; H[3] = B00; H[4] = B01; H[5] = B02;
-  H[6] = Syy; H[7] = Syz; H[8] = B10; H[9] = B11; H[10] = B12;
-  H[11] = Szz; H[12] = B20; H[13] = B21; H[14] = B22;
-  // rotational block A^T S A (+ second-derivative term, full Hessian only)
-  double R33 = A10 * B10 + A20 * B20;
-  double R34 = A10 * B11 + A20 * B21;
-  double R35 = A10 * B12 + A20 * B22;
-  double R44 = A01 * B01 + A11 * B11 + A21 * B21;
-  double R45 = A01 * B02 + A11 * B12 + A21 * B22;
-  double R55 = A02 * B02 + A12 * B12 + A22 * B22;
-  if (MODE == 1) {
-    // ref :369-394 layout of the 15 second-derivative rows; term 3 of :479-489
-    const float* h = P.hang;
-    R33 += w1 * (double)dot3f(h + 0, x, y, z) + w2 * (double)dot3f(h + 3, x, y, z);
-    R34 += w1 * (double)dot3f(h + 6, x, y, z) + w2 * (double)dot3f(h + 9, x, y, z);
-    R35 += w1 * (double)dot3f(h + 12, x, y, z) + w2 * (double)dot3f(h + 15, x, y, z);
-    R44 += w0 * (double)dot3f(h + 18, x, y, z) + w1 * (double)dot3f(h + 21, x, y, z) +
-           w2 * (double)dot3f(h + 24, x, y, z);
-    R45 += w0 * (double)dot3f(h + 27, x, y, z) + w1 * (double)dot3f(h + 30, x, y, z) +
-           w2 * (double)dot3f(h + 33, x, y, z);
-    R55 += w0 * (double)dot3f(h + 36, x, y, z) + w1 * (double)dot3f(h + 39, x, y, z) +
-           w2 * (double)dot3f(h + 42, x, y, z);
+  // B = S A row by row, every row consumed at once -- H's translation x rotation block takes it as it is, the rotation
+  // block A^T S A = A^T B collects A(i, .) x B(i, .) -- so that three words of B are live at a time, not nine.  A(0, 0) = 0.
+  {
+    const double Sxx = src.S(0), Sxy = src.S(1), Sxz = src.S(2);
+    const double B00 = __builtin_fma(Sxy, A10, Sxz * A20), B01 = __builtin_fma(Sxx, A01, __builtin_fma(Sxy, A11, Sxz * A21)),
+                 B02 = __builtin_fma(Sxx, A02, __builtin_fma(Sxy, A12, Sxz * A22));
+    NDT_PUT(EV_H + 0, Sxx); NDT_PUT(EV_H + 1, Sxy); NDT_PUT(EV_H + 2, Sxz);
+    NDT_PUT(EV_H + 3, B00); NDT_PUT(EV_H + 4, B01); NDT_PUT(EV_H + 5, B02);
+    NDT_T1(EV_H + 18, A01, B01); NDT_T1(EV_H + 19, A01, B02); NDT_T1(EV_H + 20, A02, B02);
   }
-  H[15] = R33; H[16] = R34; H[17] = R35; H[18] = R44; H[19] = R45; H[20] = R55;
+  {
+    const double Sxy = src.S(1), Syy = src.S(3), Syz = src.S(4);
+    const double B10 = __builtin_fma(Syy, A10, Syz * A20), B11 = __builtin_fma(Sxy, A01, __builtin_fma(Syy, A11, Syz * A21)),
+                 B12 = __builtin_fma(Sxy, A02, __builtin_fma(Syy, A12, Syz * A22));
+    NDT_PUT(EV_H + 6, Syy); NDT_PUT(EV_H + 7, Syz);
+    NDT_PUT(EV_H + 8, B10); NDT_PUT(EV_H + 9, B11); NDT_PUT(EV_H + 10, B12);
+    NDT_T1(EV_H + 15, A10, B10); NDT_T1(EV_H + 16, A10, B11); NDT_T1(EV_H + 17, A10, B12);
+    NDT_A1(EV_H + 18, A11, B11); NDT_A1(EV_H + 19, A11, B12); NDT_A1(EV_H + 20, A12, B12);
+  }
+  {
+    const double Sxz = src.S(2), Syz = src.S(4), Szz = src.S(5);
+    const double B20 = __builtin_fma(Syz, A10, Szz * A20), B21 = __builtin_fma(Sxz, A01, __builtin_fma(Syz, A11, Szz * A21)),
+                 B22 = __builtin_fma(Sxz, A02, __builtin_fma(Syz, A12, Szz * A22));
+    NDT_PUT(EV_H + 11, Szz);
+    NDT_PUT(EV_H + 12, B20); NDT_PUT(EV_H + 13, B21); NDT_PUT(EV_H + 14, B22);
+    NDT_A1(EV_H + 15, A20, B20); NDT_A1(EV_H + 16, A20, B21); NDT_A1(EV_H + 17, A20, B22);
+    NDT_A1(EV_H + 18, A21, B21); NDT_A1(EV_H + 19, A21, B22); NDT_A1(EV_H + 20, A22, B22);
+  }
+  if (MODE == 1) {
+    // + second-derivative term, full Hessian only (ref :369-394 layout of the 15 rows; term 3 of :479-489)
+    const float* h = T + 24;
+    const double w0 = src.w(0), w1 = src.w(1), w2 = src.w(2);
+    NDT_A2(EV_H + 15, w1, (double)dot3f(h + 0, x, y, z), w2, (double)dot3f(h + 3, x, y, z));
+    NDT_A2(EV_H + 16, w1, (double)dot3f(h + 6, x, y, z), w2, (double)dot3f(h + 9, x, y, z));
+    NDT_A2(EV_H + 17, w1, (double)dot3f(h + 12, x, y, z), w2, (double)dot3f(h + 15, x, y, z));
+    NDT_A3(EV_H + 18, w0, (double)dot3f(h + 18, x, y, z), w1, (double)dot3f(h + 21, x, y, z), w2, (double)dot3f(h + 24, x, y, z));
+    NDT_A3(EV_H + 19, w0, (double)dot3f(h + 27, x, y, z), w1, (double)dot3f(h + 30, x, y, z), w2, (double)dot3f(h + 33, x, y, z));
+    NDT_A3(EV_H + 20, w0, (double)dot3f(h + 36, x, y, z), w1, (double)dot3f(h + 39, x, y, z), w2, (double)dot3f(h + 42, x, y, z));
+  }
+#undef NDT_A3
+#undef NDT_A2
+#undef NDT_A1
+#undef NDT_T3
+#undef NDT_T2
+#undef NDT_T1
+#undef NDT_PUT
+}
+
+// The 69 table words out of LDS into scalar registers: lane k fetches word k (and word 64 + k), then one v_readlane per word.
+__device__ __forceinline__ void angle_tables_to_sgprs(float T[69], const AngleTables& tab, int lane) {
+  const float* w = tab.jang;   // runs on into hang[]: the two arrays are contiguous
+  const float a = w[lane], b = w[64 + (lane < 5 ? lane : 0)];
+#pragma unroll
+  for (int k = 0; k < 64; ++k) T[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), k));
+#pragma unroll
+  for (int k = 0; k < 5; ++k) T[64 + k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), k));
 }
 
 struct RigidRT {
@@ -280,20 +356,27 @@ __device__ __forceinline__ void point_pairs(PairAcc& a, float x, float y, float 
   const VoxelRecord r2 = fetch_record(rec, slot[2] >= 0 ? slot[2] : 0, PACKED);
   __builtin_amdgcn_sched_barrier(0);
   pair_update<MODE>(a, r0, xt, yt, zt, ec, slot[0] >= 0);
+  pin_sums<MODE>(a);
   const VoxelRecord r3 = fetch_record(rec, slot[3] >= 0 ? slot[3] : 0, PACKED);
   __builtin_amdgcn_sched_barrier(0);
   pair_update<MODE>(a, r1, xt, yt, zt, ec, slot[1] >= 0);
+  pin_sums<MODE>(a);
   const VoxelRecord r4 = fetch_record(rec, slot[4] >= 0 ? slot[4] : 0, PACKED);
   __builtin_amdgcn_sched_barrier(0);
   pair_update<MODE>(a, r2, xt, yt, zt, ec, slot[2] >= 0);
+  pin_sums<MODE>(a);
   const VoxelRecord r5 = fetch_record(rec, slot[5] >= 0 ? slot[5] : 0, PACKED);
   __builtin_amdgcn_sched_barrier(0);
   pair_update<MODE>(a, r3, xt, yt, zt, ec, slot[3] >= 0);
+  pin_sums<MODE>(a);
   const VoxelRecord r6 = fetch_record(rec, slot[6] >= 0 ? slot[6] : 0, PACKED);
   __builtin_amdgcn_sched_barrier(0);
   pair_update<MODE>(a, r4, xt, yt, zt, ec, slot[4] >= 0);
+  pin_sums<MODE>(a);
   pair_update<MODE>(a, r5, xt, yt, zt, ec, slot[5] >= 0);
+  pin_sums<MODE>(a);
   pair_update<MODE>(a, r6, xt, yt, zt, ec, slot[6] >= 0);
+  pin_sums<MODE>(a);
 }
 
 // FLANN's L2_Simple in f32, accumulated x, y, z, strict `<` (ref: radiusSearch,
@@ -326,7 +409,7 @@ template <int MODE, bool RADIUS, bool CHAIN>
 __device__ __forceinline__ void point_pairs_kd(PairAcc& a, float x, float y, float z, const GridGeom& g,
                                                const int* __restrict__ cell2leaf,
                                                const VoxelRecord* __restrict__ rec, const float4* __restrict__ cent,
-                                               const RigidRT& P, const EvalConsts& ec, int* __restrict__ lds_list,
+                                               const RigidRT& P, const EvalConsts& ec, int* __restrict__ lds_list /* the wave's own KD_CELLS x 64 ints */,
                                                bool active) {
   a.w[0] = a.w[1] = a.w[2] = 0.0;
 #pragma unroll
@@ -366,8 +449,10 @@ __device__ __forceinline__ void point_pairs_kd(PairAcc& a, float x, float y, flo
       slot[3 * r + 2] = (rowok & xin2) ? v.c : -1;
     }
   }
-  // column `threadIdx.x` of lds_list[KD_CELLS][blockDim.x]: conflict-free for a wave
-  const int stride = (int)blockDim.x;
+  // column `lane` of the wave's own lds_list[KD_CELLS][64]: conflict-free, and private to the wave (it becomes the
+  // wave's hand-over area to the finishing waves once the pairs are done, see k_derivatives)
+  constexpr int stride = 64;
+  const int kd_lane = (int)(threadIdx.x & 63u);
   int count = 0;
   bool filtered = false;  // the LDS column holds leaves that already passed the distance test
   if (RADIUS && CHAIN) {
@@ -392,7 +477,7 @@ __device__ __forceinline__ void point_pairs_kd(PairAcc& a, float x, float y, flo
           d = d + ey * ey;
           d = d + ez * ez;
           if (d < ec.kd_radius2) {
-            if (count < KD_CELLS) { lds_list[count * stride + (int)threadIdx.x] = sl; ++count; }
+            if (count < KD_CELLS) { lds_list[count * stride + kd_lane] = sl; ++count; }
             else overflow = true;
           }
           sl = __float_as_int(c.w);
@@ -427,7 +512,7 @@ __device__ __forceinline__ void point_pairs_kd(PairAcc& a, float x, float y, flo
         // (no branch: the slot is stored at position `count` whether it is a neighbour or not -- the next cell overwrites
         // a position that was not taken, and positions >= count are never read; KDTREE -0.2 ... -0.5 us per launch)
         const int in = (int)((unsigned int)(slot[n0 + q] >= 0) & (unsigned int)(d < ec.kd_radius2));
-        lds_list[count * stride + (int)threadIdx.x] = slot[n0 + q];
+        lds_list[count * stride + kd_lane] = slot[n0 + q];
         count += in;
       }
     }
@@ -435,34 +520,41 @@ __device__ __forceinline__ void point_pairs_kd(PairAcc& a, float x, float y, flo
 #pragma unroll
     for (int n = 0; n < KD_CELLS; ++n) {
       if (slot[n] >= 0) {   // (DIRECT26 keeps the branch: 27 unconditional stores cost it 0.5 us, profiles/r04_kd_mask_ab.txt)
-        lds_list[count * stride + (int)threadIdx.x] = slot[n];
+        lds_list[count * stride + kd_lane] = slot[n];
         ++count;
       }
     }
   }
   // wave-uniform trip count (the lanes of a wave only read their own column: no barrier needed)
-  int trips = count;
+  // (count <= KD_CELLS = 27: five ballots find the maximum bit by bit and leave it in a SCALAR register; the butterfly of
+  // six shuffles that stood here shared its lane-address arithmetic with the wave reduction at the end of the kernel,
+  // and the compiler kept those addresses in registers -- or spilled them -- across the whole pair loop)
+  int trips = 0;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) trips = max(trips, __shfl_xor(trips, off));
+  for (int b = 4; b >= 0; --b) {
+    const int c = trips | (1 << b);
+    if (__ballot(count >= c) != 0ull) trips = c;
+  }
   // (Requesting the record of trip j + 1 before trip j is worked on was measured: KDTREE 33.7 against
   // 32.0 us, DIRECT26 32.9 against 30.2 -- the other waves of the SIMD already hide a trip's round trip.)
   for (int j = 0; j < trips; ++j) {
     const bool have = j < count;
     if (!CHAIN) {
-      const int sl = have ? lds_list[j * stride + (int)threadIdx.x] : 0;
+      const int sl = have ? lds_list[j * stride + kd_lane] : 0;
       const VoxelRecord r = rec[sl];
       pair_update<MODE>(a, r, xt, yt, zt, ec, have);  // (KDTREE: only centroids within the radius were listed)
     } else if (RADIUS && filtered) {
-      const int sl = have ? lds_list[j * stride + (int)threadIdx.x] : 0;
+      const int sl = have ? lds_list[j * stride + kd_lane] : 0;
       const VoxelRecord r = rec[sl];
       pair_update<MODE>(a, r, xt, yt, zt, ec, have);
     } else {
-      int sl = have ? lds_list[j * stride + (int)threadIdx.x] : -1;
+      int sl = have ? lds_list[j * stride + kd_lane] : -1;
       while (__ballot(sl >= 0) != 0ull) {  // every lane of the wave leaves together
         const bool live = sl >= 0;
         const VoxelRecord r = rec[live ? sl : 0];
         const bool present = live && (!RADIUS || kd_within(r, xt, yt, zt, ec.kd_radius2));
         pair_update<MODE>(a, r, xt, yt, zt, ec, present);
+        pin_sums<MODE>(a);
         sl = live ? (int)r.pad : -1;
       }
     }
@@ -473,7 +565,7 @@ __device__ __forceinline__ void point_pairs_kd(PairAcc& a, float x, float y, flo
 // l holds the wave sum of word l>>1.  The two widest steps use gfx950's
 // v_permlane32_swap / v_permlane16_swap (exchange the upper half of one register with
 // the lower half of another in one instruction, no select needed); the last four
-// (8 -> 1 words) use xor shuffles.  ~100 instructions instead of 6 x 32 shuffles.
+// (8 -> 1 words) stay inside a row of 16 lanes and go through DPP.  ~100 instructions instead of 6 x 32 shuffles.
 typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
 
 template <bool SWAP32>
@@ -495,13 +587,24 @@ __device__ __forceinline__ double swap_add(double a, double b) {
   return na + nb;
 }
 
-template <int N>
-__device__ __forceinline__ void rs_step(double* a, int mask, bool upper) {
+// In-row steps: the partner's word comes through DPP (two v_mov_b32_dpp per f64, no LDS round trip -- a finishing wave
+// runs this alone on its SIMD at the end of a block, where four ds_bpermute latencies in a row were a third of the
+// reduction's time).  CTRL: row_ror:8 (lane ^ 8), row_half_mirror (lane -> 7 - lane within 8: ANY pairing of the two
+// halves serves a reduce-scatter), quad_perm [2,3,0,1] and [1,0,3,2] (lane ^ 2, lane ^ 1).
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned int lo = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)u, CTRL, 0xf, 0xf, false);
+  const unsigned int hi = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)(u >> 32), CTRL, 0xf, 0xf, false);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <int N, int CTRL>
+__device__ __forceinline__ void rs_step(double* a, bool upper) {
 #pragma unroll
   for (int i = 0; i < N / 2; ++i) {
     const double send = upper ? a[i] : a[i + N / 2];
     const double keep = upper ? a[i + N / 2] : a[i];
-    a[i] = keep + __shfl_xor(send, mask);
+    a[i] = keep + dpp_f64<CTRL>(send);
   }
 }
 
@@ -510,10 +613,107 @@ __device__ __forceinline__ void wave_reduce_scatter32(double* acc, int lane) {
   for (int i = 0; i < 16; ++i) acc[i] = swap_add<true>(acc[i], acc[i + 16]);
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = swap_add<false>(acc[i], acc[i + 8]);
-  rs_step<8>(acc, 8, (lane & 8) != 0);
-  rs_step<4>(acc, 4, (lane & 4) != 0);
-  rs_step<2>(acc, 2, (lane & 2) != 0);
-  acc[0] += __shfl_xor(acc[0], 1);
+  rs_step<8, 0x128>(acc, (lane & 8) != 0);
+  rs_step<4, 0x141>(acc, (lane & 4) != 0);
+  rs_step<2, 0x4E>(acc, (lane & 2) != 0);
+  acc[0] += dpp_f64<0xB1>(acc[0]);
+}
+
+// ---- finishing waves (round 5) ----------------------------------------------------------------------------------
+// Per-wave stamps (profiles/r05_stamps_per_wave.txt) showed what the 200 k-point launch waits for: a block's 13 waves
+// sit 4 + 3 + 3 + 3 on the SIMDs of its compute unit, every wave carried its points through pairs (~690 VALU
+// instructions), expansion (~220) and reduce-scatter (~140), and the block's row waited for the FOURTH wave of the full
+// SIMD -- 4 x 1.75 us of VALU issue behind the first memory round trips.  Now a wave hands its per-point pair sums
+// (w, S, score, best) to LDS and only FOUR finishing waves per block, one per SIMD under the hardware's round-robin
+// placement (wave i on SIMD i mod 4), expand and reduce: their own points straight from registers, the other waves'
+// from LDS, accumulated per lane in a fixed order, then ONE reduce-scatter each.
+//   * A SIMD that holds one wave more than the others finishes its pair phases last whatever happens: its finishing
+//     wave is its LAST wave, which expands its own points only -- the tail behind the last pair phase is one expansion
+//     from registers and one reduce-scatter.  Its earlier waves' points go to the other SIMDs' finishing waves.
+//   * The other SIMDs' finishing waves are their FIRST (oldest) waves: they are through their own pairs first, and
+//     the hardware issues oldest-first, so their expansions interleave with the younger waves' pair phases instead of
+//     queueing up behind them (a finishing wave that is alone on its SIMD issues one dependent instruction at a time:
+//     measured 0.9 us per expansion against 0.4 interleaved).
+// The item -> finishing wave table (EvalConsts::item_owner / fin_waves, derivs_item_owners()) balances pair phases
+// against expansions: 13 waves = SIMD loads (4 P + 1 E, 3 P + 4 E, 3 P + 4 E, 3 P + 4 E) instead of 4 x (P + E + R) on
+// the full one, and 4 reduce-scatters per block instead of 13.  The placement assumption costs speed, never correctness,
+// when it does not hold: tables and order of additions are fixed per block shape, so sums stay bit-reproducible.
+// A wave's LDS region: [64 x {x, y, z, npairs}] first -- the point goes there BEFORE the pair phase, so that it is not
+// held in registers through it (the kernel sits at the 128-VGPR edge) -- then the 11 f64 words per lane; in the 27-cell
+// modes the candidate list lies where the f64 words will go (it is dead when they are written).
+constexpr int PART_F64 = 11;                                   // score, best, w[3], S[6]
+constexpr int PART_XYZ_BYTES = 64 * 16;
+constexpr int PART_BYTES = PART_XYZ_BYTES + PART_F64 * 64 * 8; // 6656 bytes per wave
+__host__ __device__ constexpr int wave_region_bytes(bool kd) {
+  return kd ? (PART_XYZ_BYTES + KD_CELLS * 64 * 4 > PART_BYTES ? PART_XYZ_BYTES + KD_CELLS * 64 * 4 : PART_BYTES) : PART_BYTES;
+}
+
+// before the pair phase: the point as the expansion wants it -- a non-finite one (it never has neighbours, ref :573, so
+// w = S = 0) as the origin, so that it expands to exact zeros
+__device__ __forceinline__ void store_point(char* region, int lane, float x, float y, float z) {
+  const bool fin = isfinite(x) && isfinite(y) && isfinite(z);
+  reinterpret_cast<float4*>(region)[lane] = make_float4(fin ? x : 0.0f, fin ? y : 0.0f, fin ? z : 0.0f, 0.0f);
+}
+__device__ __forceinline__ void load_point(const char* region, int lane, float& x, float& y, float& z) {
+  const float4 q = reinterpret_cast<const float4*>(region)[lane];
+  x = q.x; y = q.y; z = q.z;
+}
+
+template <int MODE>
+__device__ __forceinline__ void store_partials(char* region, int lane, const PairAcc& a) {
+  double* d = reinterpret_cast<double*>(region + PART_XYZ_BYTES);
+  d[0 * 64 + lane] = a.score;
+  d[1 * 64 + lane] = a.best;
+  if (MODE != 3) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) d[(2 + k) * 64 + lane] = a.w[k];
+  }
+  if (MODE == 1 || MODE == 2) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) d[(5 + k) * 64 + lane] = a.S[k];
+  }
+  reinterpret_cast<int*>(region)[4 * lane + 3] = a.npairs;
+}
+
+// (see RegSource)
+struct LdsSource {
+  const char* region;
+  int lane;
+  __device__ __forceinline__ double f64(int k) const {
+    return reinterpret_cast<const double*>(region + PART_XYZ_BYTES)[k * 64 + lane];
+  }
+  __device__ __forceinline__ double score() const { return f64(0); }
+  __device__ __forceinline__ double best() const { return f64(1); }
+  __device__ __forceinline__ int npairs() const { return reinterpret_cast<const int*>(region)[4 * lane + 3]; }
+  __device__ __forceinline__ double w(int k) const { return f64(2 + k); }
+  __device__ __forceinline__ double S(int k) const { return f64(5 + k); }
+  __device__ __forceinline__ void point(float& px, float& py, float& pz) const { load_point(region, lane, px, py, pz); }
+};
+
+// A wave has published its item (its pair sums, and -- waves 0 and 1 of an ordinary or batched launch -- its share of
+// the angle tables): LDS traffic of one wave is executed in order, the flag goes out behind the data.
+// The flag is a 64-bit TAG of (launch, block, wave, process): LDS is not initialised, and no barrier stands between a
+// wave clearing its own flag -- the first thing it does -- and a finishing wave looking at it, microseconds later, behind
+// its own pair phase (a block barrier at the start made every wave wait for the last one to be launched, 0.44 us, and
+// start its memory round trips in lock-step with the others).  Should a wave ever be launched that late, the word its
+// flag holds is what an earlier workgroup left there: equal to this tag with probability 2^-64.
+__device__ __forceinline__ unsigned long long item_tag(unsigned long long base, int wave) { return base ^ (unsigned long long)wave; }
+__device__ __forceinline__ void publish_item(unsigned long long* s_item, unsigned long long base, int wave, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) __hip_atomic_store(&s_item[wave], item_tag(base, wave), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// The waited-for wave belongs to the same workgroup (resident by construction) and publishes unconditionally; the trip
+// bound (~0.5 s) only keeps a wave from spinning for ever should that ever be broken.  Returns false on the bound.
+__device__ __forceinline__ bool wait_item(unsigned long long* s_item, unsigned long long base, int it) {
+  const unsigned long long want = item_tag(base, it);
+  for (int trip = 0; trip < (1 << 22); ++trip) {
+    if (__hip_atomic_load(&s_item[it], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == want) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      return true;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return false;
 }
 
 #ifdef NDT_STAMPS
@@ -748,7 +948,8 @@ __device__ __forceinline__ void sum_rows(__amdgpu_buffer_rsrc_t rows, unsigned i
 // kernel, no float atomics, and the summation tree does not depend on arrival order:
 // results are bit-reproducible.  host_slots != nullptr: the evaluation is written as 32 tagged
 // slots into pinned host memory for the host to poll; otherwise 32 plain doubles go to `out`.
-__device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], double* __restrict__ rows,
+__device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], int fin /* >= 0: this wave is the finishing wave of SIMD `fin` and acc holds its sums */,
+                                                    int nfin, double* __restrict__ rows,
                                                     double* __restrict__ group_rows,
                                                     unsigned int* __restrict__ counters,
                                                     double* __restrict__ out,
@@ -757,22 +958,23 @@ __device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], double
                                                     const XchgInfo* __restrict__ xi, unsigned long long xround,
                                                     int my_row /* this block's row */, int nb /* rows = computing blocks */,
                                                     bool dedicated /* a block without points adds the rows */, int mute_row = 0) {
-  __shared__ double lds_w[MAX_WAVES][EV_WORDS];
+  __shared__ double lds_w[4][EV_WORDS];
   __shared__ double lds_c[MAX_COLS][EV_WORDS];
   __shared__ int s_last;
   __shared__ int s_fail;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
   if (threadIdx.x == 0) s_fail = 0;
-  wave_reduce_scatter32(acc, lane);
-  if ((lane & 1) == 0) lds_w[wave][lane >> 1] = acc[0];
+  if (fin >= 0) {   // wave-uniform
+    wave_reduce_scatter32(acc, lane);
+    if ((lane & 1) == 0) lds_w[fin][lane >> 1] = acc[0];
+  }
   NDT_WSTAMP(5);
   __syncthreads();
   NDT_WSTAMP(6);
   const __amdgpu_buffer_rsrc_t rrows = slots_rsrc(rows);
   if (threadIdx.x < EV_WORDS) {
     double sum = 0.0;
-    const int nwaves = (int)blockDim.x >> 6;
-    for (int wv = 0; wv < nwaves; ++wv) sum += lds_w[wv][threadIdx.x];
+    for (int f = 0; f < nfin; ++f) sum += lds_w[f][threadIdx.x];
 #ifdef NDT_TEST_SEAMS
     if (mute_row != my_row + 1)   // (seam: this block's row never arrives)
 #endif
@@ -781,7 +983,7 @@ __device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], double
   NDT_WSTAMP(7);
   NDT_STAMP(4);
 #ifdef NDT_STAMPS
-  if (wave == 0) NDT_WSTAMP_DRAINED(8);
+  if ((threadIdx.x >> 6) == 0) NDT_WSTAMP_DRAINED(8);
   ws_flush();
 #endif
   if (dedicated) return;  // the summing block (summer_finish) polls the rows; this block is done
@@ -914,6 +1116,11 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
   }
 #endif
   __shared__ AngleTables tab;
+  __shared__ unsigned long long s_item[MAX_WAVES];   // a wave's pair sums (and table words) are in LDS: see "finishing waves"
+  if ((threadIdx.x & 63u) == 0) s_item[threadIdx.x >> 6] = 0ull;   // (own flag, first thing)
+  // (top bit set: never the zero just written; the low four bits are the wave's)
+  const unsigned long long item_base =
+      ((((seq * 0x9E3779B97F4A7C15ull) ^ ec.item_salt ^ ((unsigned long long)(blockIdx.y * gridDim.x + blockIdx.x) << 8))) | (1ull << 63)) & ~15ull;
   RigidRT rt;
   // The 69 table words are fetched by 69 lanes as one vector load each -- from the pose array,
   // or straight out of the kernel-argument segment -- at the very start, and written to LDS
@@ -1053,33 +1260,62 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
 #pragma unroll
   for (int k = 0; k < 6; ++k) a.S[k] = 0.0;
   a.score = 0.0; a.best = 0.0; a.npairs = 0;
-  if (NB >= 2 && NB <= 4) {
+  extern __shared__ int lds_dyn[];   // one region per wave: the KD candidate list first, the hand-over of its pair sums afterwards
+  constexpr bool KD = NB >= 2 && NB <= 4;
+  // (the wave's number as a scalar: nothing but the thread id and the pair sums stays in vector registers through the
+  // pair phase -- the kernel sits at the 128-VGPR edge there)
+  const int lane = (int)(threadIdx.x & 63u), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  char* const regions = reinterpret_cast<char*>(lds_dyn);
+  if (!(MBOX && ec.mbox_preload) && i < n) { x = sx[i]; y = sy[i]; z = sz[i]; }
+  char* const my_region = regions + (size_t)wave * wave_region_bytes(KD);
+  NDT_STAMP(1);
+  NDT_WSTAMP_DRAINED(1);
+  store_point(my_region, lane, x, y, z);
+  // (the table words were requested before the point: they have arrived with it; a pre-launched kernel has had its
+  // tables in LDS since it was released)
+  if (!MBOX && threadIdx.x < 69) tab.jang[threadIdx.x] = tab_word;  // runs on into hang[]: the two arrays are contiguous
+  if (KD) {
     // every lane takes part (wave-wide trip count): lanes beyond n run with nothing to add
-    extern __shared__ int lds_kd_list[];  // KD_CELLS x blockDim.x leaf indices
-    if (!(MBOX && ec.mbox_preload) && i < n) { x = sx[i]; y = sy[i]; z = sz[i]; }
-    NDT_STAMP(1);
-    NDT_WSTAMP_DRAINED(1);
-    point_pairs_kd<MODE, NB == 2 || NB == 4, NB == 4>(a, x, y, z, g, cell2leaf, rec, cent, rt, ec, lds_kd_list, i < n);
+    point_pairs_kd<MODE, NB == 2 || NB == 4, NB == 4>(a, x, y, z, g, cell2leaf, rec, cent, rt, ec,
+                                                      reinterpret_cast<int*>(my_region + PART_XYZ_BYTES), i < n);
   } else if (i < n) {
-    if (!(MBOX && ec.mbox_preload)) { x = sx[i]; y = sy[i]; z = sz[i]; }
-    NDT_STAMP(1);
-    NDT_WSTAMP_DRAINED(1);
     point_pairs<MODE, NB == 1 || NB == 6, NB >= 5>(a, x, y, z, g, cell2leaf, rec, rt, ec);
   }
   NDT_STAMP(2);
   NDT_WSTAMP(2);
-  if (!MBOX) {  // (a pre-launched kernel has had its tables in LDS since it was released)
-    if (threadIdx.x < 69) tab.jang[threadIdx.x] = tab_word;  // runs on into hang[]: the two arrays are contiguous
-    __syncthreads();  // angle tables visible
-  }
+  // ---- hand-over to the finishing waves (see above) ----
+  // (the lane number once more, from the exec mask this time: a value derived from the thread id in front of the pair
+  // phase would be kept in a register through it -- or spilled around it, as the multi-grid kernels did)
+  const int lane2 = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const int nw = (int)(blockDim.x >> 6), nfin = nw < 4 ? nw : 4;
+  const int simd = wave & 3;                                   // (the SIMD this wave is taken to sit on)
+  const bool finishing = (int)((ec.fin_waves >> (4 * simd)) & 15u) == wave;
+  if (!finishing) store_partials<MODE>(my_region, lane2, a);
+  publish_item(s_item, item_base, wave, lane2);
   NDT_WSTAMP(3);
   double acc[EV_WORDS];
-  if (a.npairs == 0) { x = 0.0f; y = 0.0f; z = 0.0f; }  // a skipped (e.g. non-finite) point must expand to exact zeros
-  expand_point<MODE>(acc, a, x, y, z, tab);
+  if (finishing) {   // wave-uniform
+    bool ok = true;
+    if (!MBOX) {    // the angle tables are in LDS once waves 0 and 1 have published
+      ok = wait_item(s_item, item_base, 0) && ok;
+      if (nw > 1) ok = wait_item(s_item, item_base, 1) && ok;
+    }
+    float T[69];
+    angle_tables_to_sgprs(T, tab, lane2);
+    load_point(my_region, lane2, x, y, z);
+    expand_point<MODE, false>(acc, RegSource{a, x, y, z}, T);   // its own points: the pair sums straight from registers
+    const unsigned int owners = ec.item_owner, fins = ec.fin_waves;
+    for (int it = 0; it < nw; ++it) {                           // the other waves' in a fixed order
+      if ((int)((owners >> (2 * it)) & 3u) != simd || (int)((fins >> (4 * (it & 3))) & 15u) == it) continue;
+      ok = wait_item(s_item, item_base, it) && ok;
+      expand_point<MODE, true>(acc, LdsSource{regions + (size_t)it * wave_region_bytes(KD), lane2}, T);
+    }
+    if (!ok && lane2 == 0) acc[EV_FAIL] += 1.0;   // (never seen: a sibling wave that did not publish)
+  }
   NDT_STAMP(3);
   NDT_WSTAMP(4);
   double* base = partials + (size_t)blockIdx.y * (gridDim.x + NGROUPS) * ROW_WORDS;
-  block_reduce_finish(acc, base + (size_t)NGROUPS * ROW_WORDS, base, counters + blockIdx.y * COUNTERS_PER_POSE,
+  block_reduce_finish(acc, finishing ? simd : -1, nfin, base + (size_t)NGROUPS * ROW_WORDS, base, counters + blockIdx.y * COUNTERS_PER_POSE,
                       out + (size_t)blockIdx.y * EV_WORDS,
                       flag ? flag + (size_t)blockIdx.y * ROW_WORDS : nullptr,  // pose y's 32 host slots
                       seq, ec.single_level_max,
@@ -1202,6 +1438,44 @@ static int derivs_dedicated_summer(size_t n_src, int K, int cus) {
   return 1;
 }
 
+// Which finishing wave expands which wave's points (k_derivatives, "finishing waves").  The hardware places the waves
+// of a block round-robin on the four SIMDs of its compute unit (observed on every block of every launch stamped,
+// profiles/r05_stamps_per_wave.txt), so wave i is taken to sit on SIMD i mod 4.
+//   fin_waves: 4 bits per SIMD -- its finishing wave (15: none): the LAST wave of a SIMD that holds one wave more than
+//              others do (it finishes its pairs last anyway and expands itself from registers), the FIRST wave elsewhere
+//              (it is through its pairs first and works the others' items off as they arrive);
+//   owners:    2 bits per wave -- the SIMD whose finishing wave expands that wave's points: its own SIMD's first; then
+//              items move off the fullest SIMD, the earliest-finishing ones first, for as long as that lowers the largest
+//              load, counted in VALU instructions (pair phase + LDS hand-over, expansion, reduce-scatter).
+// 13 waves: wave 12 expands itself, waves 1 / 2 / 3 take four items each.  Depends on the block shape only: fixed
+// tables, a fixed order of additions.
+void derivs_item_owners(int threads, unsigned int* owners_out, unsigned int* fin_waves_out) {
+  const int nw = threads / 64, nfin = nw < 4 ? nw : 4;
+  int fin_of_simd[4] = {15, 15, 15, 15}, p[4] = {0, 0, 0, 0}, e[4] = {0, 0, 0, 0}, owner[MAX_WAVES];
+  for (int i = 0; i < nw; ++i) { ++p[i % 4]; ++e[i % 4]; owner[i] = i % 4; }
+  const int pmin = nw >= 4 ? nw / 4 : 1;
+  for (int q = 0; q < nfin; ++q) fin_of_simd[q] = (nw >= 4 && p[q] > pmin) ? q + 4 * (p[q] - 1) : q;
+  constexpr int P = 710, E = 245, R = 140;
+  for (;;) {
+    int m = 0, k = 0, load[4];
+    for (int q = 0; q < nfin; ++q) load[q] = p[q] * P + e[q] * E + R;
+    for (int q = 1; q < nfin; ++q) { if (load[q] > load[m]) m = q; if (load[q] < load[k]) k = q; }
+    if (load[k] + E >= load[m]) break;
+    int it = -1;
+    for (int i = 0; i < nw && it < 0; ++i)
+      if (owner[i] == m && i != fin_of_simd[i % 4]) it = i;
+    if (it < 0) break;
+    owner[it] = k;
+    --e[m];
+    ++e[k];
+  }
+  unsigned int ob = 0u, fb = 0u;
+  for (int i = 0; i < nw; ++i) ob |= (unsigned int)owner[i] << (2 * i);
+  for (int q = 0; q < 4; ++q) fb |= (unsigned int)fin_of_simd[q] << (4 * q);
+  *owners_out = ob;
+  *fin_waves_out = fb;
+}
+
 int derivs_grid_blocks(size_t n_src, int K, int cus) { return derivs_point_blocks(n_src, K, cus) + derivs_dedicated_summer(n_src, K, cus); }
 
 void launch_derivatives(const float* sx, const float* sy, const float* sz, size_t n_src,
@@ -1253,7 +1527,9 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
   // the format (as a run-time flag) cost more than the shorter fetch gave back (KDTREE 21.9 -> 22.5 us, DIRECT26 29.1 -> 29.7)
   if (ec.multigrid || ec.kdtree || ec.direct26) ecl.packed = 0;
   const int nb = ec.multigrid ? 4 : (ec.kdtree ? 2 : (ec.direct26 ? 3 : (ec.direct7 ? (ecl.packed ? 6 : 1) : (ecl.packed ? 5 : 0))));
-  const size_t dyn_lds = nb >= 2 && nb <= 4 ? (size_t)KD_CELLS * threads * sizeof(int) : 0;
+  derivs_item_owners(threads, &ecl.item_owner, &ecl.fin_waves);
+  // one LDS region per wave: the 27-cell modes' candidate list, then the wave's hand-over to the finishing waves
+  const size_t dyn_lds = (size_t)(threads / 64) * (size_t)wave_region_bytes(nb >= 2 && nb <= 4);
   // ev_start / ev_stop: events attached to THIS dispatch (hipExtLaunchKernel): they carry the kernel's own begin and
   // end timestamps, what rocprofv3 reports -- events recorded around the launch include ~2.4 us of dispatch
 #define NDT_LAUNCH2(B, M, NBH, MB, GY, FLAG, SEQ)                                                            \

@@ -131,6 +131,9 @@ struct EvalConsts {
   int compute_units;  // host side only: compute units of the handle's device (block shapes, XCD count)
   int safe_sum;    // 1: the final sum is made by the block that draws the LAST TICKET (no block waits for rows of blocks that
                    // may not be resident): the re-evaluation after a lost row
+  unsigned int item_owner;  // k_derivatives: 2 bits per wave of a block -- the SIMD whose finishing wave expands that wave's points
+  unsigned long long item_salt;  // ... per-process random bits in the tags the waves of a block publish their items under (process_item_salt())
+  unsigned int fin_waves;   // ... 4 bits per SIMD: its finishing wave (derivs_item_owners(), ndt_derivs.hip; per launch, from the block shape)
   int mute_row;    // test seam (libndt_hip_seams.so only): row + 1 of the block that withholds its partial row; 0 = none
 };
 

@@ -69,6 +69,34 @@ def test_tuning_round_trip_and_validation(pkg):
     assert pkg.get_tuning() == t0
 
 
+def test_finishing_wave_tables_cover_every_block_shape(pkg):
+    """k_derivatives' finishing waves (round 5): for every block shape the tables name one finishing wave per SIMD, every
+    other wave's points are expanded by exactly one of them, and the 13-wave block of the 200 k-point scan gets the
+    assignment DESIGN 4.1 describes (wave 12 itself only; waves 1, 2, 3 four items each)."""
+    L = pkg.lib()
+    for threads in range(64, 1025, 64):
+        ow, fw = C.c_uint(), C.c_uint()
+        assert L.ndt_debug_item_owners(threads, C.byref(ow), C.byref(fw)) == 0
+        nw = threads // 64
+        fins = [(fw.value >> (4 * q)) & 15 for q in range(4)]
+        owners = [(ow.value >> (2 * i)) & 3 for i in range(nw)]
+        nfin = min(4, nw)
+        assert all(f < nw and f % 4 == q for q, f in enumerate(fins[:nfin])) and all(f == 15 for f in fins[nfin:])
+        load = [0] * 4
+        for i in range(nw):
+            assert fins[owners[i]] != 15
+            if i in fins:
+                assert owners[i] == i % 4        # a finishing wave expands its own points
+            load[owners[i]] += 1
+        assert sum(load) == nw and (nw < 4 or min(load[:nfin]) >= 1)
+        if nw == 13:
+            assert fins == [12, 1, 2, 3] and load == [1, 4, 4, 4]
+            assert [owners[i] for i in (0, 4, 8)] == [1, 2, 3]
+        if nw in (8, 12, 16):
+            assert fins == [0, 1, 2, 3] and load == [nw // 4] * 4
+    assert L.ndt_debug_item_owners(100, C.byref(ow), C.byref(fw)) == -1
+
+
 def test_abi_signatures_have_no_torch_types():
     txt = open(os.path.join(ROOT, "include", "ndt_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)  # declarations only

@@ -4,15 +4,17 @@ For the ordinary launch (ndt_eval_derivatives at the converged pose) and for the
 align: when every wave of every block finished its pairs, its expansion, its reduce-scatter, passed the block barrier,
 and when the block's row went out; which SIMD each wave ran on; what the summing block's poll trips saw.
 Answers VERDICT r04 item 1(a): is the time between wave 0's `expanded` and the block's `row stored` the other waves'
-pair phase (VALU issue on the SIMD that holds four waves) or the reduction / hand-off?"""
+pair phase (VALU issue on the SIMD that holds four waves) or the reduction / hand-off?  (profiles/r05_stamps_per_wave.txt is
+the run BEFORE the finishing-wave change; since then stamps 4 and 5 of a wave that is not one of its block's last four are
+just the moments it reaches the block barrier.)"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import __graft_entry__ as ge
 pkg = ge.load_package(); pkg.apply_env_tuning(); S = pkg.synth
 WS_WAVES, WS_N, WS_TRIPS = 16, 10, 64
-NAMES = ["entry", "xyz loaded", "pairs done", "tables (barrier)", "expanded", "wave reduced", "block barrier", "row issued / leaving",
-         "row acknowledged"]
+NAMES = ["entry", "xyz loaded", "pairs done", "pair sums published", "expanded (finishing waves: all their items)", "wave reduced (finishing waves)",
+         "block barrier", "row issued / leaving", "row acknowledged"]
 cfg = S.config_c3()
 ndt = pkg.NormalDistributionsTransform(device_id=0, resolution=0.5, step_size=0.1, trans_epsilon=1e-4, max_iterations=35)
 ndt.setInputTarget(cfg["target"])
@@ -57,6 +59,8 @@ def report(title, t, hw, trips, t0):
     a = rel[:, 0, 8][comp[:, 0, 8] > 0]
     if a.size:
         print("  wave 0      %-22s %s" % (NAMES[8], pct(a)))
+    ent = np.where(valid, rel[:, :, 0], np.nan)
+    print("  a block's waves enter within %.2f us of each other (median; max %.2f)" % (np.nanmedian(np.nanmax(ent, 1) - np.nanmin(ent, 1)), np.nanmax(np.nanmax(ent, 1) - np.nanmin(ent, 1))))
     # per block: the first and the last wave through each phase
     print("  per block, first / last wave through a phase (median over blocks):")
     for k in (2, 4, 5):
@@ -96,6 +100,11 @@ def report(title, t, hw, trips, t0):
                         v.append(rel[b, order[rank], k])
             rows.append(np.median(v) if v else float("nan"))
         print("    %-22s on the fullest SIMD, 1st..4th wave to get there: %s" % (NAMES[k], "  ".join("%6.2f" % r for r in rows)))
+    # the finishing waves (derivs_item_owners): the last wave of a SIMD with one wave more than the others, the first elsewhere
+    pmin = nwv // 4
+    fw = [q + 4 * (((nwv - q + 3) // 4) - 1) if (nwv >= 4 and (nwv - q + 3) // 4 > pmin) else q for q in range(min(4, nwv))]
+    for k in (2, 4, 5):
+        print("    finishing waves %-46s %s" % (NAMES[k], "  ".join("w%d %.2f" % (w, np.median(rel[:, w, k])) for w in fw)))
     if ded:
         sm = (t[0, :nwv, :] - t0[0]) * 0.01
         print("  summing block: polling from %.2f | a wave has all its slots: first %.2f last %.2f | barrier passed %.2f | result issued %.2f | acknowledged (wave 0) %.2f"
