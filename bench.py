@@ -243,6 +243,8 @@ def main():
     current = {"mode": "none", "steps": 0}
     inject = os.environ.get("NDT_BENCH_INJECT_FAILURE")   # tests only: "<variant>" -> the last rank errors in its 3rd step
 
+    step_opts = {"blocking_target": False}
+
     def step():
         if inject is not None and inject == current["mode"] and rank == world - 1:
             current["steps"] += 1
@@ -251,7 +253,10 @@ def main():
         t0 = time.perf_counter()
         # (the build is ENQUEUED -- the arrays stay put -- and the align's first evaluation goes onto the stream behind it;
         # t1 - t0 is the host's time in the call, the build itself is `ms_target_build_device`)
-        ndt.setInputTargetDeviceDeferred(tptr[0], tptr[1], tptr[2], n_tgt)
+        if step_opts["blocking_target"]:   # (protocol_variants only: the blocking call of rounds 1-3)
+            ndt.setInputTargetDevice(tptr[0], tptr[1], tptr[2], n_tgt)
+        else:
+            ndt.setInputTargetDeviceDeferred(tptr[0], tptr[1], tptr[2], n_tgt)
         t1 = time.perf_counter()
         ndt.setInputSourceDeviceView(sptr[0], sptr[1], sptr[2], c)
         ndt.align(guess_cm, return_transform=False)
@@ -263,7 +268,7 @@ def main():
             board.barrier()
         hip.synchronize()
 
-    def timed_region():
+    def timed_region(wake_steps=None):
         """W warm-up steps, then exactly K steps between two fences; max wall time over ranks.
         With several ranks an engine error (a reducer that stops answering) does not leave the other
         ranks stranded in a fence: the failing rank still walks through the same board calls and
@@ -273,7 +278,7 @@ def main():
             # (device wake-up, untimed, in front of the W warm-up steps: after an idle period -- the seconds of cloud
             # synthesis before this point -- an MI355X needs ~30 ms of work to be back at its clocks; W = 5 steps are
             # 2.6 ms.  tools/warmup_probe.py: steps 5..24 after 5 s of idling average 0.576 ms, steps 45.. 0.52.)
-            for _ in range(WAKE_STEPS + args.warmup):
+            for _ in range((WAKE_STEPS if wake_steps is None else wake_steps) + args.warmup):
                 step()
         except pkg.NdtError as e:
             if not multi:
@@ -433,8 +438,14 @@ def main():
         elapsed, iters, evals = res["elapsed"], res["iters"], res["evals"]
         out.update({
             "value": iters / elapsed, "ms_per_step": 1e3 * elapsed / args.steps,
-            "ms_scan": 1e3 * elapsed / args.steps, "ms_target_build": 1e3 * res["t_build"] / args.steps,
-            "ms_align": 1e3 * res["t_align"] / args.steps,
+            "ms_scan": 1e3 * elapsed / args.steps,
+            # Key meanings as in rounds 1-3: ms_target_build is the BUILD (device time; the set-target call
+            # only enqueues it since round 4 -- its host time is ms_target_build_enqueue), ms_align the align WITHOUT the
+            # build that now finishes inside it (ms_align_incl_build is what the call takes)
+            "ms_target_build": out.get("ms_target_build_device") or 0.0,
+            "ms_target_build_enqueue": 1e3 * res["t_build"] / args.steps,
+            "ms_align_incl_build": 1e3 * res["t_align"] / args.steps,
+            "ms_align": max(1e3 * res["t_align"] / args.steps - (out.get("ms_target_build_device") or 0.0), 0.0),
             "iterations_per_align": iters / args.steps, "evaluations_per_align": evals / args.steps,
             # line-search requests at the pose of the evaluation before them, answered without a launch
             "evaluations_reused_per_align": res["reused"] / args.steps,
@@ -651,6 +662,89 @@ def main():
                     cfgs[name] = {"error": "%s: %s" % (type(e).__name__, e)}
             return cfgs
 
+        def protocol_variants():
+            """Not `value`: the headline step under the measurement protocols of earlier rounds, so that a change of the
+            headline between rounds splits into methodology and engine: without the untimed device wake-up
+            steps in front of the warm-up (rounds 1-3; NDT_BENCH_WAKE_STEPS=0), and with the BLOCKING ndt_set_target_device
+            in the step (rounds 1-3: the build awaited inside the set-target call), and both."""
+            if os.environ.get("NDT_BENCH_PROTOCOLS", "1") != "1":
+                return None
+            v = {"what": "same C3 step, K = %d steps after W = %d warm-up steps" % (args.steps, args.warmup),
+                 "headline": {"ms_per_step": 1e3 * res["elapsed"] / args.steps, "device_wake_steps": WAKE_STEPS, "set_target": "deferred"}}
+            time.sleep(2.0)   # (an idle pause like the one in front of the headline's region: cloud synthesis took seconds)
+            r0 = timed_region(wake_steps=0)
+            v["no_wake_steps"] = {"ms_per_step": 1e3 * r0["elapsed"] / args.steps, "device_wake_steps": 0, "set_target": "deferred"}
+            step_opts["blocking_target"] = True
+            try:
+                rb = timed_region()
+                time.sleep(2.0)
+                rb0 = timed_region(wake_steps=0)
+            finally:
+                step_opts["blocking_target"] = False
+            v["blocking_set_target"] = {"ms_per_step": 1e3 * rb["elapsed"] / args.steps, "device_wake_steps": WAKE_STEPS, "set_target": "blocking",
+                                        "ms_set_target": 1e3 * rb["t_build"] / args.steps, "ms_align": 1e3 * rb["t_align"] / args.steps}
+            v["rounds_1_to_3_protocol"] = {"ms_per_step": 1e3 * rb0["elapsed"] / args.steps, "device_wake_steps": 0, "set_target": "blocking"}
+            return v
+
+        def cadence():
+            """Not `value`: the headline step as a driver at the reference's keyframe rate sees it -- one step every 100 ms
+            (10 Hz) and every 50 ms (20 Hz), the device idle in between, and the first step after 5 s of idling; then the
+            same with the engine's idle-time heartbeat on (ndt_set_keepwarm, 1 ms period; default off).  Medians."""
+            if os.environ.get("NDT_BENCH_CADENCE", "1") != "1":
+                return None
+
+            def sclk():
+                # the shader clock the driver reports right now (MHz), where the box lets an ordinary user read it
+                try:
+                    import glob
+                    best = None
+                    for f in glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"):
+                        for ln in open(f).read().splitlines():
+                            if ln.strip().endswith("*"):
+                                mhz = int("".join(ch for ch in ln.split(":")[1] if ch.isdigit()))
+                                best = mhz if best is None else max(best, mhz)
+                    return best
+                except Exception:  # noqa: BLE001
+                    return None
+
+            def one():
+                t0 = time.perf_counter()
+                step()
+                return 1e3 * (time.perf_counter() - t0)
+
+            def paced(period, n):
+                t, clk = [], []
+                for _ in range(n):
+                    time.sleep(period)
+                    clk.append(sclk())
+                    t.append(one())
+                clk = [c_ for c_ in clk if c_ is not None]
+                return float(np.median(t)), (float(np.median(clk)) if clk else None)
+
+            def block():
+                for _ in range(10):
+                    one()
+                busy = float(np.median([one() for _ in range(20)]))
+                m10, c10 = paced(0.1, 25)
+                m20, c20 = paced(0.05, 30)
+                time.sleep(5.0)
+                c5 = sclk()
+                first = one()
+                return {"ms_step_back_to_back": busy, "ms_step_10hz": m10, "ms_step_20hz": m20, "ms_first_step_after_5s_idle": first,
+                        "sclk_mhz_before_a_10hz_step": c10, "sclk_mhz_before_a_20hz_step": c20, "sclk_mhz_after_5s_idle": c5}
+
+            v = block()
+            ndt.setKeepWarm(1000)
+            try:
+                time.sleep(0.05)
+                v["keepwarm_1ms"] = block()
+                v["keepwarm_1ms"]["beats"] = ndt.keepWarm()[1]
+            finally:
+                ndt.setKeepWarm(0)
+            return v
+
+        side("protocol_variants", protocol_variants)
+        side("cadence", cadence)
         side("packed_records", packed)
         side("host_cloud", host_cloud)
         side("configs", other_configs)

@@ -264,6 +264,14 @@ typedef struct ndt_tuning {
   int timing_bracket;         /* 0: kernel-timing events attached to the dispatch (default); 1: recorded around the launch call */
   int reserved[13];           /* zero */
 } ndt_tuning;
+/* Idle-device heartbeat (round 5; default off).  A driver at the reference's 10-20 Hz keyframe rate leaves the device idle for
+ * 50-100 ms between two aligns, and an idle MI355X drops its clocks: the align that follows runs 5-10 % slower than in a
+ * busy loop.  period_us > 0 (>= 100): while the handle has been idle for a period, a background thread
+ * launches one small kernel (one block per compute unit, ~3 us) per period on a lowest-priority stream; 0 stops it.
+ * ndt_get_keepwarm returns the period (0: off) and, if beats != NULL, the number of beats launched so far. */
+int ndt_set_keepwarm(ndt_handle* h, int period_us);
+int ndt_get_keepwarm(const ndt_handle* h, long long* beats);
+
 int ndt_get_tuning(ndt_tuning* out);
 /* NDT_ERR_INVALID_ARG (nothing changed) when a field is outside its documented values. */
 int ndt_set_tuning(const ndt_tuning* t);

@@ -206,7 +206,7 @@ ABI_SYMBOLS = [
     "ndt_set_record_format", "ndt_get_record_format",
     "ndt_set_handoff_mode", "ndt_get_handoff_mode", "ndt_wait", "ndt_get_handoff_timing",
     "ndt_voxel_downsample_device", "ndt_voxel_downsample", "ndt_get_iteration_history",
-    "ndt_get_tuning", "ndt_set_tuning",
+    "ndt_get_tuning", "ndt_set_tuning", "ndt_set_keepwarm", "ndt_get_keepwarm",
 ]
 
 _lib = None
@@ -222,6 +222,8 @@ def lib():
         L = C.CDLL(LIB_PATH)
         fp, dp, vp = C.POINTER(C.c_float), C.POINTER(C.c_double), C.c_void_p
         L.ndt_abi_version.restype = C.c_int
+        L.ndt_set_keepwarm.argtypes = [vp, C.c_int]
+        L.ndt_get_keepwarm.argtypes = [vp, C.POINTER(C.c_longlong)]
         L.ndt_get_tuning.argtypes = [C.POINTER(Tuning)]
         L.ndt_set_tuning.argtypes = [C.POINTER(Tuning)]
         L.ndt_default_params.argtypes = [C.POINTER(Params)]
@@ -779,6 +781,15 @@ class NormalDistributionsTransform:
         self._check(lib().ndt_comm_destroy(self._h))
 
     # --- instrumentation ---
+    def setKeepWarm(self, period_us):
+        """ndt_set_keepwarm: an idle-time heartbeat every period_us (0: off, the default)."""
+        self._check(lib().ndt_set_keepwarm(self._h, int(period_us)))
+
+    def keepWarm(self):
+        """(period_us, beats launched so far)."""
+        b = C.c_longlong(0)
+        return lib().ndt_get_keepwarm(self._h, C.byref(b)), b.value
+
     def enableKernelTiming(self, on=True):
         self._check(lib().ndt_enable_kernel_timing(self._h, int(on)))
 

@@ -26,6 +26,7 @@
 
 #include "../../include/ndt_hip.h"
 #include "ndt_comm.h"
+#include "ndt_keepwarm.h"
 #include "ndt_kernels.h"
 #include "ndt_newton.h"
 #include "ndt_repack_pool.h"
@@ -100,6 +101,7 @@ struct PinBuf {  // pinned, device-mapped host memory
 struct ndt_handle {
   ndt_params prm;
   int device = -1;
+  KeepWarm keepwarm;                   // optional idle-time heartbeat (ndt_set_keepwarm), off by default
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;       // pre-launched evaluation kernels alternate between `stream` and this one
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
@@ -1421,6 +1423,7 @@ int ndt_create(const ndt_params* p, ndt_handle** out) {
 
 int ndt_destroy(ndt_handle* h) {
   if (!h) return NDT_OK;
+  h->keepwarm.stop();
   (void)hipSetDevice(h->device);
   settle_discard(h);
   if (h->ustream) (void)hipStreamSynchronize(h->ustream);
@@ -2016,10 +2019,26 @@ int ndt_clear_regularization_pose(ndt_handle* h) {
   return NDT_OK;
 }
 
+int ndt_set_keepwarm(ndt_handle* h, int period_us) {
+  if (!h || period_us < 0 || (period_us > 0 && period_us < 100)) return NDT_ERR_INVALID_ARG;
+  h->keepwarm.start(h->device, h->n_cus, period_us);
+  return NDT_OK;
+}
+int ndt_get_keepwarm(const ndt_handle* h, long long* beats) {
+  if (!h) return NDT_ERR_INVALID_ARG;
+  if (beats) *beats = h->keepwarm.beats();
+  return h->keepwarm.period_us();
+}
+
 int ndt_align(ndt_handle* h, const float guess[16], ndt_result* out) {
   if (!h || !guess || !out) return NDT_ERR_INVALID_ARG;
   int rc = bind_device(h);
   if (rc) return rc;
+  struct Busy {   // (the heartbeat pauses while an align runs, and counts its period from the align's end)
+    KeepWarm& k;
+    explicit Busy(KeepWarm& kw) : k(kw) { k.touch(); }
+    ~Busy() { k.touch(); }
+  } busy(h->keepwarm);
   h->spec_build_failed = false;
   h->spec_first = first_eval_behind_build(h);   // the build's verdict is then collected inside the first evaluation
   if (!h->spec_first) {

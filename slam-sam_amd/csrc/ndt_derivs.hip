@@ -69,11 +69,14 @@ __device__ __forceinline__ void pair_update(PairAcc& a, const VoxelRecord& r, fl
   // unrolled pairs do not each split the wave three more times:
   //   q non-finite or < -1e-9 -> no contribution;  d2*q/2 > 50 -> no contribution;
   //   |d1*d2*e| < 1e-15 -> score only.
-  bool ok = present && isfinite(q) && !(q < -1e-9);
-  q = fmax(q, 0.0);
+  // (ordered compares: a NaN or -Inf q fails the first, a +Inf q the second -- no separate finiteness test; a masked
+  // pair's e may be anything finite or not: it is SELECTED away, never multiplied away)
+  bool ok = present && q >= -1e-9;
+  asm("v_max_f64 %0, %1, 0" : "=v"(q) : "v"(q));   // q = max(q, 0), NaN -> 0 (fmax() costs a canonicalising v_max in front)
   const double earg = ec.d2 * q * 0.5;
   ok = ok && !(earg > 50.0);
-  const double e = exp(-fmin(earg, 50.0));
+  const double e = exp(-earg);   // (computed for every lane and selected below: as `ok ? exp(..) : 0` it became a branch with
+                                 // the polynomial's constants re-materialised in vector registers inside it)
   const double sc = ok ? -ec.d1 * e : 0.0;
   a.score += sc;
   a.best = fmax(a.best, sc);
@@ -923,12 +926,22 @@ __device__ __forceinline__ void sum_rows(__amdgpu_buffer_rsrc_t rows, unsigned i
       s += (missing & (1u << k)) ? 0.0 : __longlong_as_double((long long)(((unsigned long long)t[k].w << 32) | t[k].z));
   }
   NDT_WSTAMP(6);
-  lds_c[c][v] = s;
+  // the two columns of a wave first (lanes v and v + 32 hold the same word), then the waves' sums as a fixed tree of
+  // depth 4 -- a chain of up to 32 dependent LDS reads and adds stood here (0.6 us behind the last row, stamps of round 5)
+  s += __shfl_xor(s, 32);
+  if ((threadIdx.x & 32u) == 0) lds_c[c >> 1][v] = s;
   __syncthreads();
   NDT_WSTAMP(7);
   if (threadIdx.x < EV_WORDS) {
-    double t = 0.0;
-    for (int k = 0; k < ncols; ++k) t += lds_c[k][threadIdx.x];
+    const int nwv = ((int)blockDim.x + 63) >> 6;
+    double q[MAX_WAVES];
+#pragma unroll
+    for (int k = 0; k < MAX_WAVES; ++k) q[k] = k < nwv ? lds_c[k][threadIdx.x] : 0.0;
+#pragma unroll
+    for (int w = 1; w < MAX_WAVES; w <<= 1)
+#pragma unroll
+      for (int k = 0; k + w < MAX_WAVES; k += 2 * w) q[k] += q[k + w];
+    double t = q[0];
     if (threadIdx.x == EV_WORDS - 1 && *s_fail) t += 1.0;
     if (xi != nullptr && !*s_fail) {
       // (a local sum that missed rows is NOT published: the host re-evaluates, peers wait for that)

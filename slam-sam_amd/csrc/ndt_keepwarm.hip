@@ -1,0 +1,55 @@
+// ndt_keepwarm.hip -- see ndt_keepwarm.h.
+#include "ndt_keepwarm.h"
+
+namespace ndt {
+
+namespace {
+// ~3 us of dependent FMAs per thread, one block per compute unit: enough for the power management to count the device
+// as in use, 0.3 % of it at a 1 ms period.  The result goes nowhere (the store is there so that the loop is not removed).
+__global__ void __launch_bounds__(256) k_keepwarm(float* sink, int rounds) {
+  float a = (float)threadIdx.x * 1e-3f, b = 1.0001f;
+  for (int i = 0; i < rounds; ++i) a = __builtin_fmaf(a, b, 1e-7f);
+  if (a == 123456.789f) sink[0] = a;   // (never)
+}
+}  // namespace
+
+void KeepWarm::run(int device, int compute_units) {
+  if (hipSetDevice(device) != hipSuccess) return;
+  hipStream_t s = nullptr;
+  int lo = 0, hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = the LEAST urgent: a beat never gets in an evaluation's way
+  if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, lo) != hipSuccess) return;
+  float* sink = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&sink), 64) != hipSuccess) { (void)hipStreamDestroy(s); return; }
+  const long long period_ns = (long long)period_us_ * 1000ll;
+  while (!quit_.load(std::memory_order_relaxed)) {
+    std::this_thread::sleep_for(std::chrono::microseconds(period_us_));
+    if (now_ns() - last_activity_.load(std::memory_order_relaxed) < period_ns) continue;   // the engine is working
+    hipLaunchKernelGGL(k_keepwarm, dim3((unsigned)compute_units), dim3(256), 0, s, sink, 1500);
+    if (hipStreamQuery(s) != hipSuccess) (void)hipGetLastError();   // (not ready is the normal answer)
+    beats_.fetch_add(1, std::memory_order_relaxed);
+  }
+  (void)hipStreamSynchronize(s);
+  (void)hipFree(sink);
+  (void)hipStreamDestroy(s);
+}
+
+int KeepWarm::start(int device, int compute_units, int period_us) {
+  stop();
+  if (period_us <= 0) return 0;
+  period_us_ = period_us;
+  quit_.store(false);
+  touch();
+  th_ = std::thread([this, device, compute_units] { run(device, compute_units > 0 ? compute_units : 256); });
+  return 0;
+}
+
+void KeepWarm::stop() {
+  if (th_.joinable()) {
+    quit_.store(true);
+    th_.join();
+  }
+  period_us_ = 0;
+}
+
+}  // namespace ndt

@@ -56,6 +56,18 @@ def test_bench_line_schema():
     assert st["poses_per_launch"] == 20 and st["ms_per_launch"] > 0 and 0 < st["frac"] < 1 and st["launches_timed"] >= 1
     assert c5["svn_k20"]["mean_error_m"] < c5["svn_k20"]["mean_prior_error_m"]
     assert c5["svn_k20"]["svn_iterations_per_sec"] > 100 * c5["svn_k20"]["reference_log"]["svn_iterations_per_sec"]
+    # key meanings of rounds 1-3 kept: the build's own time under ms_target_build, the call's under ..._enqueue
+    assert d["ms_target_build"] == d["ms_target_build_device"] > 0.02 and 0 < d["ms_target_build_enqueue"] < d["ms_target_build"]
+    assert abs(d["ms_align"] + d["ms_target_build"] - d["ms_align_incl_build"]) < 1e-9 and d["ms_align"] > 0
+    # the headline under the protocols of earlier rounds, and at the drivers' cadence
+    pv = d["protocol_variants"]
+    for k in ("headline", "no_wake_steps", "blocking_set_target", "rounds_1_to_3_protocol"):
+        assert pv[k]["ms_per_step"] > 0 and pv[k]["set_target"] in ("deferred", "blocking"), k
+    assert pv["no_wake_steps"]["device_wake_steps"] == 0 and pv["headline"]["device_wake_steps"] == d["device_wake_steps"]
+    cd = d["cadence"]
+    for blk in (cd, cd["keepwarm_1ms"]):
+        assert 0 < blk["ms_step_back_to_back"] and 0 < blk["ms_step_10hz"] and 0 < blk["ms_step_20hz"] and 0 < blk["ms_first_step_after_5s_idle"]
+    assert cd["keepwarm_1ms"]["beats"] > 1000      # (one per millisecond of idling: > 9 s of pauses)
     assert d["evaluations_reused_per_align"] >= 0 and d["config"]["rccl"]["version"] > 20000
     assert 0 <= d["evaluations_prelaunched_per_align"] < d["evaluations_per_align"] and d["prelaunch_timeouts"] == 0
     cb = d["cpu_baseline"]
