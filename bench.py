@@ -712,10 +712,15 @@ def main():
                 step()
                 return 1e3 * (time.perf_counter() - t0)
 
-            def paced(period, n):
+            def paced(period, n, spin=False):
                 t, clk = [], []
                 for _ in range(n):
-                    time.sleep(period)
+                    if spin:   # the HOST thread stays awake (busy-wait), only the device idles
+                        t_end = time.perf_counter() + period
+                        while time.perf_counter() < t_end:
+                            pass
+                    else:
+                        time.sleep(period)
                     clk.append(sclk())
                     t.append(one())
                 clk = [c_ for c_ in clk if c_ is not None]
@@ -727,10 +732,14 @@ def main():
                 busy = float(np.median([one() for _ in range(20)]))
                 m10, c10 = paced(0.1, 25)
                 m20, c20 = paced(0.05, 30)
+                m10s, _ = paced(0.1, 15, spin=True)
                 time.sleep(5.0)
                 c5 = sclk()
                 first = one()
                 return {"ms_step_back_to_back": busy, "ms_step_10hz": m10, "ms_step_20hz": m20, "ms_first_step_after_5s_idle": first,
+                        # the same 10 Hz cadence with the calling thread busy-waiting instead of sleeping: what of the
+                        # difference to back-to-back is the HOST core waking up, not the device
+                        "ms_step_10hz_host_thread_spinning": m10s,
                         "sclk_mhz_before_a_10hz_step": c10, "sclk_mhz_before_a_20hz_step": c20, "sclk_mhz_after_5s_idle": c5}
 
             v = block()

@@ -396,6 +396,14 @@ class NormalDistributionsTransform
   // vg.setInputCloud(map); vg.filter(*ds_map)) ----
   // `out` receives the centroid (x, y, z and, for point types with an `intensity` member at byte 16, the intensity) of
   // every occupied voxel in ascending voxel index; the engine's target and source are left as they are
+  template <class P>
+  static auto intensity_offset_of(int) -> decltype((void)static_cast<const float*>(&std::declval<const P&>().intensity), int()) {
+    static const P probe{};
+    return (int)(reinterpret_cast<const char*>(&probe.intensity) - reinterpret_cast<const char*>(&probe.x));
+  }
+  template <class P>
+  static int intensity_offset_of(long) { return -1; }
+
   template <class Cloud>
   void voxelDownsample(const Cloud& in, float leaf, Cloud& out) {
     out.points.clear();
@@ -404,7 +412,9 @@ class NormalDistributionsTransform
     using P = typename std::decay<decltype(in.points[0])>::type;
     out.points.resize(in.points.size());   // value-initialised points: the fields the engine does not write keep their defaults
     size_t m = 0;
-    status_ = ndt_voxel_downsample(h_, &in.points[0].x, in.points.size(), sizeof(P), sizeof(P) >= 32 ? 16 : -1, leaf,
+    // the intensity is averaged only for point types that HAVE a float member of that name, at ITS offset (pcl::PointXYZRGB
+    // and PointNormal are 32 bytes too and carry packed colour / a normal at byte 16: never averaged as a float)
+    status_ = ndt_voxel_downsample(h_, &in.points[0].x, in.points.size(), sizeof(P), intensity_offset_of<P>(0), leaf,
                                    &out.points[0].x, out.points.size(), &m);
     out.points.resize(status_ == NDT_OK ? m : 0);
   }
