@@ -815,6 +815,26 @@ def main():
             else:
                 n_comm = ndt.commRankCount()
                 current["mode"], current["steps"] = mode, 0
+                integrity = None
+                if mode == "p2p":
+                    # Before anything is timed over the peer-write exchange: 10 000 lock-step rounds of patterned slots
+                    # through the exchange areas (ndt_comm_p2p_selftest) -- the direct test of the 16-byte single-copy
+                    # assumption the in-kernel exchange rests on, the first time it crosses a device boundary.
+                    try:
+                        it = ndt.commP2pSelftest(int(os.environ.get("NDT_BENCH_P2P_SELFTEST", "10000")))
+                    except pkg.NdtError as e:
+                        it = {"error": str(e), "torn": -1, "missed": -1, "rounds": 0, "longest_us": 0.0}
+                    board.barrier()
+                    worst = board.allmax(float(max(it["torn"], 0) + max(it["missed"], 0) + (1 if "error" in it else 0)))
+                    integrity = dict(it, ranks_clean=bool(worst == 0.0))
+                    if worst != 0.0:
+                        variants[mode] = {"failed": "slot integrity pass", "slot_integrity": integrity}
+                        if out is not None:
+                            out.setdefault("reduce_failed", mode)
+                        ndt.commDestroy()
+                        board.barrier()
+                        dog.cancel()
+                        continue
                 res = timed_region()
                 if res is None:      # an engine error on some rank: the variant is reported as failed, the others stand
                     variants[mode] = "failed"
@@ -848,6 +868,43 @@ def main():
                                                      "the same order and must agree bit for bit" % (digests["p2p"], digests["shm"]))
                     if mode == "rccl":
                         variants[mode]["ncclCommCount"] = n_comm
+                    if integrity is not None:
+                        variants[mode]["slot_integrity"] = integrity
+                    # What the sum itself costs under this transport and how long every rank's kernel runs -- a flat
+                    # scaling curve then reads as "reduce-bound" or "fixed-chain-bound" from this one run:
+                    # an instrumented repeat (ordinary launches, HIP events attached to the dispatch; host-side transports:
+                    # wall time of the cross-rank sum; peer-write: the exchange's duration counted inside the kernel)
+                    try:
+                        if mode == "p2p":
+                            ndt.commP2pStats(reset=True)
+                        ndt.enableKernelTiming(True)
+                        tq0 = ndt.getTiming()
+                        for _ in range(max(2, args.steps // 4)):
+                            step()
+                        tq1 = ndt.getTiming()
+                        ndt.enableKernelTiming(False)
+                        nq = max(tq1["n_timed_evals"] - tq0["n_timed_evals"], 1)
+                        k_us = 1e3 * (tq1["ms_eval_kernel_total"] - tq0["ms_eval_kernel_total"]) / nq
+                        if mode == "p2p":
+                            ps = ndt.commP2pStats()
+                            r_us, r_max = ps["mean_us"], ps["max_us"]
+                        else:
+                            r_us, r_max = 1e3 * (tq1["ms_reduce_kernel_total"] - tq0["ms_reduce_kernel_total"]) / nq, None
+                        per_rank = [json.loads(b.decode()) for b in board.allgather(json.dumps([k_us, r_us]).encode())]
+                        variants[mode]["k_derivatives_us_per_rank"] = [round(p_[0], 2) for p_ in per_rank]
+                        variants[mode]["reduce_us_per_evaluation_per_rank"] = [round(p_[1], 2) for p_ in per_rank]
+                        variants[mode]["reduce_us_per_evaluation"] = max(p_[1] for p_ in per_rank)
+                        if r_max is not None:
+                            variants[mode]["reduce_us_longest_on_rank0"] = r_max
+                        variants[mode]["reduce_note"] = ("local sum in hand -> global sum in hand: " +
+                                                         {"shm": "host wall time of the shared-memory sum", "p2p": "own row published -> every rank's row read, inside the kernel's final sum",
+                                                          "rccl": "ncclAllReduce + read-back on the engine's stream (host wall time)"}[mode])
+                    except Exception as e:  # noqa: BLE001  (instrumentation must never cost the variant)
+                        variants[mode]["reduce_probe_error"] = "%s: %s" % (type(e).__name__, e)
+                        try:
+                            ndt.enableKernelTiming(False)
+                        except Exception:  # noqa: BLE001
+                            pass
                     if out is None and sane:
                         out = instrumented(res, mode, variants)
                         if rank != 0:

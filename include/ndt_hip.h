@@ -479,6 +479,15 @@ int ndt_comm_init_shm(ndt_handle* h, const char* name, int rank, int nranks);
 #define NDT_P2P_HANDLE_BYTES 64
 int ndt_comm_p2p_handle(ndt_handle* h, void* out_handle);
 int ndt_comm_init_p2p(ndt_handle* h, const void* handles, int rank, int nranks);
+/* First-contact instrumentation of the peer-write reducer (round 5).
+ * ndt_comm_p2p_selftest: COLLECTIVE (every rank, same `rounds`; put a barrier of your own behind it): `rounds` lock-step rounds
+ * of patterned {tag, value} slots through the exchange areas, written and read exactly as the derivative kernel's final sum
+ * does it -- the direct test of "a 16-byte slot is seen entirely old or entirely new" across devices.  out: {rounds completed,
+ * slots seen with a new tag and an old value, rounds a peer missed (the pass stops at the first), longest round in 10 ns ticks}.
+ * ndt_comm_p2p_stats: out = {exchanges made inside a kernel's final sum since ndt_comm_init_p2p (or the last reset), their
+ * summed duration and the longest one in 10 ns ticks (own row published -> every rank's row read), exchanges a peer was late for}. */
+int ndt_comm_p2p_selftest(ndt_handle* h, int rounds, int64_t out[4]);
+int ndt_comm_p2p_stats(ndt_handle* h, int64_t out[4], int reset);
 /* caller-supplied all-reduce(sum) over NDT_EVAL_WORDS doubles, in place */
 typedef int (*ndt_allreduce_fn)(void* ctx, double* words, int n);
 int ndt_comm_init_hook(ndt_handle* h, ndt_allreduce_fn fn, void* ctx, int rank, int nranks);
@@ -531,7 +540,8 @@ int ndt_svn_align(ndt_handle* h, const ndt_svn_params* p, const double prior16[1
 /* ---- instrumentation ------------------------------------------------------ */
 typedef struct ndt_timing {
   double ms_last_eval_kernel;   /* HIP-event time of the last derivative kernel */
-  double ms_last_reduce_kernel; /* 0 since the final sum moved into the derivative kernel */
+  double ms_last_reduce_kernel; /* round 5: wall time of the last CROSS-RANK sum on the host (shm / hook transports; 0 without
+                                 * a reducer; the peer-write exchange runs inside the kernel: ndt_comm_p2p_stats) */
   double ms_last_build;
   int64_t n_eval_launches;      /* since handle creation */
   double ms_eval_kernel_total;  /* summed HIP-event time of the accumulation kernel while timing is on */

@@ -207,6 +207,7 @@ ABI_SYMBOLS = [
     "ndt_set_handoff_mode", "ndt_get_handoff_mode", "ndt_wait", "ndt_get_handoff_timing",
     "ndt_voxel_downsample_device", "ndt_voxel_downsample", "ndt_get_iteration_history",
     "ndt_get_tuning", "ndt_set_tuning", "ndt_set_keepwarm", "ndt_get_keepwarm",
+    "ndt_comm_p2p_selftest", "ndt_comm_p2p_stats",
 ]
 
 _lib = None
@@ -222,6 +223,8 @@ def lib():
         L = C.CDLL(LIB_PATH)
         fp, dp, vp = C.POINTER(C.c_float), C.POINTER(C.c_double), C.c_void_p
         L.ndt_abi_version.restype = C.c_int
+        L.ndt_comm_p2p_selftest.argtypes = [vp, C.c_int, C.POINTER(C.c_int64)]
+        L.ndt_comm_p2p_stats.argtypes = [vp, C.POINTER(C.c_int64), C.c_int]
         L.ndt_set_keepwarm.argtypes = [vp, C.c_int]
         L.ndt_get_keepwarm.argtypes = [vp, C.POINTER(C.c_longlong)]
         L.ndt_get_tuning.argtypes = [C.POINTER(Tuning)]
@@ -776,6 +779,19 @@ class NormalDistributionsTransform:
         if n < 0:
             raise NdtError(n, "ndt_comm_rank_count")
         return n
+
+    def commP2pSelftest(self, rounds=10000):
+        """COLLECTIVE slot-integrity pass of the peer-write reducer: dict(rounds, torn, missed, longest_us)."""
+        out = (C.c_int64 * 4)()
+        self._check(lib().ndt_comm_p2p_selftest(self._h, int(rounds), out))
+        return dict(rounds=int(out[0]), torn=int(out[1]), missed=int(out[2]), longest_us=out[3] * 0.01)
+
+    def commP2pStats(self, reset=False):
+        """In-kernel exchanges since init / the last reset: dict(exchanges, mean_us, max_us, late)."""
+        out = (C.c_int64 * 4)()
+        self._check(lib().ndt_comm_p2p_stats(self._h, out, int(reset)))
+        n = int(out[0])
+        return dict(exchanges=n, mean_us=(out[1] * 0.01 / n) if n else 0.0, max_us=out[2] * 0.01, late=int(out[3]))
 
     def commDestroy(self):
         self._check(lib().ndt_comm_destroy(self._h))

@@ -1218,6 +1218,7 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
     int rc = h->red.allreduce_device(h->dres.p, EV_WORDS, s, &h->err);
     if (rc) return rc;
     HIP_TRY(h, hipMemcpyAsync(h->result.h, h->dres.p, EV_WORDS * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (h->timing && h->ev2) HIP_TRY(h, hipEventRecord(h->ev2, s));
   }
   if (spin) {
     int rc = wait_slots(h, seq, 1, buf);
@@ -1232,6 +1233,15 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
     h->tm.ms_last_eval_kernel = ms;
     h->tm.ms_eval_kernel_total += ms;
     h->tm.n_timed_evals++;
+    if (dev_out && h->ev2) {   // RCCL: the all-reduce and the read-back behind the kernel, device time
+      float mr = 0;
+      if (hipEventElapsedTime(&mr, h->ev1, h->ev2) == hipSuccess) {
+        h->tm.ms_last_reduce_kernel = mr;
+        h->tm.ms_reduce_kernel_total += mr;
+      } else {
+        (void)hipGetLastError();
+      }
+    }
   }
   double words[EV_WORDS];
   if (spin) {
@@ -1249,8 +1259,16 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
     }
     // (otherwise the words ARE the global sums already)
   } else if (!dev_out) {
+    // (kernel timing on: the cross-rank sum's own wall time, from the local sum in hand to the global one -- what the
+    // --gpus N bench line reports per transport)
+    const auto t_red = std::chrono::steady_clock::now();
     int rc = h->red.allreduce_host(words, EV_WORDS, &h->err);
     if (rc) return rc;
+    if (h->timing && h->red.mode() != NDT_REDUCE_NONE) {
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_red).count();
+      h->tm.ms_last_reduce_kernel = ms;
+      h->tm.ms_reduce_kernel_total += ms;
+    }
   }
   // word 31 is zero by construction; the in-kernel final sum raises it when it gave up waiting
   // for a partial row (a lost hand-off must not look like a converged result), and the kernel
@@ -2442,6 +2460,29 @@ int ndt_comm_init_p2p(ndt_handle* h, const void* handles, int rank, int nranks) 
   if (rc) return rc;
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return h->red.init_p2p(handles, rank, nranks, &h->err);
+}
+
+int ndt_comm_p2p_stats(ndt_handle* h, int64_t out[4], int reset) {
+  if (!h || !out) return NDT_ERR_INVALID_ARG;
+  int rc = bind_device(h);
+  if (rc) return rc;
+  unsigned long long v[4] = {0, 0, 0, 0};
+  rc = h->red.p2p_stats(v, reset != 0, &h->err);
+  for (int k = 0; k < 4; ++k) out[k] = (int64_t)v[k];
+  return rc;
+}
+
+int ndt_comm_p2p_selftest(ndt_handle* h, int rounds, int64_t out[4]) {
+  if (!h || !out || rounds < 1) return NDT_ERR_INVALID_ARG;
+  int rc = bind_device(h);
+  if (rc) return rc;
+  quit_prelaunched(h);
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream2));
+  unsigned long long v[4] = {0, 0, 0, 0};
+  rc = h->red.p2p_selftest(rounds, v, &h->err);
+  for (int k = 0; k < 4; ++k) out[k] = (int64_t)v[k];
+  return rc;
 }
 
 int ndt_comm_init_hook(ndt_handle* h, ndt_allreduce_fn fn, void* ctx, int rank, int nranks) {

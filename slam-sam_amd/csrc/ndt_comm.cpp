@@ -283,7 +283,10 @@ int Reducer::init_p2p(const void* handles, int rank, int nranks, std::string* er
   }
   for (int r = 0; r < nranks; ++r) info.area[r] = (unsigned long long)reinterpret_cast<uintptr_t>(xpeer_[r]);
   hipError_t e = hipSuccess;
-  if (!xinfo_dev_) e = hipMalloc(&xinfo_dev_, sizeof(XchgInfo));
+  if (!xstats_) e = hipMalloc(&xstats_, 4 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMemset(xstats_, 0, 4 * sizeof(unsigned long long));
+  info.stats = (unsigned long long)reinterpret_cast<uintptr_t>(xstats_);
+  if (e == hipSuccess && !xinfo_dev_) e = hipMalloc(&xinfo_dev_, sizeof(XchgInfo));
   if (e == hipSuccess) e = hipMemcpy(xinfo_dev_, &info, sizeof(info), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     (void)hipGetLastError();
@@ -320,6 +323,110 @@ __global__ void __launch_bounds__(64) k_publish_row(XchgInfo info, unsigned long
 }
 }  // namespace
 #endif
+
+int Reducer::p2p_stats(unsigned long long out[4], bool reset, std::string* err) {
+  if (mode_ != NDT_REDUCE_P2P || !xstats_ || !out) return NDT_ERR_INVALID_ARG;
+  hipError_t e = hipMemcpy(out, xstats_, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && reset) e = hipMemset(xstats_, 0, 4 * sizeof(unsigned long long));
+  if (e != hipSuccess) {
+    if (err) *err = hip_err("reading the exchange counters", e);
+    return NDT_ERR_COMM;
+  }
+  return NDT_OK;
+}
+
+#ifdef __HIPCC__
+namespace {
+// value of word v that rank w writes under tag t: every bit depends on every input (splitmix64)
+__host__ __device__ inline unsigned long long selftest_pattern(unsigned long long t, int w, int v) {
+  unsigned long long z = t * 0x9E3779B97F4A7C15ull + (unsigned long long)(w * 64 + v) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+// One wave per rank; lane v < 32 owns word v.  Round k (tag = base + k): the own row goes to every rank's area, then the
+// rows of all ranks are polled in the own area -- the loads and stores of xchg_allsum (ndt_derivs.hip), the same
+// offsets, the same two generations (a rank can be one round ahead of the slowest at most).  A slot whose tag is this
+// round's and whose value is not the pattern was seen half-written.
+__global__ void __launch_bounds__(64) k_xchg_selftest(XchgInfo info, unsigned long long base, int rounds, unsigned long long* out) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const int v = threadIdx.x, n = info.nranks, me = info.rank;
+  unsigned long long torn = 0ull, done = 0ull, late = 0ull, longest = 0ull;
+  const __amdgpu_buffer_rsrc_t own = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(info.area[me]), 0, 0xFFFFFFFFu, 0x00020000);
+  for (int k = 1; k <= rounds; ++k) {   // (wave-uniform control flow: every lane takes the same exits)
+    const unsigned long long tag = base + (unsigned long long)k;
+    if (v < NDT_EVAL_WORDS) {
+      const unsigned long long bits = selftest_pattern(tag, me, v);
+      u32x4 d;
+      d.x = (unsigned int)tag; d.y = (unsigned int)(tag >> 32); d.z = (unsigned int)bits; d.w = (unsigned int)(bits >> 32);
+      for (int r = 0; r < n; ++r) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(info.area[r]), 0, 0xFFFFFFFFu, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(d, rs, xchg_slot_offset(tag, me, v), 0, 17 /* sc0 sc1 */);
+      }
+    }
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    bool timed_out = false;
+    for (int r = 0; r < n; ++r) {
+      for (;;) {
+        asm volatile("" ::: "memory");
+        u32x4 q;
+        q.x = (unsigned int)tag; q.y = (unsigned int)(tag >> 32); q.z = 0u; q.w = 0u;
+        if (v < NDT_EVAL_WORDS) q = __builtin_amdgcn_raw_buffer_load_b128(own, xchg_slot_offset(tag, r, v), 0, 17);
+        const bool here = q.x == (unsigned int)tag && q.y == (unsigned int)(tag >> 32);
+        if (__ballot(here) == ~0ull) {
+          const unsigned long long got = ((unsigned long long)q.w << 32) | q.z;
+          if (v < NDT_EVAL_WORDS && got != selftest_pattern(tag, r, v)) ++torn;
+          break;
+        }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > XCHG_TIMEOUT_TICKS * 50ull) { timed_out = true; break; }   // 1 s
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (timed_out) break;
+    }
+    const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t0;
+    longest = dt > longest ? dt : longest;
+    if (timed_out) { ++late; break; }
+    ++done;
+  }
+  // lane sums of the torn slots; the other counters are wave-uniform
+  for (int off = 32; off > 0; off >>= 1) torn += __shfl_xor(torn, off);
+  if (v == 0) { out[0] = done; out[1] = torn; out[2] = late; out[3] = longest; }
+}
+}  // namespace
+#endif
+
+int Reducer::p2p_selftest(int rounds, unsigned long long out[4], std::string* err) {
+  if (mode_ != NDT_REDUCE_P2P || rounds < 1 || !out) return NDT_ERR_INVALID_ARG;
+#ifdef __HIPCC__
+  XchgInfo info;
+  std::memset(&info, 0, sizeof(info));
+  info.rank = rank_;
+  info.nranks = nranks_;
+  for (int r = 0; r < nranks_; ++r) info.area[r] = (unsigned long long)reinterpret_cast<uintptr_t>(xpeer_[r]);
+  unsigned long long* d_out = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_out), 4 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMemset(d_out, 0, 4 * sizeof(unsigned long long));
+  if (e == hipSuccess) {
+    // tags far above any evaluation count, a fresh range per pass; the slots they leave behind never match a real round.
+    // EVEN base: round k uses generation k & 1 on every rank
+    const unsigned long long base = (1ull << 62) + (xtests_++ << 32);
+    hipLaunchKernelGGL(k_xchg_selftest, dim3(1), dim3(64), 0, nullptr, info, base, rounds, d_out);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+  }
+  if (e == hipSuccess) e = hipMemcpy(out, d_out, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  if (d_out) (void)hipFree(d_out);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    if (err) *err = hip_err("exchange-area integrity pass", e);
+    return NDT_ERR_COMM;
+  }
+  return NDT_OK;
+#else
+  (void)err;
+  return NDT_ERR_UNSUPPORTED;
+#endif
+}
 
 // one row {round, value} x n of the own rank into every rank's area, from the host (batched evaluations)
 int Reducer::p2p_publish_from_host(uint64_t round, const double* words, int n, std::string* err) {
@@ -512,6 +619,7 @@ void Reducer::destroy() {
       xpeer_[r] = nullptr;
     }
     if (xinfo_dev_) { (void)hipFree(xinfo_dev_); xinfo_dev_ = nullptr; }
+    if (xstats_) { (void)hipFree(xstats_); xstats_ = nullptr; }
     if (xarea_) { (void)hipFree(xarea_); xarea_ = nullptr; }
     if (xstage_) { (void)hipHostFree(xstage_); xstage_ = nullptr; }
     if (xback_) { (void)hipHostFree(xback_); xback_ = nullptr; }

@@ -41,6 +41,16 @@ class Reducer {
   const XchgInfo* p2p_info() const { return static_cast<const XchgInfo*>(xinfo_dev_); }
   uint64_t p2p_round() const { return xround_; }
   void p2p_set_round(uint64_t r) { xround_ = r; }
+  // {exchanges made inside a kernel, their summed duration, the longest (10 ns ticks), exchanges a peer was late for}
+  // since init_p2p; `reset`: back to zero afterwards
+  int p2p_stats(unsigned long long out[4], bool reset, std::string* err);
+  // COLLECTIVE slot-integrity pass over the exchange areas (every rank calls it with the same `rounds`): `rounds` lock-step
+  // rounds of patterned {tag, value} slots, the value a function of (tag, writer, word), written to every rank's area and
+  // read back by every rank exactly as the derivative kernel's final sum does it (16-byte system-scope stores and loads, two
+  // generations) -- the only direct test of the assumption that such a slot is seen entirely old or entirely new.
+  // out: {rounds completed, slots whose tag was new and whose value was not (torn), rounds a peer did not show up in time
+  // (the pass stops at the first), longest wait for a round in 10 ns ticks}
+  int p2p_selftest(int rounds, unsigned long long out[4], std::string* err);
   // host side of the exchange: the rows of round `round` of the own area, waited for (120 s) and added in
   // rank order -- the continuation of a kernel that reported EV_FAIL = 3 (its own row is published)
   int p2p_finish_on_host(uint64_t round, double* words, int n, std::string* err);
@@ -73,6 +83,8 @@ class Reducer {
   void* xinfo_dev_ = nullptr;
   uint64_t xround_ = 0;                   // global evaluations exchanged so far
   uint64_t xbround_ = 0;                  // batched rounds exchanged so far (their own region of the area, their own tags)
+  void* xstats_ = nullptr;                // four counters (XchgInfo::stats), device memory
+  uint64_t xtests_ = 0;                   // integrity passes run so far (their tags never repeat)
   double* xstage_ = nullptr;              // pinned, device-mapped: the batch's values on their way to the publish kernel
   unsigned long long* xback_ = nullptr;   // pinned: the rows of a batch round as read back
   int p2p_publish_from_host(uint64_t round, const double* words, int n, std::string* err);

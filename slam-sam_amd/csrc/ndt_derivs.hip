@@ -861,6 +861,14 @@ __device__ __forceinline__ double xchg_allsum(const XchgInfo* __restrict__ xi, u
     for (int k = 0; k < XB; ++k)
       if (r0 + k < n) s += __longlong_as_double((long long)(((unsigned long long)q[k].w << 32) | q[k].z));
   }
+  if (v == 0 && xi->stats != 0ull) {   // (fire and forget: nobody waits for these)
+    unsigned long long* st = reinterpret_cast<unsigned long long*>(xi->stats);
+    const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t0;
+    __hip_atomic_fetch_add(st + 0, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(st + 1, dt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_max(st + 2, dt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (*late) __hip_atomic_fetch_add(st + 3, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   return s;
 }
 

@@ -203,6 +203,9 @@ constexpr size_t XCHG_AREA_BYTES = XCHG_SINGLE_BYTES + XCHG_BATCH_BYTES;
 struct XchgInfo {
   int rank, nranks;
   unsigned long long area[XCHG_MAX_RANKS];  // every rank's exchange area as mapped in THIS process; [rank] is local
+  // four counters in this rank's device memory (ndt_comm_p2p_stats): exchanges made inside a kernel, their summed and
+  // their longest duration -- own row published to every row gathered -- in 10 ns ticks, exchanges a peer was late for
+  unsigned long long stats;
 };
 __host__ __device__ inline unsigned int xchg_slot_offset(unsigned long long round, int row, int word) {
   return (unsigned int)((((unsigned int)(round & 1ull) * XCHG_MAX_RANKS + (unsigned int)row) * EV_WORDS + (unsigned int)word) * 16u);

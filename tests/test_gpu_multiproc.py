@@ -34,6 +34,12 @@ def _worker(rank, world, name, out_dir, mode="shm"):
     else:
         ndt.commInitShm(name, rank, world)
     assert ndt.commRankCount() == world
+    selftest = stats0 = None
+    if mode == "p2p":
+        # the slot-integrity pass (collective) before the exchange areas carry evaluations, and once more behind them below
+        selftest = ndt.commP2pSelftest(2000)
+        board.barrier()
+        stats0 = ndt.commP2pStats(reset=True)
     T = ndt.align(cfg["guess"])
     r = ndt.getResult()
     used, quit, timeouts = ndt.prelaunchCounters()
@@ -49,6 +55,19 @@ def _worker(rank, world, name, out_dir, mode="shm"):
     b5_again = ndt.evalDerivatives(poses5)
     assert all(x["score"] == y["score"] and np.array_equal(x["hessian"], y["hessian"]) for x, y in zip(b5, b5_again))
     T2 = ndt.align(cfg["guess"])                      # a second align on the same reducer (round tags keep counting)
+    if mode == "p2p":
+        stats = ndt.commP2pStats()
+        board.barrier()
+        again = ndt.commP2pSelftest(501)              # (odd: the last round sits in generation 1, where the next evaluation writes)
+        board.barrier()
+        T3 = ndt.align(cfg["guess"])                  # ... and evaluations behind an integrity pass: its tags never match a real round
+        assert np.array_equal(T3, T2)
+        assert selftest == dict(selftest, rounds=2000, torn=0, missed=0) and again == dict(again, rounds=501, torn=0, missed=0), (selftest, again)
+        # (the late-rank test makes rank 1 late for one evaluation on purpose: the other rank's kernel counts it)
+        assert stats0["exchanges"] == 0 and (stats["late"] == 0 or os.environ.get("NDT_DEBUG_P2P_LATE_MS"))
+        # every single-pose evaluation (and the score-only one) was exchanged inside a kernel; batches go through the host
+        assert stats["exchanges"] >= 2 * r["n_evaluations"] and 0 < stats["mean_us"] <= stats["max_us"], stats
+        assert stats["max_us"] < 20000 or os.environ.get("NDT_DEBUG_P2P_LATE_MS"), stats   # (20 ms: the kernel's own time-out)
     np.savez(os.path.join(out_dir, "%s_rank%d.npz" % (mode, rank)), T=T, T2=T2, it=r["iterations"], ev=r["n_evaluations"],
              H=r["hessian"], tp=r["transform_probability"], n_pairs=e["n_pairs"], score=e["score"], g=e["gradient"],
              sc=sc["score"], used=used, timeouts=timeouts, finishes=ndt.p2pHostFinishes(),
