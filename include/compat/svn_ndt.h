@@ -14,4 +14,10 @@ using SvnNdtResult = ndt_hip::SvnNdtResult;
 template <typename PointSource, typename PointTarget>
 using SvnNormalDistributionsTransform = ndt_hip::SvnNormalDistributionsTransform<PointSource, PointTarget>;
 
+// svn_ndt::VoxelGridCovariance<PointT> (ref: extern/svn_ndt/include/voxel_grid_covariance.h): the host-side view of the
+// device's voxel grid -- getLeaf(index | point), getLeaves, getCentroids, nearestKSearch, radiusSearch,
+// getNeighborhoodAtPoint7 / 1, getMinPointPerVoxel, getCovEigValueInflationRatio; one grid type whatever the point type
+template <typename PointT>
+using VoxelGridCovariance = ndt_hip::TargetGrid;
+
 }  // namespace svn_ndt

@@ -31,6 +31,7 @@
 #pragma once
 
 #include <algorithm>
+#include <cmath>
 #include <array>
 #include <cstddef>
 #include <cstring>
@@ -194,11 +195,14 @@ class TargetGrid {
   using Entry = std::pair<size_t, Leaf>;  // {voxel index, leaf}
   const std::vector<Entry>& getLeaves() const { return leaves_; }
   int getMinPointPerVoxel() const { return min_points_; }
-  // O(log V): the leaves are kept in ascending index order
+  // O(log V): the leaves are kept in ascending index order.  Like the reference's getLeaf(index), only a VALID leaf is
+  // handed out -- at least getMinPointPerVoxel() points (a leaf whose covariance could not be inverted carries -1; ref:
+  // voxel_grid_covariance.h:262-278).  (The engine exports the valid leaves only, so getLeaves() iterates over those; the
+  // reference's map also holds the voxels with too few points, which its users filter out: include/pipeline.hpp:186.)
   const Leaf* getLeaf(size_t index) const {
     auto it = std::lower_bound(leaves_.begin(), leaves_.end(), index,
                                [](const Entry& e, size_t i) { return e.first < i; });
-    return (it != leaves_.end() && it->first == index) ? &it->second : nullptr;
+    return (it != leaves_.end() && it->first == index && it->second.d.point_count >= min_points_) ? &it->second : nullptr;
   }
   Vector3d getLeafCenter(size_t index) const {
     double c[3] = {0.0, 0.0, 0.0};
@@ -206,8 +210,121 @@ class TargetGrid {
       for (int a = 0; a < 3; ++a) c[a] = (double)l->d.center[a];
     return detail::from_colmajor<Vector3d>(c, 3, 1);
   }
+
+  // ---- the reference grid's query surface (round 5; ref: extern/svn_ndt/include/voxel_grid_covariance.h:194-200,280-381,
+  // voxel_grid_covariance_impl.hpp:46-71,455-615), answered on the host from the exported leaves and the grid geometry --
+  // the same f32 bounds test and index arithmetic, so a query lands in the voxel the engine's kernels put it in.  Points
+  // are anything with x / y / z members (pcl::PointXYZ, PointXYZI, the PCL-free point types of this header) or
+  // operator[] (Eigen::Vector3f).  No driver calls these; they exist so that code written against the reference's grid
+  // class keeps compiling.
+  using LeafConstPtr = const Leaf*;
+  double getCovEigValueInflationRatio() const { return eig_ratio_; }
+  bool isPointWithinBounds(float px, float py, float pz) const {   // ref: voxel_grid_covariance_impl.hpp:46-71
+    if (gi_.inverse_leaf_size == 0.0f) return false;
+    const float w = gi_.leaf_size;
+    return px >= (float)gi_.min_b[0] * w && px < (float)(gi_.max_b[0] + 1) * w && py >= (float)gi_.min_b[1] * w &&
+           py < (float)(gi_.max_b[1] + 1) * w && pz >= (float)gi_.min_b[2] * w && pz < (float)(gi_.max_b[2] + 1) * w;
+  }
+  LeafConstPtr getLeafAt(float px, float py, float pz) const {    // ref: voxel_grid_covariance.h:280-303
+    if (!isPointWithinBounds(px, py, pz)) return nullptr;
+    const float il = gi_.inverse_leaf_size;
+    const int i0 = static_cast<int>(std::floor(px * il) - (float)gi_.min_b[0]);
+    const int i1 = static_cast<int>(std::floor(py * il) - (float)gi_.min_b[1]);
+    const int i2 = static_cast<int>(std::floor(pz * il) - (float)gi_.min_b[2]);
+    return getLeaf(static_cast<size_t>(i0 + i1 * gi_.div_b[0] + i2 * gi_.div_b[0] * gi_.div_b[1]));
+  }
+  template <class P>
+  auto getLeaf(const P& p) const -> decltype((void)p.x, LeafConstPtr()) { return getLeafAt(p.x, p.y, p.z); }
+  template <class V>
+  auto getLeaf(const V& v) const -> decltype((void)v[0], (void)v.data(), LeafConstPtr()) { return getLeafAt((float)v[0], (float)v[1], (float)v[2]); }
+  // DIRECT7 / DIRECT1 (ref: voxel_grid_covariance_impl.hpp:560-615): the point offset by +-leaf in f32 and re-classified
+  template <class P>
+  int getNeighborhoodAtPoint7(const P& ref, std::vector<LeafConstPtr>& neighbors) const {
+    neighbors.clear();
+    neighbors.reserve(7);
+    const float w = gi_.leaf_size, x = ref.x, y = ref.y, z = ref.z;
+    if (LeafConstPtr c = getLeafAt(x, y, z)) neighbors.push_back(c);
+    if (!(w > 0.0f)) return (int)neighbors.size();
+    const float probe[6][3] = {{x + w, y, z}, {x - w, y, z}, {x, y + w, z}, {x, y - w, z}, {x, y, z + w}, {x, y, z - w}};
+    for (const auto& q : probe)
+      if (LeafConstPtr l = getLeafAt(q[0], q[1], q[2])) neighbors.push_back(l);
+    return (int)neighbors.size();
+  }
+  template <class P>
+  int getNeighborhoodAtPoint1(const P& ref, std::vector<LeafConstPtr>& neighbors) const {
+    neighbors.clear();
+    if (LeafConstPtr l = getLeafAt(ref.x, ref.y, ref.z)) neighbors.push_back(l);
+    return (int)neighbors.size();
+  }
+  // the centroid cloud the reference's kd-tree is built on: the f32-rounded means of the valid leaves, ascending voxel
+  // index (ref: voxel_grid_covariance_impl.hpp:400-440)
+  struct Centroid { float x, y, z; };
+  const std::vector<Centroid>& getCentroids() const {
+    if (!centroids_built_) {
+      centroids_.clear();
+      centroid_leaf_.clear();
+      for (size_t i = 0; i < leaves_.size(); ++i) {
+        const ndt_leaf& d = leaves_[i].second.d;
+        if (d.point_count < min_points_) continue;
+        centroids_.push_back(Centroid{(float)d.mean[0], (float)d.mean[1], (float)d.mean[2]});
+        centroid_leaf_.push_back(i);
+      }
+      centroids_built_ = true;
+    }
+    return centroids_;
+  }
+  // FLANN's L2_Simple in f32 (accumulated x, y, z), strict `<` on the squared radius, results by ascending distance -- what
+  // pcl::KdTreeFLANN::radiusSearch returns (ref: voxel_grid_covariance_impl.hpp:505-554).  A linear scan of the centroids: a
+  // host-side convenience, not the engine's KDTREE path (that one is the 27-cell scan inside k_derivatives).
+  template <class P>
+  int radiusSearch(const P& point, double radius, std::vector<LeafConstPtr>& k_leaves, std::vector<float>& k_sqr_distances,
+                   unsigned int max_nn = 0) const {
+    k_leaves.clear();
+    k_sqr_distances.clear();
+    if (radius <= 0.0) return 0;
+    const float r2 = (float)(radius * radius);
+    std::vector<std::pair<float, size_t>> hits;
+    const std::vector<Centroid>& c = getCentroids();
+    for (size_t i = 0; i < c.size(); ++i) {
+      const float d = sqr_distance(c[i], point.x, point.y, point.z);
+      if (d < r2) hits.emplace_back(d, i);
+    }
+    std::sort(hits.begin(), hits.end());
+    if (max_nn > 0 && hits.size() > max_nn) hits.resize(max_nn);
+    for (const auto& h : hits) { k_leaves.push_back(&leaves_[centroid_leaf_[h.second]].second); k_sqr_distances.push_back(h.first); }
+    return (int)k_leaves.size();
+  }
+  template <class P>
+  int nearestKSearch(const P& point, int k, std::vector<LeafConstPtr>& k_leaves, std::vector<float>& k_sqr_distances) const {
+    k_leaves.clear();
+    k_sqr_distances.clear();
+    if (k <= 0) return 0;
+    std::vector<std::pair<float, size_t>> all;
+    const std::vector<Centroid>& c = getCentroids();
+    all.reserve(c.size());
+    for (size_t i = 0; i < c.size(); ++i) all.emplace_back(sqr_distance(c[i], point.x, point.y, point.z), i);
+    const size_t n = std::min(all.size(), (size_t)k);
+    std::partial_sort(all.begin(), all.begin() + n, all.end());
+    for (size_t i = 0; i < n; ++i) { k_leaves.push_back(&leaves_[centroid_leaf_[all[i].second]].second); k_sqr_distances.push_back(all[i].first); }
+    return (int)n;
+  }
+
   std::vector<Entry> leaves_;
   int min_points_ = 6;
+  ndt_grid_info gi_{};          // geometry of the grid the leaves were exported from
+  double eig_ratio_ = 0.01;
+
+ private:
+  static float sqr_distance(const Centroid& c, float px, float py, float pz) {
+    const float ex = px - c.x, ey = py - c.y, ez = pz - c.z;
+    float d = ex * ex;
+    d = d + ey * ey;
+    d = d + ez * ez;
+    return d;
+  }
+  mutable std::vector<Centroid> centroids_;
+  mutable std::vector<size_t> centroid_leaf_;   // centroid -> position in leaves_
+  mutable bool centroids_built_ = false;
 };
 
 #if NDT_HIP_WITH_PCL
@@ -381,9 +498,11 @@ class NormalDistributionsTransform
   // ---- voxel grid (ref: include/pipeline.hpp:178-206) ----
   const TargetGrid& getTargetCells() {
     ndt_grid_info gi;
-    grid_.leaves_.clear();
+    grid_ = TargetGrid();
     grid_.min_points_ = prm_.min_points_per_voxel < 3 ? 3 : prm_.min_points_per_voxel;
+    grid_.eig_ratio_ = prm_.eig_inflation_ratio;
     if (h_ && ndt_get_grid_info(h_, &gi) == NDT_OK && gi.n_leaves > 0) {
+      grid_.gi_ = gi;
       std::vector<ndt_leaf> buf((size_t)gi.n_leaves);
       const int64_t n = ndt_export_leaves(h_, buf.data(), buf.size());  // ascending index
       grid_.leaves_.reserve(n > 0 ? (size_t)n : 0);
@@ -650,6 +769,7 @@ class SvnNormalDistributionsTransform {
     } else {
       status_ = source.points.empty() ? ndt_set_source(h_, nullptr, 0, 12)
                                       : ndt_set_source(h_, &source.points[0].x, source.points.size(), sizeof(source.points[0]));
+      n_source_ = status_ == NDT_OK ? source.points.size() : 0;
       if (status_ == NDT_OK && svn_.particle_count > 0) {
         std::vector<double> particles(16 * (size_t)svn_.particle_count);
         ndt_svn_sample_particles(prior_pose_colmajor, svn_.particle_count, seed_++, particles.data());
@@ -680,12 +800,45 @@ class SvnNormalDistributionsTransform {
   }
 #endif
 
+  // ---- the reference's public math hook (round 5; ref: extern/svn_ndt/include/svn_ndt.h:186-206, svn_ndt_impl.hpp:518-668) ----
+  // computeParticleDerivatives: NDT score, gradient and (Gauss-Newton, the svn default) Hessian of the source at the pose
+  // p = [x, y, z, roll, pitch, yaw].  The reference takes the ORIGINAL points from its member input_ (set by align) and
+  // the moved ones from `trans_cloud`; here the source is what setInputSource() / the last align() handed over and the
+  // engine moves it itself -- trans_cloud is only checked for its size.  One launch (ndt_eval_derivatives, K = 1).
+  template <class CloudPtr>
+  void setInputSource(const CloudPtr& cloud) {
+    if (!h_) return;
+    status_ = cloud && !cloud->points.empty()
+                  ? ndt_set_source(h_, &cloud->points[0].x, cloud->points.size(), sizeof(cloud->points[0]))
+                  : ndt_set_source(h_, nullptr, 0, 12);
+    n_source_ = status_ == NDT_OK && cloud ? cloud->points.size() : 0;
+  }
+  template <class Vec6, class Mat6, class Cloud>
+  double computeParticleDerivatives(Vec6& score_gradient, Mat6& hessian, const Cloud& trans_cloud, const Vec6& p,
+                                    bool compute_hessian = true) {
+    double pose[6], words[NDT_EVAL_WORDS], score = 0.0, g[6], H[36];
+    for (int i = 0; i < 6; ++i) { pose[i] = p[i]; score_gradient[i] = 0.0; }
+    for (int r = 0; r < 6; ++r)
+      for (int c = 0; c < 6; ++c) hessian(r, c) = 0.0;
+    if (!h_) { status_ = NDT_ERR_NO_DEVICE; return 0.0; }
+    if (trans_cloud.points.size() != n_source_) { status_ = NDT_ERR_INVALID_ARG; return 0.0; }
+    status_ = ndt_eval_derivatives(h_, pose, nullptr, 1, compute_hessian ? 1 : 0, words);
+    if (status_ != NDT_OK) return 0.0;
+    ndt_unpack_eval(words, &score, g, H);
+    for (int i = 0; i < 6; ++i) score_gradient[i] = g[i];
+    if (compute_hessian)
+      for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 6; ++c) hessian(r, c) = H[6 * r + c];
+    return score;
+  }
+
   int lastStatus() const { return status_; }
   std::string lastError() const { return h_ ? ndt_last_error(h_) : "no engine (ndt_create failed: GPU required)"; }
   ndt_handle* handle() { return h_; }
 
  private:
   void push() { if (h_) status_ = ndt_set_params(h_, &prm_); }
+  size_t n_source_ = 0;
   ndt_params prm_{};
   ndt_svn_params svn_{};
   ndt_handle* h_ = nullptr;

@@ -33,12 +33,21 @@ def test_cpp_driver_shaped_calls_through_reference_names():
     _run("test_driver_shape")
 
 
+@pytest.mark.gpu
+def test_cpp_grid_queries_and_svn_math_hook_against_the_oracle():
+    """extern/svn_ndt/include/voxel_grid_covariance.h:194-200,280-381 and svn_ndt.h:186-206 on the adapter, through the
+    compat header names: neighbour sets (DIRECT7 / DIRECT1 / radius) equal the oracle's on 4000 queries, and
+    computeParticleDerivatives equals the oracle's derivatives to 1e-9."""
+    _run("test_grid_queries")
+
+
 def test_cpp_adapter_compiles():
     """All faces of the adapter build with plain g++ against the C-ABI library: the dependency-free
     one, and the Eigen + PCL + GTSAM one (against the API mocks) through include/compat."""
     subprocess.check_call(["make", "-C", CPP, "all"])
     assert os.path.exists(os.path.join(CPP, "test_adapter"))
     assert os.path.exists(os.path.join(CPP, "test_driver_shape"))
+    assert os.path.exists(os.path.join(CPP, "test_grid_queries"))
 
 
 def test_compat_headers_cover_the_references_includes():
