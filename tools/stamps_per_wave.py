@@ -135,3 +135,5 @@ for rep in range(3):
     ms = raw[nb * 9:].reshape(nb, 2).astype(np.int64)
     report("pre-launched evaluation (last of an align), repeat %d, counters %s" % (rep, ndt.prelaunchCounters()), t, hw, trips,
            (ms[:, 1].min(), "the first block saw the pose"))
+    if os.environ.get("NDT_STAMPS_DUMP"):   # raw arrays for offline analysis: [block][wave][stamp], hw ids, per-block {entry, pose seen}
+        np.savez(os.environ["NDT_STAMPS_DUMP"] + "_%d.npz" % rep, t=t, hw=hw, ms=ms, trips=trips, xcc=raw[nb * 8:nb * 9].view(np.uint32).reshape(nb, 2))
