@@ -429,7 +429,7 @@ __device__ __forceinline__ void point_pairs_kd(PairAcc& a, float x, float y, flo
   const int i2 = finite ? (int)(floorf(zt * g.inv_leaf) - (float)g.min_b[2]) : -4;
   // The 27 cells are nine rows of three x-adjacent cells: ONE 12-byte load per row (nine loads in flight instead of
   // 27; round 3).  At the ends of the grid a row starts one or two ints outside it -- the index grid is readable four
-  // ints beyond either end (IndexGrid, ndt_api.hip) and those lanes are masked.  Cell n = (dx+1) + 3 (dy+1) + 9 (dz+1),
+  // ints beyond either end (IndexGrid, ndt_engine.h) and those lanes are masked.  Cell n = (dx+1) + 3 (dy+1) + 9 (dz+1),
   // as before: the listing order, hence the summation order, is unchanged.
   int slot[KD_CELLS];
   {
@@ -1116,7 +1116,7 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
               unsigned int* __restrict__ arrive_ctr, unsigned long long* arrived_host,
               const BuildGeom* __restrict__ geom_dev) {
   // geom_dev != nullptr: the launch was enqueued BEHIND the voxel-grid build that produces its grid, before the host
-  // knew the geometry (ndt_api.hip, evaluate(): the first evaluation of an align that follows a deferred build).  The
+  // knew the geometry (ndt_evaluate.hip, evaluate(): the first evaluation of an align that follows a deferred build).  The
   // build's last block has left the geometry and its verdict in device memory; after a refused build every block leaves
   // at once -- nobody waits for anybody, the host repeats the evaluation the ordinary way.
   GridGeom g = g_arg;

@@ -22,7 +22,7 @@
 
 using ndt::se3::Pose;
 
-// internal entry point of ndt_api.hip (not in the public header): ndt_eval_derivatives with host
+// internal entry point of ndt_evaluate.hip (not in the public header): ndt_eval_derivatives with host
 // work run between the launch and the wait
 extern "C" int ndt_eval_derivatives_overlapped(ndt_handle* h, const double* poses6, const float* transforms, int K,
                                                int compute_hessian, double* out, void (*overlap)(void*), void* ctx);

@@ -37,7 +37,7 @@ def test_production_library_is_not_steered_by_the_environment(pkg):
     out = subprocess.run(["strings", os.path.join(ROOT, "slam-sam_amd", "libndt_hip.so")], capture_output=True, text=True).stdout
     names = sorted({ln for ln in out.splitlines() if re.fullmatch(r"NDT_[A-Z0-9_]+", ln)})
     assert names == ["NDT_COMM_TIMEOUT_S", "NDT_HANDOFF", "NDT_PRELAUNCH", "NDT_UPLOAD_THREADS"], names
-    for src in ("ndt_api.hip", "ndt_derivs.hip", "ndt_target.hip", "ndt_comm.cpp", "ndt_repack_pool.h", "ndt_newton.cpp", "ndt_svn.cpp"):
+    for src in ("ndt_handle.hip", "ndt_handoff.hip", "ndt_evaluate.hip", "ndt_keyframes.hip", "ndt_keepwarm.hip", "ndt_derivs.hip", "ndt_target.hip", "ndt_comm.cpp", "ndt_repack_pool.h", "ndt_newton.cpp", "ndt_svn.cpp"):
         txt = open(os.path.join(ROOT, "slam-sam_amd", "csrc", src)).read()
         for m in re.finditer(r'getenv\("(NDT_[A-Z0-9_]+)"\)', txt):
             assert m.group(1) in names or m.group(1).startswith("NDT_DEBUG_"), (src, m.group(1))
