@@ -693,19 +693,26 @@ def main():
             if os.environ.get("NDT_BENCH_CADENCE", "1") != "1":
                 return None
 
-            def sclk():
-                # the shader clock the driver reports right now (MHz), where the box lets an ordinary user read it
+            def clocks():
+                # the clocks the driver reports right now (MHz: shader, memory, fabric, SoC), where the box lets an ordinary user read them
+                out = {}
                 try:
                     import glob
-                    best = None
-                    for f in glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"):
-                        for ln in open(f).read().splitlines():
-                            if ln.strip().endswith("*"):
-                                mhz = int("".join(ch for ch in ln.split(":")[1] if ch.isdigit()))
-                                best = mhz if best is None else max(best, mhz)
-                    return best
+                    for name in ("sclk", "mclk", "fclk", "socclk"):
+                        best = None
+                        for f in glob.glob("/sys/class/drm/card*/device/pp_dpm_" + name):
+                            for ln in open(f).read().splitlines():
+                                if ln.strip().endswith("*"):
+                                    mhz = int("".join(ch for ch in ln.split(":")[1] if ch.isdigit()))
+                                    best = mhz if best is None else max(best, mhz)
+                        if best is not None:
+                            out[name] = best
                 except Exception:  # noqa: BLE001
-                    return None
+                    pass
+                return out
+
+            def sclk():
+                return clocks().get("sclk")
 
             def one():
                 t0 = time.perf_counter()
@@ -735,12 +742,14 @@ def main():
                 m10s, _ = paced(0.1, 15, spin=True)
                 time.sleep(5.0)
                 c5 = sclk()
+                call = clocks()
                 first = one()
                 return {"ms_step_back_to_back": busy, "ms_step_10hz": m10, "ms_step_20hz": m20, "ms_first_step_after_5s_idle": first,
                         # the same 10 Hz cadence with the calling thread busy-waiting instead of sleeping: what of the
                         # difference to back-to-back is the HOST core waking up, not the device
                         "ms_step_10hz_host_thread_spinning": m10s,
-                        "sclk_mhz_before_a_10hz_step": c10, "sclk_mhz_before_a_20hz_step": c20, "sclk_mhz_after_5s_idle": c5}
+                        "sclk_mhz_before_a_10hz_step": c10, "sclk_mhz_before_a_20hz_step": c20, "sclk_mhz_after_5s_idle": c5,
+                        "clocks_mhz_after_5s_idle": call}
 
             v = block()
             ndt.setKeepWarm(1000)
