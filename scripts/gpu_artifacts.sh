@@ -17,7 +17,7 @@ if has multi; then   # the multi-rank code path on a 1-GPU box: 2 and 4 ranks on
   NDT_BENCH_FORCE_DIST=1 NDT_BENCH_PROBE=0 timeout -k 10 400 python bench.py --gpus 1 --no-cpu-baseline > $OUT/bench_dist1.json 2> $OUT/bench_dist1.err; echo "dist1 rc=$?"
 fi
 if has prof; then    # rocprofv3 kernel stats of the bench command (headline workload only)
-  ( cd /tmp && export TMPDIR=/tmp NDT_BENCH_PROBE=0 NDT_BENCH_HOST_CLOUD=0 NDT_BENCH_CONFIGS=0 NDT_BENCH_PACKED=0
+  ( cd /tmp && export TMPDIR=/tmp NDT_BENCH_PROBE=0 NDT_BENCH_HOST_CLOUD=0 NDT_BENCH_CONFIGS=0 NDT_BENCH_PACKED=0 NDT_BENCH_PROTOCOLS=0 NDT_BENCH_CADENCE=0
     timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $OUT/prof -o r --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/prof.log 2>&1
     cp $(find $OUT/prof -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv; rm -rf $OUT/prof/*/*trace* 2>/dev/null )
 fi

@@ -584,7 +584,16 @@ int ndt_align(ndt_handle* h, const float guess[16], ndt_result* out) {
     if (rc) return rc;
   }
   const double dev_ms0 = h->tm.ms_eval_kernel_total;
-  EvalFn fn = [h](const double* p, const float* T, bool need_h, Eval* e) { return evaluate(h, p, T, need_h, e); };
+  // (the moment the FIRST evaluation of this align is in hand: the stream-placement comparison below times what
+  // comes after it -- the first evaluation carries the wait for a deferred build or hand-off, 0.06-0.12 ms of a 0.5 ms
+  // align, and an align without one would otherwise look 15 % faster than one with: ADVICE r04)
+  bool first_done = false;
+  std::chrono::steady_clock::time_point t_first_done;
+  EvalFn fn = [h, &first_done, &t_first_done](const double* p, const float* T, bool need_h, Eval* e) {
+    const int r = evaluate(h, p, T, need_h, e);
+    if (!first_done) { first_done = true; t_first_done = std::chrono::steady_clock::now(); }
+    return r;
+  };
   const int64_t n_total = h->n_src_global >= 0 ? h->n_src_global : (int64_t)h->n_src;
   h->prelaunch_armed = true;
   const int64_t timeouts0 = h->n_prelaunch_timeouts;
@@ -612,7 +621,9 @@ int ndt_align(ndt_handle* h, const float guess[16], ndt_result* out) {
     const int64_t launched = h->tm.n_eval_launches - launches0;
     if (launched >= 8 && h->n_prelaunch_used - used0 >= launched - 2) {   // a pre-launched align of some length
       const int which = h->streams_this_align ? 0 : 1;
-      const double us = 1e3 * out->ms_total / (double)launched;
+      // per evaluation BEHIND the first one: like with like, whether or not this align had a build to wait for
+      const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_first_done).count() /
+                        (double)(launched - 1);
       // the BEST recent sample of a placement, slowly forgotten (+2 % per align): a host hiccup can only make a
       // sample slower, so it can neither inflate the figure a probe is compared with nor pass for a fast probe
       double& m = h->us_eval_mean[which];
