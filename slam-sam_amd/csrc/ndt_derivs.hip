@@ -125,14 +125,45 @@ struct AngleTables {
 // registers of pair sums fetched up front made a third of the kernel's instantiations spill.
 struct RegSource {
   const PairAcc& a;
-  float x, y, z;
   __device__ __forceinline__ double score() const { return a.score; }
   __device__ __forceinline__ double best() const { return a.best; }
   __device__ __forceinline__ int npairs() const { return a.npairs; }
   __device__ __forceinline__ double w(int k) const { return a.w[k]; }
   __device__ __forceinline__ double S(int k) const { return a.S[k]; }
-  __device__ __forceinline__ void point(float& px, float& py, float& pz) const { px = x; py = y; pz = z; }
 };
+
+// The point-dependent factors of an expansion -- the eight non-trivial entries of A(x) (ref :339-363) and, for the full
+// Hessian, the fifteen second-derivative products (ref :369-394) -- computed from the angle tables, or fetched from LDS
+// where a wave has computed them AHEAD of its pair phase (precompute_geo: the finishing wave that expands last).
+struct TableGeo {
+  const float* T;
+  float x, y, z;
+  __device__ __forceinline__ double A(int k) const { return (double)dot3f(T + 3 * k, x, y, z); }
+  __device__ __forceinline__ double h(int k) const { return (double)dot3f(T + 24 + 3 * k, x, y, z); }
+};
+struct PreGeo {
+  const float* pre;   // [23][64] f32 (the products ARE f32: the expansion widens them): A(0..7), h(0..14), lane-minor
+  int lane;
+  __device__ __forceinline__ double A(int k) const { return (double)pre[k * 64 + lane]; }
+  __device__ __forceinline__ double h(int k) const { return (double)pre[(8 + k) * 64 + lane]; }
+};
+constexpr int PRE_WORDS = 23;
+constexpr int PRE_BYTES = PRE_WORDS * 64 * 4;   // 5 888: fits behind the point in a wave's hand-over region (static_assert below)
+// (word(k): table word k as a wave-uniform value.  Eight products at a time: the wave is in front of its pair phase,
+// with the grid geometry, R|t and every pointer live in scalar registers -- all 69 words at once would spill them)
+template <int MODE, class Word>
+__device__ __forceinline__ void precompute_geo(float* pre, int lane, const Word& word, float x, float y, float z) {
+  if (MODE == 3) return;
+#pragma unroll
+  for (int k0 = 0; k0 < (MODE == 1 ? PRE_WORDS : 8); k0 += 8) {
+#pragma unroll
+    for (int k = k0; k < k0 + 8 && k < (MODE == 1 ? PRE_WORDS : 8); ++k) {
+      const float m[3] = {word(3 * k), word(3 * k + 1), word(3 * k + 2)};
+      pre[k * 64 + lane] = dot3f(m, x, y, z);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
 
 // ACCUM: the words are ADDED to acc (a finishing wave expands several waves' points, see k_derivatives).
 // T: the 69 angle-table words (jang[24] then hang[45]) -- wave-uniform values the finishing waves hold in SCALAR
@@ -141,8 +172,8 @@ struct RegSource {
 // Every product-sum is written as an explicit fma chain and contraction is OFF here: the pre-launched, the ordinary and
 // the batched instantiations must round identically (their results are compared bit for bit), which "the compiler fuses
 // what it likes" does not promise across separately compiled instantiations.
-template <int MODE, bool ACCUM, class Src>
-__device__ __forceinline__ void expand_point(double acc[EV_WORDS], const Src& src, const float* T) {
+template <int MODE, bool ACCUM, class Src, class Geo>
+__device__ __forceinline__ void expand_point(double acc[EV_WORDS], const Src& src, const Geo& geo) {
 #pragma clang fp contract(off)
 #define NDT_PUT(k, v) do { if (ACCUM) acc[(k)] += (v); else acc[(k)] = (v); } while (0)
   // a b (+ acc)            /  a b + c d (+ acc)  /  a b + c d + e f (+ acc)
@@ -174,14 +205,8 @@ __device__ __forceinline__ void expand_point(double acc[EV_WORDS], const Src& sr
   }
 
   // point Jacobian, angular block A (3x3) from the ORIGINAL point (ref :339-363)
-  float x, y, z;
-  src.point(x, y, z);
-  const float* J = T;
-  const double A10 = (double)dot3f(J + 0, x, y, z), A20 = (double)dot3f(J + 3, x, y, z);
-  const double A01 = (double)dot3f(J + 6, x, y, z), A11 = (double)dot3f(J + 9, x, y, z);
-  const double A21 = (double)dot3f(J + 12, x, y, z);
-  const double A02 = (double)dot3f(J + 15, x, y, z), A12 = (double)dot3f(J + 18, x, y, z);
-  const double A22 = (double)dot3f(J + 21, x, y, z);
+  const double A10 = geo.A(0), A20 = geo.A(1), A01 = geo.A(2), A11 = geo.A(3), A21 = geo.A(4), A02 = geo.A(5), A12 = geo.A(6),
+               A22 = geo.A(7);
   {
     const double w0 = src.w(0), w1 = src.w(1), w2 = src.w(2);
     NDT_PUT(EV_G + 0, w0);
@@ -229,14 +254,13 @@ __device__ __forceinline__ void expand_point(double acc[EV_WORDS], const Src& sr
   }
   if (MODE == 1) {
     // + second-derivative term, full Hessian only (ref :369-394 layout of the 15 rows; term 3 of :479-489)
-    const float* h = T + 24;
     const double w0 = src.w(0), w1 = src.w(1), w2 = src.w(2);
-    NDT_A2(EV_H + 15, w1, (double)dot3f(h + 0, x, y, z), w2, (double)dot3f(h + 3, x, y, z));
-    NDT_A2(EV_H + 16, w1, (double)dot3f(h + 6, x, y, z), w2, (double)dot3f(h + 9, x, y, z));
-    NDT_A2(EV_H + 17, w1, (double)dot3f(h + 12, x, y, z), w2, (double)dot3f(h + 15, x, y, z));
-    NDT_A3(EV_H + 18, w0, (double)dot3f(h + 18, x, y, z), w1, (double)dot3f(h + 21, x, y, z), w2, (double)dot3f(h + 24, x, y, z));
-    NDT_A3(EV_H + 19, w0, (double)dot3f(h + 27, x, y, z), w1, (double)dot3f(h + 30, x, y, z), w2, (double)dot3f(h + 33, x, y, z));
-    NDT_A3(EV_H + 20, w0, (double)dot3f(h + 36, x, y, z), w1, (double)dot3f(h + 39, x, y, z), w2, (double)dot3f(h + 42, x, y, z));
+    NDT_A2(EV_H + 15, w1, geo.h(0), w2, geo.h(1));
+    NDT_A2(EV_H + 16, w1, geo.h(2), w2, geo.h(3));
+    NDT_A2(EV_H + 17, w1, geo.h(4), w2, geo.h(5));
+    NDT_A3(EV_H + 18, w0, geo.h(6), w1, geo.h(7), w2, geo.h(8));
+    NDT_A3(EV_H + 19, w0, geo.h(9), w1, geo.h(10), w2, geo.h(11));
+    NDT_A3(EV_H + 20, w0, geo.h(12), w1, geo.h(13), w2, geo.h(14));
   }
 #undef NDT_A3
 #undef NDT_A2
@@ -647,6 +671,7 @@ __device__ __forceinline__ void wave_reduce_scatter32(double* acc, int lane) {
 constexpr int PART_F64 = 11;                                   // score, best, w[3], S[6]
 constexpr int PART_XYZ_BYTES = 64 * 16;
 constexpr int PART_BYTES = PART_XYZ_BYTES + PART_F64 * 64 * 8; // 6656 bytes per wave
+static_assert(PRE_BYTES <= PART_BYTES, "the precomputed factors live in the finishing wave's own region");
 __host__ __device__ constexpr int wave_region_bytes(bool kd) {
   return kd ? (PART_XYZ_BYTES + KD_CELLS * 64 * 4 > PART_BYTES ? PART_XYZ_BYTES + KD_CELLS * 64 * 4 : PART_BYTES) : PART_BYTES;
 }
@@ -690,7 +715,6 @@ struct LdsSource {
   __device__ __forceinline__ int npairs() const { return reinterpret_cast<const int*>(region)[4 * lane + 3]; }
   __device__ __forceinline__ double w(int k) const { return f64(2 + k); }
   __device__ __forceinline__ double S(int k) const { return f64(5 + k); }
-  __device__ __forceinline__ void point(float& px, float& py, float& pz) const { load_point(region, lane, px, py, pz); }
 };
 
 // A wave has published its item (its pair sums, and -- waves 0 and 1 of an ordinary or batched launch -- its share of
@@ -1292,6 +1316,30 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
   NDT_STAMP(1);
   NDT_WSTAMP_DRAINED(1);
   store_point(my_region, lane, x, y, z);
+  // A finishing wave expands its OWN points first, with its SIMD's other waves still in their pair phase or -- the last
+  // wave of the fullest SIMD, which expands nobody else -- at the very end of the block with the SIMD to itself.  The factors of that expansion that depend on the pose and the point only, not on the pairs
+  // (A(x), and the second-derivative products), are computed HERE, while the SIMD waits for the first cell lookups, and
+  // parked in the wave's own region (a finishing wave hands nothing over and needs its point for nothing else, so the
+  // region is free; the 27-cell modes keep their candidate list there and expand from the tables as before).
+  const int nw = (int)(blockDim.x >> 6);
+  constexpr bool PRE = !KD && MODE != 3;
+  const bool finishing = (int)((ec.fin_waves >> (4 * (wave & 3))) & 15u) == wave;   // wave-uniform
+  float* const pre = reinterpret_cast<float*>(my_region);   // (over the point too: it has been read back by then)
+  if (PRE && finishing) {
+    float px, py, pz;
+    load_point(my_region, lane, px, py, pz);   // (as stored: a non-finite point is the origin)
+    if (MBOX) {          // out of LDS, lane k holding words k and 64 + k (as angle_tables_to_sgprs)
+      const float* w = tab.jang;
+      const float wa = w[lane], wb = w[64 + (lane < 5 ? lane : 0)];
+      precompute_geo<MODE>(pre, lane, [&](int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(k < 64 ? wa : wb), k & 63)); },
+                           px, py, pz);
+    } else if (BATCH) {  // out of the pose array
+      const PoseConsts& pg = poses[blockIdx.y];
+      precompute_geo<MODE>(pre, lane, [&](int k) { return pg.jang[k]; }, px, py, pz);   // jang[24] and hang[45] are contiguous
+    } else {             // out of the kernel arguments
+      precompute_geo<MODE>(pre, lane, [&](int k) { return k < 24 ? pose_arg.jang[k < 24 ? k : 0] : pose_arg.hang[k >= 24 ? k - 24 : 0]; }, px, py, pz);
+    }
+  }
   // (the table words were requested before the point: they have arrived with it; a pre-launched kernel has had its
   // tables in LDS since it was released)
   if (!MBOX && threadIdx.x < 69) tab.jang[threadIdx.x] = tab_word;  // runs on into hang[]: the two arrays are contiguous
@@ -1308,9 +1356,8 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
   // (the lane number once more, from the exec mask this time: a value derived from the thread id in front of the pair
   // phase would be kept in a register through it -- or spilled around it, as the multi-grid kernels did)
   const int lane2 = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-  const int nw = (int)(blockDim.x >> 6), nfin = nw < 4 ? nw : 4;
+  const int nfin = nw < 4 ? nw : 4;
   const int simd = wave & 3;                                   // (the SIMD this wave is taken to sit on)
-  const bool finishing = (int)((ec.fin_waves >> (4 * simd)) & 15u) == wave;
   if (!finishing) store_partials<MODE>(my_region, lane2, a);
   publish_item(s_item, item_base, wave, lane2);
   NDT_WSTAMP(3);
@@ -1321,15 +1368,24 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
       ok = wait_item(s_item, item_base, 0) && ok;
       if (nw > 1) ok = wait_item(s_item, item_base, 1) && ok;
     }
-    float T[69];
-    angle_tables_to_sgprs(T, tab, lane2);
-    load_point(my_region, lane2, x, y, z);
-    expand_point<MODE, false>(acc, RegSource{a, x, y, z}, T);   // its own points: the pair sums straight from registers
-    const unsigned int owners = ec.item_owner, fins = ec.fin_waves;
-    for (int it = 0; it < nw; ++it) {                           // the other waves' in a fixed order
-      if ((int)((owners >> (2 * it)) & 3u) != simd || (int)((fins >> (4 * (it & 3))) & 15u) == it) continue;
-      ok = wait_item(s_item, item_base, it) && ok;
-      expand_point<MODE, true>(acc, LdsSource{regions + (size_t)it * wave_region_bytes(KD), lane2}, T);
+    // its own points: the pair sums straight from registers
+    if (PRE) expand_point<MODE, false>(acc, RegSource{a}, PreGeo{pre, lane2});
+    if (!PRE || wave != ec.lone_wave) {   // (lone_wave: the finishing wave that has nobody else's)
+      float T[69];
+      angle_tables_to_sgprs(T, tab, lane2);
+      if (!PRE) {
+        load_point(my_region, lane2, x, y, z);
+        expand_point<MODE, false>(acc, RegSource{a}, TableGeo{T, x, y, z});
+      }
+      const unsigned int owners = ec.item_owner, fins = ec.fin_waves;
+      for (int it = 0; it < nw; ++it) {                           // the other waves' in a fixed order
+        if ((int)((owners >> (2 * it)) & 3u) != simd || (int)((fins >> (4 * (it & 3))) & 15u) == it) continue;
+        ok = wait_item(s_item, item_base, it) && ok;
+        const char* region = regions + (size_t)it * wave_region_bytes(KD);
+        float qx, qy, qz;
+        load_point(region, lane2, qx, qy, qz);
+        expand_point<MODE, true>(acc, LdsSource{region, lane2}, TableGeo{T, qx, qy, qz});
+      }
     }
     if (!ok && lane2 == 0) acc[EV_FAIL] += 1.0;   // (never seen: a sibling wave that did not publish)
   }
@@ -1470,7 +1526,9 @@ static int derivs_dedicated_summer(size_t n_src, int K, int cus) {
 //              load, counted in VALU instructions (pair phase + LDS hand-over, expansion, reduce-scatter).
 // 13 waves: wave 12 expands itself, waves 1 / 2 / 3 take four items each.  Depends on the block shape only: fixed
 // tables, a fixed order of additions.
-void derivs_item_owners(int threads, unsigned int* owners_out, unsigned int* fin_waves_out) {
+//   lone:      a finishing wave that is left with no item but its own (13 waves: wave 12), -1 if there is none: it
+//              does not fetch the angle tables behind its pair phase.
+void derivs_item_owners(int threads, unsigned int* owners_out, unsigned int* fin_waves_out, int* lone_out) {
   const int nw = threads / 64, nfin = nw < 4 ? nw : 4;
   int fin_of_simd[4] = {15, 15, 15, 15}, p[4] = {0, 0, 0, 0}, e[4] = {0, 0, 0, 0}, owner[MAX_WAVES];
   for (int i = 0; i < nw; ++i) { ++p[i % 4]; ++e[i % 4]; owner[i] = i % 4; }
@@ -1495,6 +1553,11 @@ void derivs_item_owners(int threads, unsigned int* owners_out, unsigned int* fin
   for (int q = 0; q < 4; ++q) fb |= (unsigned int)fin_of_simd[q] << (4 * q);
   *owners_out = ob;
   *fin_waves_out = fb;
+  if (lone_out != nullptr) {
+    *lone_out = -1;
+    for (int q = nfin - 1; q >= 0; --q)
+      if (e[q] == 1) *lone_out = fin_of_simd[q];   // (the lowest SIMD if several: the others go through an empty item loop)
+  }
 }
 
 int derivs_grid_blocks(size_t n_src, int K, int cus) { return derivs_point_blocks(n_src, K, cus) + derivs_dedicated_summer(n_src, K, cus); }
@@ -1548,7 +1611,7 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
   // the format (as a run-time flag) cost more than the shorter fetch gave back (KDTREE 21.9 -> 22.5 us, DIRECT26 29.1 -> 29.7)
   if (ec.multigrid || ec.kdtree || ec.direct26) ecl.packed = 0;
   const int nb = ec.multigrid ? 4 : (ec.kdtree ? 2 : (ec.direct26 ? 3 : (ec.direct7 ? (ecl.packed ? 6 : 1) : (ecl.packed ? 5 : 0))));
-  derivs_item_owners(threads, &ecl.item_owner, &ecl.fin_waves);
+  derivs_item_owners(threads, &ecl.item_owner, &ecl.fin_waves, &ecl.lone_wave);
   // one LDS region per wave: the 27-cell modes' candidate list, then the wave's hand-over to the finishing waves
   const size_t dyn_lds = (size_t)(threads / 64) * (size_t)wave_region_bytes(nb >= 2 && nb <= 4);
   // ev_start / ev_stop: events attached to THIS dispatch (hipExtLaunchKernel): they carry the kernel's own begin and

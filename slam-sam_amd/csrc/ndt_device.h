@@ -133,6 +133,7 @@ struct EvalConsts {
                    // may not be resident): the re-evaluation after a lost row
   unsigned int item_owner;  // k_derivatives: 2 bits per wave of a block -- the SIMD whose finishing wave expands that wave's points
   unsigned long long item_salt;  // ... per-process random bits in the tags the waves of a block publish their items under (process_item_salt())
+  int lone_wave;            // ... a finishing wave that expands nobody but itself (-1: none)
   unsigned int fin_waves;   // ... 4 bits per SIMD: its finishing wave (derivs_item_owners(), ndt_derivs.hip; per launch, from the block shape)
   int mute_row;    // test seam (libndt_hip_seams.so only): row + 1 of the block that withholds its partial row; 0 = none
 };

@@ -131,7 +131,7 @@ int derivs_block_threads(size_t n_src, int K, int cus);
 size_t derivs_partials_words(size_t n_src, int K, int cus);  // doubles needed in d_partials
 int derivs_counters_per_pose();
 // which finishing wave expands which wave's points: 2 bits per wave (owning SIMD), 4 bits per SIMD (its finishing wave)
-void derivs_item_owners(int threads, unsigned int* owners_out, unsigned int* fin_waves_out);
+void derivs_item_owners(int threads, unsigned int* owners_out, unsigned int* fin_waves_out, int* lone_out = nullptr);
 int derivs_read_wave_stamps(unsigned long long* out, int nblocks);  // diagnostic builds only: per-wave stamps, see ndt_derivs.hip
 int derivs_read_stamps(unsigned long long* out, int nblocks);  // diagnostic builds (-DNDT_STAMPS) only                     // ticket words per pose in d_counters
 // d_partials: derivs_partials_words() doubles, ZEROED when allocated (rows of tagged slots);
