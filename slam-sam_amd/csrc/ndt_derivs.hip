@@ -148,7 +148,7 @@ struct PreGeo {
   __device__ __forceinline__ double h(int k) const { return (double)pre[(8 + k) * 64 + lane]; }
 };
 constexpr int PRE_WORDS = 23;
-constexpr int PRE_BYTES = PRE_WORDS * 64 * 4;   // 5 888: fits behind the point in a wave's hand-over region (static_assert below)
+constexpr int PRE_BYTES = PRE_WORDS * 64 * 4;   // 5 888: fits in a wave's hand-over region (static_assert below)
 // (word(k): table word k as a wave-uniform value.  Eight products at a time: the wave is in front of its pair phase,
 // with the grid geometry, R|t and every pointer live in scalar registers -- all 69 words at once would spill them)
 template <int MODE, class Word>
@@ -305,11 +305,13 @@ __device__ __forceinline__ VoxelRecord fetch_record(const VoxelRecord* __restric
 // D7: DIRECT7 (centre + 6 face neighbours); otherwise DIRECT1 (the point's own voxel only).
 // PACKED: the record table is PackedRecord[] (compile time here: as a run-time choice the seven pipelined fetches
 // of DIRECT7 merged both formats' registers and spilled 48-140 bytes per lane)
-template <int MODE, bool D7, bool PACKED>
+// mid(): called once the cell lookups are on their way -- work that does not depend on them (precompute_geo) runs in
+// their shadow.  Every lane takes part: one without a point (active = false) has no neighbours.
+template <int MODE, bool D7, bool PACKED, class Mid>
 __device__ __forceinline__ void point_pairs(PairAcc& a, float x, float y, float z, const GridGeom& g,
                                             const int* __restrict__ cell2leaf,
                                             const VoxelRecord* __restrict__ rec, const RigidRT& P,
-                                            const EvalConsts& ec) {
+                                            const EvalConsts& ec, bool active, const Mid& mid) {
   a.w[0] = a.w[1] = a.w[2] = 0.0;
 #pragma unroll
   for (int k = 0; k < 6; ++k) a.S[k] = 0.0;
@@ -318,7 +320,7 @@ __device__ __forceinline__ void point_pairs(PairAcc& a, float x, float y, float 
   float xt = P.R[0] * x + (P.R[1] * y + (P.R[2] * z + P.t[0]));
   float yt = P.R[3] * x + (P.R[4] * y + (P.R[5] * z + P.t[1]));
   float zt = P.R[6] * x + (P.R[7] * y + (P.R[8] * z + P.t[2]));
-  const bool finite = isfinite(xt) && isfinite(yt) && isfinite(zt);  // ref :573: such points are skipped
+  const bool finite = active && isfinite(xt) && isfinite(yt) && isfinite(zt);  // ref :573: such points are skipped
   if (!finite) { xt = 0.0f; yt = 0.0f; zt = 0.0f; }  // keeps NaN / Inf out of the (masked) pair arithmetic
 
   // ref: voxel_grid_covariance_impl.hpp:560-600 -- neighbours are found by offsetting the
@@ -361,6 +363,9 @@ __device__ __forceinline__ void point_pairs(PairAcc& a, float x, float y, float 
   }
   if (!D7) {  // DIRECT1 (ref: getNeighborhoodAtPoint1, voxel_grid_covariance_impl.hpp:604-615)
     const int slot0 = (finite && cell[0] >= 0) ? cell2leaf[cell[0]] : -1;
+    __builtin_amdgcn_sched_barrier(0);
+    mid();
+    __builtin_amdgcn_sched_barrier(0);
     const VoxelRecord r0 = fetch_record(rec, slot0 >= 0 ? slot0 : 0, PACKED);
     pair_update<MODE>(a, r0, xt, yt, zt, ec, slot0 >= 0);
     return;
@@ -368,6 +373,9 @@ __device__ __forceinline__ void point_pairs(PairAcc& a, float x, float y, float 
   int slot[7];
 #pragma unroll
   for (int k = 0; k < 7; ++k) slot[k] = (finite && cell[k] >= 0) ? cell2leaf[cell[k]] : -1;
+  __builtin_amdgcn_sched_barrier(0);
+  mid();
+  __builtin_amdgcn_sched_barrier(0);
   // Fully predicated: an absent neighbour reads record 0 (a wave-wide broadcast) and is
   // masked out, so the unrolled pairs carry no exec-mask splits and no accumulator merges.
   // Records are fetched in two batches (4 + 3) so a point pays two L2 round trips for its
@@ -676,6 +684,9 @@ __host__ __device__ constexpr int wave_region_bytes(bool kd) {
   return kd ? (PART_XYZ_BYTES + KD_CELLS * 64 * 4 > PART_BYTES ? PART_XYZ_BYTES + KD_CELLS * 64 * 4 : PART_BYTES) : PART_BYTES;
 }
 
+__device__ __forceinline__ double* region_part(char* region) { return reinterpret_cast<double*>(region + PART_XYZ_BYTES); }
+__device__ __forceinline__ int* region_npairs(char* region, int lane) { return reinterpret_cast<int*>(region) + 4 * lane + 3; }
+
 // before the pair phase: the point as the expansion wants it -- a non-finite one (it never has neighbours, ref :573, so
 // w = S = 0) as the origin, so that it expands to exact zeros
 __device__ __forceinline__ void store_point(char* region, int lane, float x, float y, float z) {
@@ -688,8 +699,7 @@ __device__ __forceinline__ void load_point(const char* region, int lane, float& 
 }
 
 template <int MODE>
-__device__ __forceinline__ void store_partials(char* region, int lane, const PairAcc& a) {
-  double* d = reinterpret_cast<double*>(region + PART_XYZ_BYTES);
+__device__ __forceinline__ void store_partials(double* d /* the region's f64 words */, int* np /* this lane's pair count */, int lane, const PairAcc& a) {
   d[0 * 64 + lane] = a.score;
   d[1 * 64 + lane] = a.best;
   if (MODE != 3) {
@@ -700,19 +710,18 @@ __device__ __forceinline__ void store_partials(char* region, int lane, const Pai
 #pragma unroll
     for (int k = 0; k < 6; ++k) d[(5 + k) * 64 + lane] = a.S[k];
   }
-  reinterpret_cast<int*>(region)[4 * lane + 3] = a.npairs;
+  *np = a.npairs;
 }
 
 // (see RegSource)
 struct LdsSource {
-  const char* region;
+  const double* part;   // the region's f64 words
+  const int* np;        // this lane's pair count
   int lane;
-  __device__ __forceinline__ double f64(int k) const {
-    return reinterpret_cast<const double*>(region + PART_XYZ_BYTES)[k * 64 + lane];
-  }
+  __device__ __forceinline__ double f64(int k) const { return part[k * 64 + lane]; }
   __device__ __forceinline__ double score() const { return f64(0); }
   __device__ __forceinline__ double best() const { return f64(1); }
-  __device__ __forceinline__ int npairs() const { return reinterpret_cast<const int*>(region)[4 * lane + 3]; }
+  __device__ __forceinline__ int npairs() const { return *np; }
   __device__ __forceinline__ double w(int k) const { return f64(2 + k); }
   __device__ __forceinline__ double S(int k) const { return f64(5 + k); }
 };
@@ -804,7 +813,6 @@ constexpr int NGROUPS = 32;          // second-level fan-in (only for grids abov
 // (rows one block adds directly: ndt_tuning::deriv_single_level_max, default 2048)
 constexpr int COUNTERS_PER_POSE = 1 + NGROUPS;
 constexpr int MAX_WAVES = MAX_BLOCK / 64;
-constexpr int MAX_COLS = MAX_BLOCK / 32;  // row-parallel lanes of the final sum
 
 // Cross-block hand-off without fences and without waiting for a store to be acknowledged
 // (cdna_hip_programming.md Guideline 16, "every store sc1 ... every load sc1" form, taken one
@@ -993,7 +1001,12 @@ __device__ __forceinline__ void sum_rows(__amdgpu_buffer_rsrc_t rows, unsigned i
 // kernel, no float atomics, and the summation tree does not depend on arrival order:
 // results are bit-reproducible.  host_slots != nullptr: the evaluation is written as 32 tagged
 // slots into pinned host memory for the host to poll; otherwise 32 plain doubles go to `out`.
-__device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], int fin /* >= 0: this wave is the finishing wave of SIMD `fin` and acc holds its sums */,
+// (the finishing wave of SIMD `fin`: its 64 lanes' sums of the 32 words, into lds_w[fin])
+__device__ __forceinline__ void finish_wave_sums(double acc[EV_WORDS], int fin, int lane, double (*lds_w)[EV_WORDS]) {
+  wave_reduce_scatter32(acc, lane);
+  if ((lane & 1) == 0) lds_w[fin][lane >> 1] = acc[0];
+}
+__device__ __forceinline__ void block_reduce_finish(double (*lds_w)[EV_WORDS] /* the finishing waves' sums (finish_wave_sums) */,
                                                     int nfin, double* __restrict__ rows,
                                                     double* __restrict__ group_rows,
                                                     unsigned int* __restrict__ counters,
@@ -1003,16 +1016,12 @@ __device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], int fi
                                                     const XchgInfo* __restrict__ xi, unsigned long long xround,
                                                     int my_row /* this block's row */, int nb /* rows = computing blocks */,
                                                     bool dedicated /* a block without points adds the rows */, int mute_row = 0) {
-  __shared__ double lds_w[4][EV_WORDS];
-  __shared__ double lds_c[MAX_COLS][EV_WORDS];
+  // (the summing stage's scratch lies over the waves' regions: every wave is past the barrier below by then)
+  extern __shared__ int lds_dyn[];
+  double (*lds_c)[EV_WORDS] = reinterpret_cast<double (*)[EV_WORDS]>(lds_dyn);
   __shared__ int s_last;
   __shared__ int s_fail;
-  const int lane = threadIdx.x & 63;
   if (threadIdx.x == 0) s_fail = 0;
-  if (fin >= 0) {   // wave-uniform
-    wave_reduce_scatter32(acc, lane);
-    if ((lane & 1) == 0) lds_w[fin][lane >> 1] = acc[0];
-  }
   NDT_WSTAMP(5);
   __syncthreads();
   NDT_WSTAMP(6);
@@ -1078,7 +1087,8 @@ __device__ __forceinline__ void block_reduce_finish(double acc[EV_WORDS], int fi
 __device__ __forceinline__ void summer_finish(double* __restrict__ rows, double* __restrict__ out,
                                               unsigned long long* host_slots, unsigned long long seq, int nrows,
                                               const XchgInfo* __restrict__ xi, unsigned long long xround) {
-  __shared__ double lds_c[MAX_COLS][EV_WORDS];
+  extern __shared__ int lds_dyn[];   // (the summing block has no regions)
+  double (*lds_c)[EV_WORDS] = reinterpret_cast<double (*)[EV_WORDS]>(lds_dyn);
   __shared__ int s_fail;
   if (threadIdx.x == 0) s_fail = 0;
   __syncthreads();
@@ -1312,22 +1322,30 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
   const int lane = (int)(threadIdx.x & 63u), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   char* const regions = reinterpret_cast<char*>(lds_dyn);
   if (!(MBOX && ec.mbox_preload) && i < n) { x = sx[i]; y = sy[i]; z = sz[i]; }
-  char* const my_region = regions + (size_t)wave * wave_region_bytes(KD);
-  NDT_STAMP(1);
-  NDT_WSTAMP_DRAINED(1);
-  store_point(my_region, lane, x, y, z);
   // A finishing wave expands its OWN points first, with its SIMD's other waves still in their pair phase or -- the last
-  // wave of the fullest SIMD, which expands nobody else -- at the very end of the block with the SIMD to itself.  The factors of that expansion that depend on the pose and the point only, not on the pairs
-  // (A(x), and the second-derivative products), are computed HERE, while the SIMD waits for the first cell lookups, and
-  // parked in the wave's own region (a finishing wave hands nothing over and needs its point for nothing else, so the
-  // region is free; the 27-cell modes keep their candidate list there and expand from the tables as before).
+  // wave of the fullest SIMD, which expands nobody else -- at the very end of the block with the SIMD to itself.  The
+  // factors of an expansion that depend on the pose and the point only, not on the pairs (A(x), and the
+  // second-derivative products), are computed HERE, while the SIMD waits for the first cell lookups, and parked in the
+  // wave's own region (a finishing wave hands nothing over and needs its point for nothing else; the 27-cell modes
+  // keep their candidate list there and expand from the tables as before).
+  // (EVERY wave doing so for whoever expands its points -- the finishing waves then need neither tables nor points --
+  // was measured too, with regions of 11.5 KB: 0.6 % slower, profiles/r05_pre_all_ab.txt.  The stretch in which the
+  // SIMDs "wait" is not idle enough to take 92 more instructions per wave for nothing.)
   const int nw = (int)(blockDim.x >> 6);
   constexpr bool PRE = !KD && MODE != 3;
   const bool finishing = (int)((ec.fin_waves >> (4 * (wave & 3))) & 15u) == wave;   // wave-uniform
-  float* const pre = reinterpret_cast<float*>(my_region);   // (over the point too: it has been read back by then)
-  if (PRE && finishing) {
-    float px, py, pz;
-    load_point(my_region, lane, px, py, pz);   // (as stored: a non-finite point is the origin)
+  constexpr int region_bytes = wave_region_bytes(KD);
+  char* const my_region = regions + wave * region_bytes;
+  NDT_STAMP(1);
+  NDT_WSTAMP_DRAINED(1);
+  float* const pre = reinterpret_cast<float*>(my_region);
+  const bool precomputes = PRE && finishing;   // wave-uniform
+  if (!precomputes) store_point(my_region, lane, x, y, z);
+  auto precompute = [&]() {   // (in the shadow of the cell lookups: point_pairs)
+    if (!precomputes) return;
+    // (a non-finite point -- it never has neighbours, ref :573, so w = S = 0 -- as the origin: it expands to exact zeros)
+    const bool pfin = isfinite(x) && isfinite(y) && isfinite(z);
+    const float px = pfin ? x : 0.0f, py = pfin ? y : 0.0f, pz = pfin ? z : 0.0f;
     if (MBOX) {          // out of LDS, lane k holding words k and 64 + k (as angle_tables_to_sgprs)
       const float* w = tab.jang;
       const float wa = w[lane], wb = w[64 + (lane < 5 ? lane : 0)];
@@ -1339,7 +1357,7 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
     } else {             // out of the kernel arguments
       precompute_geo<MODE>(pre, lane, [&](int k) { return k < 24 ? pose_arg.jang[k < 24 ? k : 0] : pose_arg.hang[k >= 24 ? k - 24 : 0]; }, px, py, pz);
     }
-  }
+  };
   // (the table words were requested before the point: they have arrived with it; a pre-launched kernel has had its
   // tables in LDS since it was released)
   if (!MBOX && threadIdx.x < 69) tab.jang[threadIdx.x] = tab_word;  // runs on into hang[]: the two arrays are contiguous
@@ -1347,8 +1365,8 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
     // every lane takes part (wave-wide trip count): lanes beyond n run with nothing to add
     point_pairs_kd<MODE, NB == 2 || NB == 4, NB == 4>(a, x, y, z, g, cell2leaf, rec, cent, rt, ec,
                                                       reinterpret_cast<int*>(my_region + PART_XYZ_BYTES), i < n);
-  } else if (i < n) {
-    point_pairs<MODE, NB == 1 || NB == 6, NB >= 5>(a, x, y, z, g, cell2leaf, rec, rt, ec);
+  } else {
+    point_pairs<MODE, NB == 1 || NB == 6, NB >= 5>(a, x, y, z, g, cell2leaf, rec, rt, ec, i < n, precompute);
   }
   NDT_STAMP(2);
   NDT_WSTAMP(2);
@@ -1358,11 +1376,12 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
   const int lane2 = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   const int nfin = nw < 4 ? nw : 4;
   const int simd = wave & 3;                                   // (the SIMD this wave is taken to sit on)
-  if (!finishing) store_partials<MODE>(my_region, lane2, a);
+  if (!finishing) store_partials<MODE>(region_part(my_region), region_npairs(my_region, lane2), lane2, a);
   publish_item(s_item, item_base, wave, lane2);
   NDT_WSTAMP(3);
-  double acc[EV_WORDS];
+  __shared__ double lds_w[4][EV_WORDS];
   if (finishing) {   // wave-uniform
+    double acc[EV_WORDS];
     bool ok = true;
     if (!MBOX) {    // the angle tables are in LDS once waves 0 and 1 have published
       ok = wait_item(s_item, item_base, 0) && ok;
@@ -1370,6 +1389,7 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
     }
     // its own points: the pair sums straight from registers
     if (PRE) expand_point<MODE, false>(acc, RegSource{a}, PreGeo{pre, lane2});
+    const unsigned int owners = ec.item_owner, fins = ec.fin_waves;
     if (!PRE || wave != ec.lone_wave) {   // (lone_wave: the finishing wave that has nobody else's)
       float T[69];
       angle_tables_to_sgprs(T, tab, lane2);
@@ -1377,22 +1397,25 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
         load_point(my_region, lane2, x, y, z);
         expand_point<MODE, false>(acc, RegSource{a}, TableGeo{T, x, y, z});
       }
-      const unsigned int owners = ec.item_owner, fins = ec.fin_waves;
       for (int it = 0; it < nw; ++it) {                           // the other waves' in a fixed order
         if ((int)((owners >> (2 * it)) & 3u) != simd || (int)((fins >> (4 * (it & 3))) & 15u) == it) continue;
         ok = wait_item(s_item, item_base, it) && ok;
-        const char* region = regions + (size_t)it * wave_region_bytes(KD);
+        char* region = regions + it * region_bytes;
         float qx, qy, qz;
         load_point(region, lane2, qx, qy, qz);
-        expand_point<MODE, true>(acc, LdsSource{region, lane2}, TableGeo{T, qx, qy, qz});
+        expand_point<MODE, true>(acc, LdsSource{region_part(region), region_npairs(region, lane2), lane2}, TableGeo{T, qx, qy, qz});
       }
     }
     if (!ok && lane2 == 0) acc[EV_FAIL] += 1.0;   // (never seen: a sibling wave that did not publish)
+    NDT_WSTAMP(4);
+    finish_wave_sums(acc, simd, lane2, lds_w);
   }
   NDT_STAMP(3);
-  NDT_WSTAMP(4);
+#ifdef NDT_STAMPS
+  if (!finishing) NDT_WSTAMP(4);
+#endif
   double* base = partials + (size_t)blockIdx.y * (gridDim.x + NGROUPS) * ROW_WORDS;
-  block_reduce_finish(acc, finishing ? simd : -1, nfin, base + (size_t)NGROUPS * ROW_WORDS, base, counters + blockIdx.y * COUNTERS_PER_POSE,
+  block_reduce_finish(lds_w, nfin, base + (size_t)NGROUPS * ROW_WORDS, base, counters + blockIdx.y * COUNTERS_PER_POSE,
                       out + (size_t)blockIdx.y * EV_WORDS,
                       flag ? flag + (size_t)blockIdx.y * ROW_WORDS : nullptr,  // pose y's 32 host slots
                       seq, ec.single_level_max,
@@ -1613,7 +1636,8 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
   const int nb = ec.multigrid ? 4 : (ec.kdtree ? 2 : (ec.direct26 ? 3 : (ec.direct7 ? (ecl.packed ? 6 : 1) : (ecl.packed ? 5 : 0))));
   derivs_item_owners(threads, &ecl.item_owner, &ecl.fin_waves, &ecl.lone_wave);
   // one LDS region per wave: the 27-cell modes' candidate list, then the wave's hand-over to the finishing waves
-  const size_t dyn_lds = (size_t)(threads / 64) * (size_t)wave_region_bytes(nb >= 2 && nb <= 4);
+  // (the summing stage's 4 KB of scratch lie over them)
+  const size_t dyn_lds = std::max<size_t>((size_t)(threads / 64) * (size_t)wave_region_bytes(nb >= 2 && nb <= 4), (size_t)MAX_WAVES * EV_WORDS * sizeof(double));
   // ev_start / ev_stop: events attached to THIS dispatch (hipExtLaunchKernel): they carry the kernel's own begin and
   // end timestamps, what rocprofv3 reports -- events recorded around the launch include ~2.4 us of dispatch
 #define NDT_LAUNCH2(B, M, NBH, MB, GY, FLAG, SEQ)                                                            \
