@@ -401,6 +401,13 @@ int ndt_eval_derivatives(ndt_handle* h, const double* poses6, const float* trans
                          int K, int compute_hessian, double* out);
 /* unpack one evaluation into score, g[6], H[36] (row-major) */
 void ndt_unpack_eval(const double* eval_words, double* score, double* g6, double* H36);
+/* The two pose-only ingredients of an evaluation as the engine computes them on the host, no handle and no device
+ * needed (round 5; the C++ adapter builds the reference's public per-pair math hooks on them):
+ * - the angular tables of computeAngleDerivatives for pose [x, y, z, roll, pitch, yaw] (ref: svn_ndt_impl.hpp:254-331):
+ *   j_ang as 8 rows x 3 floats, h_ang as 15 rows x 3 floats -- the words every k_derivatives launch receives;
+ * - the Gaussian constants d1, d2 of updateNdtConstants (ref: svn_ndt_impl.hpp:90-130). */
+int ndt_angle_tables(const double pose6[6], float j_ang[24], float h_ang[45]);
+int ndt_gauss_constants(double resolution, double outlier_ratio, double* d1, double* d2);
 
 /* Scoring-only evaluation (pclomp's calculateTransformationProbability /
  * calculateNearestVoxelTransformationLikelihood [RECALLED]; the reference names them only through

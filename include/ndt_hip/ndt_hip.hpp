@@ -717,6 +717,7 @@ class SvnNormalDistributionsTransform {
     prm_.add_ridge = 1;                            // svn_ndt_impl.hpp:650-653
     status_ = ndt_create(&prm_, &h_);
     ndt_svn_default_params(&svn_);
+    updateNdtConstants();
   }
   ~SvnNormalDistributionsTransform() { ndt_destroy(h_); }
   SvnNormalDistributionsTransform(const SvnNormalDistributionsTransform&) = delete;
@@ -832,12 +833,121 @@ class SvnNormalDistributionsTransform {
     return score;
   }
 
+  // ---- the reference's other public math hooks (ref: svn_ndt.h:208-276, svn_ndt_impl.hpp:214-500) ----
+  // One point, one point-voxel pair, one pair of particles at a time, on the HOST, in the reference's own precision
+  // (f32 products, f64 accumulation): the reference opens them to its tests, and so does the adapter -- the engine's
+  // evaluation (k_derivatives; computeParticleDerivatives above) does not go through them.  The angle tables and the
+  // Gaussian constants are the engine's (ndt_angle_tables, ndt_gauss_constants: what every launch receives), so a sum
+  // of updateDerivatives over a cloud's pairs checks the kernel against the reference-shaped arithmetic
+  // (tests/cpp/test_grid_queries.cpp).  Matrix arguments: anything with (row, col); vectors: anything with [i].
+  void updateNdtConstants() { ndt_gauss_constants((double)prm_.resolution, prm_.outlier_ratio, &gauss_d1_, &gauss_d2_); }
+  double gaussD1() const { return gauss_d1_; }
+  double gaussD2() const { return gauss_d2_; }
+  template <class Vec6>
+  void computeAngleDerivatives(const Vec6& p, bool compute_hessian = true) {
+    double pose[6];
+    for (int i = 0; i < 6; ++i) pose[i] = p[i];
+    ndt_angle_tables(pose, j_ang_, h_ang_);
+    if (!compute_hessian) std::fill(h_ang_, h_ang_ + 45, 0.0f);
+  }
+  // Fills the ANGULAR entries of the 4 x 6 point Jacobian (the caller has set the translation block to identity, as in
+  // the reference) and the 24 x 6 stack of second derivatives: block i (rows 4 i .. 4 i + 3), column j = d2 x' / dp_i dp_j.
+  template <class Vec3, class PointGradient, class PointHessian>
+  void computePointDerivatives(const Vec3& x, PointGradient& point_gradient, PointHessian& point_hessian, bool compute_hessian = true) const {
+    const float xf[3] = {(float)x[0], (float)x[1], (float)x[2]};
+    auto along = [&](const float* row) { return row[0] * xf[0] + row[1] * xf[1] + row[2] * xf[2]; };
+    static const int where_j[8][2] = {{1, 3}, {2, 3}, {0, 4}, {1, 4}, {2, 4}, {0, 5}, {1, 5}, {2, 5}};   // (component, parameter)
+    for (int k = 0; k < 8; ++k) point_gradient(where_j[k][0], where_j[k][1]) = along(j_ang_ + 3 * k);
+    if (!compute_hessian) return;
+    for (int r = 0; r < 24; ++r)
+      for (int c = 0; c < 6; ++c) point_hessian(r, c) = 0.0f;
+    // (parameter i, parameter j >= i, component): the table's rows in order; the roll-roll block has no x component
+    static const int where_h[15][3] = {{3, 3, 1}, {3, 3, 2}, {3, 4, 1}, {3, 4, 2}, {3, 5, 1}, {3, 5, 2}, {4, 4, 0}, {4, 4, 1},
+                                       {4, 4, 2}, {4, 5, 0}, {4, 5, 1}, {4, 5, 2}, {5, 5, 0}, {5, 5, 1}, {5, 5, 2}};
+    for (int k = 0; k < 15; ++k) {
+      const int i = where_h[k][0], j = where_h[k][1], comp = where_h[k][2];
+      const float v = along(h_ang_ + 3 * k);
+      point_hessian(4 * i + comp, j) = v;
+      if (i != j) point_hessian(4 * j + comp, i) = v;
+    }
+  }
+  // One point-voxel pair: adds its share to score_gradient / hessian and returns its score (Magnusson eq. 6.9, 6.12, 6.13).
+  template <class Vec6, class Mat6, class PointGradient, class PointHessian, class Vec3, class Mat3>
+  double updateDerivatives(Vec6& score_gradient, Mat6& hessian, const PointGradient& point_gradient4, const PointHessian& point_hessian,
+                           const Vec3& x_trans, const Mat3& c_inv, bool compute_hessian = true, bool use_gauss_newton_hessian = true) const {
+    const double d[3] = {x_trans[0], x_trans[1], x_trans[2]};
+    double cd[3];
+    for (int r = 0; r < 3; ++r) cd[r] = c_inv(r, 0) * d[0] + c_inv(r, 1) * d[1] + c_inv(r, 2) * d[2];
+    double q = d[0] * cd[0] + d[1] * cd[1] + d[2] * cd[2];
+    if (!std::isfinite(q) || q < -1e-9) return 0.0;
+    if (q < 0.0) q = 0.0;
+    const double arg = gauss_d2_ * q * 0.5;
+    if (arg > 50.0) return 0.0;
+    const double e = std::exp(-arg), score_inc = -gauss_d1_ * e, factor = gauss_d1_ * gauss_d2_ * e;
+    if (!std::isfinite(factor) || std::fabs(factor) < 1e-15) return score_inc;
+    const float df[3] = {(float)d[0], (float)d[1], (float)d[2]};
+    float cj[3][6], row[6];   // C^-1 J (f32), (x - mu)^T C^-1 J
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 6; ++c)
+        cj[r][c] = (float)c_inv(r, 0) * point_gradient4(0, c) + (float)c_inv(r, 1) * point_gradient4(1, c) + (float)c_inv(r, 2) * point_gradient4(2, c);
+    bool fin = true;
+    for (int c = 0; c < 6; ++c) {
+      row[c] = df[0] * cj[0][c] + df[1] * cj[1][c] + df[2] * cj[2][c];
+      fin = fin && std::isfinite(factor * (double)row[c]);
+    }
+    if (fin)
+      for (int c = 0; c < 6; ++c) score_gradient[c] += factor * (double)row[c];
+    if (!compute_hessian) return score_inc;
+    double add[6][6];
+    float dc[3];   // (x - mu)^T C^-1 (f32)
+    for (int c = 0; c < 3; ++c) dc[c] = df[0] * (float)c_inv(0, c) + df[1] * (float)c_inv(1, c) + df[2] * (float)c_inv(2, c);
+    fin = true;
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 6; ++j) {
+        const float jcj = point_gradient4(0, i) * cj[0][j] + point_gradient4(1, i) * cj[1][j] + point_gradient4(2, i) * cj[2][j];
+        double t = (double)jcj;
+        if (!use_gauss_newton_hessian) {
+          const int a = i < j ? i : j, b = i < j ? j : i;   // (the stack is filled for both orders; the reference reads the upper one)
+          const float third = dc[0] * point_hessian(4 * a + 0, b) + dc[1] * point_hessian(4 * a + 1, b) + dc[2] * point_hessian(4 * a + 2, b);
+          t += -gauss_d2_ * ((double)row[i] * (double)row[j]) + (double)third;
+        }
+        add[i][j] = t * factor;
+        fin = fin && std::isfinite(add[i][j]);
+      }
+    if (fin)
+      for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) hessian(i, j) += add[i][j];
+    return score_inc;
+  }
+  // k(l, k) = exp(-|Log(l^-1 k)|^2 / h) and its gradient with respect to l in l's tangent space; Pose3: gtsam's surface
+  // (between, Logmap, equals).  h: setKernelBandwidth.
+  template <class Pose3>
+  double rbf_kernel(const Pose3& pose_l, const Pose3& pose_k) const {
+    if (svn_.kernel_bandwidth <= 1e-12) return pose_l.equals(pose_k, 1e-9) ? 1.0 : 0.0;
+    const auto xi = Pose3::Logmap(pose_l.between(pose_k));
+    double sq = 0.0;
+    for (int i = 0; i < 6; ++i) sq += xi[i] * xi[i];
+    return std::exp(-sq / svn_.kernel_bandwidth);
+  }
+  template <class Pose3>
+  auto rbf_kernel_gradient(const Pose3& pose_l, const Pose3& pose_k) const -> decltype(Pose3::Logmap(pose_l.between(pose_k))) {
+    auto xi = Pose3::Logmap(pose_l.between(pose_k));
+    if (svn_.kernel_bandwidth <= 1e-12) { for (int i = 0; i < 6; ++i) xi[i] = 0.0; return xi; }
+    double sq = 0.0;
+    for (int i = 0; i < 6; ++i) sq += xi[i] * xi[i];
+    const double s = std::exp(-sq / svn_.kernel_bandwidth) * (-2.0 / svn_.kernel_bandwidth);
+    for (int i = 0; i < 6; ++i) xi[i] *= s;
+    return xi;
+  }
+
   int lastStatus() const { return status_; }
   std::string lastError() const { return h_ ? ndt_last_error(h_) : "no engine (ndt_create failed: GPU required)"; }
   ndt_handle* handle() { return h_; }
 
  private:
-  void push() { if (h_) status_ = ndt_set_params(h_, &prm_); }
+  void push() { if (h_) status_ = ndt_set_params(h_, &prm_); updateNdtConstants(); }
+  double gauss_d1_ = 0.0, gauss_d2_ = 0.0;
+  float j_ang_[24] = {}, h_ang_[45] = {};
   size_t n_source_ = 0;
   ndt_params prm_{};
   ndt_svn_params svn_{};

@@ -839,6 +839,18 @@ void ndt_unpack_eval(const double* w, double* score, double* g6, double* H36) {
   if (H36) std::memcpy(H36, e.H, sizeof(e.H));
 }
 
+int ndt_angle_tables(const double pose6[6], float j_ang[24], float h_ang[45]) {
+  if (!pose6 || !j_ang || !h_ang) return NDT_ERR_INVALID_ARG;
+  angle_tables(pose6, j_ang, h_ang);
+  return NDT_OK;
+}
+
+int ndt_gauss_constants(double resolution, double outlier_ratio, double* d1, double* d2) {
+  if (!d1 || !d2 || !(resolution > 0.0)) return NDT_ERR_INVALID_ARG;
+  gauss_constants(resolution, outlier_ratio, d1, d2);
+  return NDT_OK;
+}
+
 int ndt_transform_source(ndt_handle* h, const float T[16], float* out_xyz, size_t cap_points) {
   if (!h || !T || !out_xyz) return NDT_ERR_INVALID_ARG;
   int rc = bind_device(h);

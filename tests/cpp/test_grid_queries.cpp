@@ -2,7 +2,8 @@
 // names (include/compat), against the CPU oracle (test infrastructure): neighbour sets of getNeighborhoodAtPoint7 / 1 and
 // radiusSearch, getLeaf(point), getCentroids, nearestKSearch, getCovEigValueInflationRatio
 // (ref: extern/svn_ndt/include/voxel_grid_covariance.h:194-200,280-381) and computeParticleDerivatives
-// (ref: extern/svn_ndt/include/svn_ndt.h:186-206).  Exit code 0 = pass.  Needs an MI355X; run by tests/test_gpu_cpp_adapter.py.
+// (ref: extern/svn_ndt/include/svn_ndt.h:186-206) and, summed over a cloud's pairs, the per-pair hooks
+// computeAngleDerivatives / computePointDerivatives / updateDerivatives (:208-254).  Exit code 0 = pass.  Needs an MI355X; run by tests/test_gpu_cpp_adapter.py.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -167,6 +168,56 @@ int main() {
   Cloud wrong;
   svn.computeParticleDerivatives(g, H, wrong, p, true);
   CHECK(svn.lastStatus() == NDT_ERR_INVALID_ARG);
+
+  // ---- the per-pair hooks (ref: svn_ndt.h:208-254): computeAngleDerivatives once, then for every source point
+  // computePointDerivatives and, for every neighbour of the moved point, updateDerivatives -- the loop of the reference's
+  // computeParticleDerivatives (svn_ndt_impl.hpp:518-668) written with the adapter's names.  Its sums must agree with the
+  // engine's one-launch evaluation to the f32 products the hooks use (measured 5e-9 .. 3e-8 of the largest entry; bound 1e-6),
+  // Gauss-Newton and full.
+  for (int full = 0; full < 2; ++full) {
+    svn.setUseGaussNewtonHessian(full == 0);
+    V6 g_dev{};
+    ndt_hip::Matrix6d H_dev;
+    const double s_dev = svn.computeParticleDerivatives(g_dev, H_dev, moved, p, true);
+    CHECK(svn.lastStatus() == NDT_OK);
+    svn.computeAngleDerivatives(p, true);
+    V6 g_host{};
+    ndt_hip::Matrix6d H_host;
+    for (int r = 0; r < 6; ++r)
+      for (int c = 0; c < 6; ++c) H_host(r, c) = 0.0;
+    double s_host = 0.0;
+    long pairs = 0;
+    ndt_hip::Mat<float, 4, 6> pg;
+    ndt_hip::Mat<float, 24, 6> ph;
+    for (const PointT& q : src->points) {
+      for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 6; ++c) pg(r, c) = (r == c && r < 3) ? 1.0f : 0.0f;
+      const double x[3] = {q.x, q.y, q.z};
+      svn.computePointDerivatives(x, pg, ph, true);
+      PointT m{};   // the moved point, f32 in the reference's association (transformPointCloud)
+      m.x = T[0] * q.x + (T[4] * q.y + (T[8] * q.z + T[12]));
+      m.y = T[1] * q.x + (T[5] * q.y + (T[9] * q.z + T[13]));
+      m.z = T[2] * q.x + (T[6] * q.y + (T[10] * q.z + T[14]));
+      std::vector<const ndt_hip::TargetGrid::Leaf*> nb;
+      grid.getNeighborhoodAtPoint7(m, nb);
+      for (const auto* leaf : nb) {
+        const ndt_hip::Vector3d mu = leaf->getMean();
+        const double d[3] = {(double)m.x - mu[0], (double)m.y - mu[1], (double)m.z - mu[2]};
+        const ndt_hip::Matrix3d ci = leaf->getInverseCov();
+        s_host += svn.updateDerivatives(g_host, H_host, pg, ph, d, ci, true, full == 0);
+        ++pairs;
+      }
+    }
+    for (int i = 0; i < 6; ++i) H_host(i, i) += 1e-6;   // the ridge of computeParticleDerivatives (ref :650-653)
+    double gm = 0, hm = 0, ge = 0, he = 0;
+    for (int i = 0; i < 6; ++i) { gm = std::max(gm, std::fabs(g_dev[i])); ge = std::max(ge, std::fabs(g_host[i] - g_dev[i])); }
+    for (int r = 0; r < 6; ++r)
+      for (int c = 0; c < 6; ++c) { hm = std::max(hm, std::fabs(H_dev(r, c))); he = std::max(he, std::fabs(H_host(r, c) - H_dev(r, c))); }
+    std::printf("per-pair hooks, %s Hessian: %ld pairs, score %.9f (engine %.9f), gradient err %.2e of %.2e, Hessian err %.2e of %.2e\n",
+                full ? "full" : "Gauss-Newton", pairs, s_host, s_dev, ge, gm, he, hm);
+    CHECK(pairs == od.n_pairs);
+    CHECK(std::fabs(s_host - s_dev) <= 1e-9 * std::fabs(s_dev) && ge <= 1e-6 * gm && he <= 1e-6 * hm);
+  }
   oracle_grid_free(og);
   std::printf("PASS\n");
   return 0;

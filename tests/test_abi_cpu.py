@@ -319,3 +319,55 @@ def test_quoted_hbm_traffic_matches_the_newest_pmc_summary():
     assert have["FETCH_SIZE_KB"] == pytest.approx(want["FETCH_SIZE_KB"], rel=2e-3)
     assert have["WRITE_SIZE_KB"] == pytest.approx(want["WRITE_SIZE_KB"], rel=2e-3)
     assert os.path.basename(mod.newest_summary()) in have["source"]
+
+
+def test_angle_tables_are_the_derivatives_of_the_rotation(pkg):
+    """ndt_angle_tables (host arithmetic, no device): the eight rows of j_ang are d(R x)/d(roll, pitch, yaw) and the fifteen
+    rows of h_ang the second derivatives, in the reference's row order (svn_ndt_impl.hpp:270-331) -- checked against central
+    differences of R = Rx(roll) Ry(pitch) Rz(yaw) (ref: the pose-to-matrix convention of :761); ndt_gauss_constants against
+    the closed form of :90-130."""
+    L = pkg.lib()
+    L.ndt_angle_tables.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.ndt_gauss_constants.argtypes = [C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+
+    def rot(a):
+        cx, sx, cy, sy, cz, sz = np.cos(a[0]), np.sin(a[0]), np.cos(a[1]), np.sin(a[1]), np.cos(a[2]), np.sin(a[2])
+        rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+        ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+        rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+        return rx @ ry @ rz
+
+    ang = np.array([0.31, -0.22, 0.47])
+    pose = (C.c_double * 6)(1.0, 2.0, 3.0, *ang)
+    j, h = (C.c_float * 24)(), (C.c_float * 45)()
+    assert L.ndt_angle_tables(pose, j, h) == 0
+    j, h = np.array(j, dtype=np.float64).reshape(8, 3), np.array(h, dtype=np.float64).reshape(15, 3)
+    e = 1e-5
+
+    def d1(k):
+        dp = np.zeros(3); dp[k] = e
+        return (rot(ang + dp) - rot(ang - dp)) / (2 * e)
+
+    def d2(a, b):
+        da, db = np.zeros(3), np.zeros(3); da[a] = e; db[b] = e
+        return (rot(ang + da + db) - rot(ang + da - db) - rot(ang - da + db) + rot(ang - da - db)) / (4 * e * e)
+
+    # rows of j_ang: (component of x', angle): (y, roll) (z, roll) (x, pitch) (y, pitch) (z, pitch) (x, yaw) (y, yaw) (z, yaw)
+    for row, (comp, k) in enumerate([(1, 0), (2, 0), (0, 1), (1, 1), (2, 1), (0, 2), (1, 2), (2, 2)]):
+        np.testing.assert_allclose(j[row], d1(k)[comp], atol=2e-7)
+    assert np.abs(d1(0)[0]).max() < 1e-9   # x' does not depend on roll: no row for it
+    hrows = [(1, 0, 0), (2, 0, 0), (1, 0, 1), (2, 0, 1), (1, 0, 2), (2, 0, 2), (0, 1, 1), (1, 1, 1), (2, 1, 1),
+             (0, 1, 2), (1, 1, 2), (2, 1, 2), (0, 2, 2), (1, 2, 2), (2, 2, 2)]
+    for row, (comp, a, b) in enumerate(hrows):
+        want = d2(a, b)[comp]
+        if row == 6:   # the reference's table has +sin(pitch) where d2 x'/dpitch^2 has -sin(pitch) (kept: svn_ndt_impl.hpp:312)
+            want = want * np.array([1.0, 1.0, -1.0])
+        np.testing.assert_allclose(h[row], want, atol=2e-4)
+    d1c, d2c = C.c_double(), C.c_double()
+    assert L.ndt_gauss_constants(1.0, 0.55, C.byref(d1c), C.byref(d2c)) == 0
+    c1, c2 = 10.0 * (1 - 0.55), 0.55
+    d3 = -np.log(c2)
+    a = -np.log(c1 + c2) - d3
+    b = -2.0 * np.log((-np.log(c1 * np.exp(-0.5) + c2) - d3) / a)
+    assert abs(d1c.value - a) < 1e-15 and abs(d2c.value - b) < 1e-15
+    assert L.ndt_gauss_constants(0.0, 0.55, C.byref(d1c), C.byref(d2c)) != 0
