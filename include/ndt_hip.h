@@ -539,6 +539,10 @@ void ndt_svn_default_params(ndt_svn_params* p);
 /* prior.retract(sigma * N(0,1)) for K particles (ref :708-716); the reference seeds from the
  * wall clock, here the seed is explicit.  particles16: K x 16 doubles. */
 int ndt_svn_sample_particles(const double prior16[16], int K, uint64_t seed, double* particles16);
+/* The particle kernel of Stage 2 for ONE pair, as ndt_svn_align evaluates it (round 5; host arithmetic, no handle):
+ * k = exp(-|Log(l^-1 k)|^2 / bandwidth) and, if grad6 != NULL, its gradient with respect to l in l's tangent space,
+ * [rotation, translation] (ref: rbf_kernel / rbf_kernel_gradient, svn_ndt_impl.hpp:213-244).  Poses: 4 x 4 column-major. */
+int ndt_svn_rbf_kernel(const double pose_l16[16], const double pose_k16[16], double bandwidth, double* k, double* grad6);
 /* particles16 (K x 16): initial particles in, final particles out.  The source / target
  * clouds are those of the handle (ndt_set_target / ndt_set_source). */
 int ndt_svn_align(ndt_handle* h, const ndt_svn_params* p, const double prior16[16],

@@ -919,25 +919,26 @@ class SvnNormalDistributionsTransform {
         for (int j = 0; j < 6; ++j) hessian(i, j) += add[i][j];
     return score_inc;
   }
-  // k(l, k) = exp(-|Log(l^-1 k)|^2 / h) and its gradient with respect to l in l's tangent space; Pose3: gtsam's surface
-  // (between, Logmap, equals).  h: setKernelBandwidth.
+  // k(l, k) = exp(-|Log(l^-1 k)|^2 / h) and its gradient with respect to l in l's tangent space ([rotation, translation],
+  // gtsam's order), evaluated by the engine's own Stage-2 arithmetic (ndt_svn_rbf_kernel).  Pose3: anything with matrix();
+  // h: setKernelBandwidth.  The gradient comes back as Vec6 (default: six doubles in a std::array).
   template <class Pose3>
   double rbf_kernel(const Pose3& pose_l, const Pose3& pose_k) const {
-    if (svn_.kernel_bandwidth <= 1e-12) return pose_l.equals(pose_k, 1e-9) ? 1.0 : 0.0;
-    const auto xi = Pose3::Logmap(pose_l.between(pose_k));
-    double sq = 0.0;
-    for (int i = 0; i < 6; ++i) sq += xi[i] * xi[i];
-    return std::exp(-sq / svn_.kernel_bandwidth);
+    double a[16], b[16], k = 0.0;
+    pose_matrix(pose_l, a);
+    pose_matrix(pose_k, b);
+    ndt_svn_rbf_kernel(a, b, svn_.kernel_bandwidth, &k, nullptr);
+    return k;
   }
-  template <class Pose3>
-  auto rbf_kernel_gradient(const Pose3& pose_l, const Pose3& pose_k) const -> decltype(Pose3::Logmap(pose_l.between(pose_k))) {
-    auto xi = Pose3::Logmap(pose_l.between(pose_k));
-    if (svn_.kernel_bandwidth <= 1e-12) { for (int i = 0; i < 6; ++i) xi[i] = 0.0; return xi; }
-    double sq = 0.0;
-    for (int i = 0; i < 6; ++i) sq += xi[i] * xi[i];
-    const double s = std::exp(-sq / svn_.kernel_bandwidth) * (-2.0 / svn_.kernel_bandwidth);
-    for (int i = 0; i < 6; ++i) xi[i] *= s;
-    return xi;
+  template <class Vec6 = std::array<double, 6>, class Pose3>
+  Vec6 rbf_kernel_gradient(const Pose3& pose_l, const Pose3& pose_k) const {
+    double a[16], b[16], k = 0.0, g[6];
+    pose_matrix(pose_l, a);
+    pose_matrix(pose_k, b);
+    ndt_svn_rbf_kernel(a, b, svn_.kernel_bandwidth, &k, g);
+    Vec6 out{};
+    for (int i = 0; i < 6; ++i) out[i] = g[i];
+    return out;
   }
 
   int lastStatus() const { return status_; }
@@ -946,6 +947,12 @@ class SvnNormalDistributionsTransform {
 
  private:
   void push() { if (h_) status_ = ndt_set_params(h_, &prm_); updateNdtConstants(); }
+  template <class Pose3>
+  static void pose_matrix(const Pose3& p, double T[16]) {
+    const auto M = p.matrix();
+    for (int c = 0; c < 4; ++c)
+      for (int r = 0; r < 4; ++r) T[4 * c + r] = M(r, c);
+  }
   double gauss_d1_ = 0.0, gauss_d2_ = 0.0;
   float j_ang_[24] = {}, h_ang_[45] = {};
   size_t n_source_ = 0;

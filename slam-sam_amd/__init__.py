@@ -207,7 +207,7 @@ ABI_SYMBOLS = [
     "ndt_set_handoff_mode", "ndt_get_handoff_mode", "ndt_wait", "ndt_get_handoff_timing",
     "ndt_voxel_downsample_device", "ndt_voxel_downsample", "ndt_get_iteration_history",
     "ndt_get_tuning", "ndt_set_tuning", "ndt_set_keepwarm", "ndt_get_keepwarm",
-    "ndt_comm_p2p_selftest", "ndt_comm_p2p_stats", "ndt_angle_tables", "ndt_gauss_constants",
+    "ndt_comm_p2p_selftest", "ndt_comm_p2p_stats", "ndt_angle_tables", "ndt_gauss_constants", "ndt_svn_rbf_kernel",
 ]
 
 _lib = None

@@ -30,6 +30,21 @@ extern "C" int ndt_eval_derivatives_overlapped(ndt_handle* h, const double* pose
 namespace se3 = ndt::se3;
 
 namespace {
+// k(l, k) = exp(-|Log(l^-1 k)|^2 / h) and its gradient with respect to l in l's tangent space, k (-2 / h) Log(l^-1 k)
+// (ref: svn_ndt_impl.hpp:213-244); h <= 1e-12: the delta function the reference falls back to
+inline void rbf_pair(const se3::Pose& l, const se3::Pose& k, double hb, double* kv, double kg[6]) {
+  double d[6];
+  se3::logmap(se3::between(l, k), d);
+  double sq = 0;
+  for (int i = 0; i < 6; ++i) sq += d[i] * d[i];
+  if (hb <= 1e-12) {
+    *kv = sq < 1e-18 ? 1.0 : 0.0;
+    for (int i = 0; i < 6; ++i) kg[i] = 0.0;
+  } else {
+    *kv = std::exp(-sq / hb);
+    for (int i = 0; i < 6; ++i) kg[i] = *kv * (-2.0 / hb) * d[i];
+  }
+}
 
 double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -123,6 +138,14 @@ void ndt_svn_default_params(ndt_svn_params* p) {
   p->stop_threshold = 1e-4;
 }
 
+int ndt_svn_rbf_kernel(const double pose_l16[16], const double pose_k16[16], double bandwidth, double* k, double* grad6) {
+  if (!pose_l16 || !pose_k16 || !k) return NDT_ERR_INVALID_ARG;
+  double kg[6];
+  rbf_pair(se3::from_colmajor(pose_l16), se3::from_colmajor(pose_k16), bandwidth, k, kg);
+  if (grad6) std::memcpy(grad6, kg, sizeof(kg));
+  return NDT_OK;
+}
+
 int ndt_svn_sample_particles(const double prior16[16], int K, uint64_t seed, double* particles16) {
   if (!prior16 || !particles16 || K <= 0) return NDT_ERR_INVALID_ARG;
   // prior.retract(sigma .* N(0,1)), sigmas in GTSAM order [rot, trans] (ref :708-716).  The
@@ -194,18 +217,8 @@ int ndt_svn_align(ndt_handle* h, const ndt_svn_params* sp, const double prior16[
       kok.assign((size_t)K * K, 1);
       for (int l = 0; l < K; ++l)
         for (int k = l + 1; k < K; ++k) {
-          double d[6];
-          se3::logmap(se3::between(part[(size_t)l], part[(size_t)k]), d);
-          double sq = 0;
-          for (int i = 0; i < 6; ++i) sq += d[i] * d[i];
           double kv, kg[6];
-          if (hb <= 1e-12) {
-            kv = sq < 1e-18 ? 1.0 : 0.0;
-            std::memset(kg, 0, sizeof(kg));
-          } else {
-            kv = std::exp(-sq / hb);
-            for (int i = 0; i < 6; ++i) kg[i] = kv * (-2.0 / hb) * d[i];
-          }
+          rbf_pair(part[(size_t)l], part[(size_t)k], hb, &kv, kg);
           const bool ok = std::isfinite(kv) && all_finite(kg, 6);
           const size_t a = (size_t)l * K + k, b = (size_t)k * K + l;
           kval[a] = kval[b] = kv;

@@ -207,6 +207,23 @@ int main() {
               result.iterations, std::sqrt(serr), result.final_covariance(0, 0));
   ok = ok && result.iterations > 0 && std::sqrt(serr) < 0.05 && result.final_covariance(0, 0) > 0.0;
 
+  // the particle kernel hooks (ref: svn_ndt.h:256-276): k(l, l) = 1 with a zero gradient; for a pure translation d the
+  // logarithm is d itself: k = exp(-|d|^2 / h), gradient = k (-2 / h) [0, 0, 0, d] in gtsam's [rotation, translation] order
+  {
+    Eigen::Matrix4d A = Eigen::Matrix4d::Identity(), B = Eigen::Matrix4d::Identity();
+    B(0, 3) = 0.3; B(1, 3) = -0.2; B(2, 3) = 0.1;
+    const gtsam::Pose3 pa(A), pb(B);
+    const double kaa = svn_ndt_ptr->rbf_kernel(pa, pa), kab = svn_ndt_ptr->rbf_kernel(pa, pb);
+    const auto gaa = svn_ndt_ptr->rbf_kernel_gradient(pa, pa), gab = svn_ndt_ptr->rbf_kernel_gradient(pa, pb);
+    const double want = std::exp(-(0.09 + 0.04 + 0.01) / 1.0);
+    double gerr = std::fabs(gab[0]) + std::fabs(gab[1]) + std::fabs(gab[2]) + std::fabs(gab[3] + 2.0 * want * 0.3) +
+                  std::fabs(gab[4] - 2.0 * want * 0.2) + std::fabs(gab[5] + 2.0 * want * 0.1);
+    for (int i = 0; i < 6; ++i) gerr += std::fabs(gaa[i]);
+    std::printf("[F] rbf_kernel: k(a, a)=%.3f k(a, b)=%.12f (want %.12f) gradient err %.1e; gauss d1=%.6f d2=%.6f\n", kaa, kab, want, gerr,
+                svn_ndt_ptr->gaussD1(), svn_ndt_ptr->gaussD2());
+    ok = ok && kaa == 1.0 && std::fabs(kab - want) < 1e-15 && gerr < 1e-14 && svn_ndt_ptr->gaussD1() < 0.0 && svn_ndt_ptr->gaussD2() > 0.0;
+  }
+
   std::printf(ok ? "PASS\n" : "FAIL\n");
   return ok ? 0 : 1;
 }
