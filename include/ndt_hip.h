@@ -249,7 +249,7 @@ typedef struct ndt_tuning {
   int deriv_single_level_max; /* rows one block adds directly (default 2048); larger grids go through 32 group rows */
   int deriv_xcd;              /* 0: chunk = block id; 1: XCD-aware chunks on resident single-pose grids (default); 2: stripes too */
   int bucket_build;           /* 1: steady-state builds in two launches (default); 0: launch-per-phase sort pipeline */
-  int bucket_tile;            /* 0: chosen from the cloud size (default); 4096 | 8192 points per tile of k_bucket_pass */
+  int bucket_tile;            /* 0: chosen from the cloud size (default); 1024 | 2048 | 4096 | 8192 points per tile of k_bucket_pass */
   int fused_sort;             /* 1: one launch per sort digit where the cloud allows it (default); 0: classic passes */
   int bounds_blocks;          /* blocks of the bounds pass (default 256) */
   int bounds_unroll;          /* 8 (default) | 4 */

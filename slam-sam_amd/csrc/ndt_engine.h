@@ -133,7 +133,7 @@ struct ndt_handle {
   DevBuf<uint32_t> run_tags;          // tagged block leaf counts of the fused run search
   uint32_t run_seq = 0;
   long long n_fused_sort_fallbacks = 0;
-  DevBuf<int> bucket_off;             // first point of every bucket (two-launch bucketed build)
+  DevBuf<uint32_t> bucket_tab;        // two-launch build: where a tile holds a bucket's points, [bucket][tile] = {count : 16 | first : 16}
   DevBuf<int> bnd;                    // its 8 bounds words {min xyz, max xyz, #finite, largest bucket}; neutral between builds
   long long n_bucket_builds = 0, n_bucket_fallbacks = 0;
   int bucket_skip = 0, bucket_backoff = 0;  // builds to go before the two-launch build is tried again after a decline

@@ -121,7 +121,7 @@ int build_begin(ndt_handle* h, const float* x, const float* y, const float* z, s
 
   HIP_TRY(h, h->small.ensure(16));
   HIP_TRY(h, h->brows.ensure(8 * (size_t)std::max(nrows, bucket_build_tiles(n))));
-  HIP_TRY(h, h->bucket_off.ensure(260));
+  HIP_TRY(h, h->bucket_tab.ensure(bucket_table_words()));
   if (!h->bnd.p) {
     HIP_TRY(h, h->bnd.ensure(8));
     int rc = neutral_bounds(h);
@@ -153,7 +153,7 @@ int build_begin(ndt_handle* h, const float* x, const float* y, const float* z, s
   // fused = launches that wait, inside the kernel, for sibling blocks (k_sort_pass, k_runs<RUNS_FUSED>)
   br.fused = fused_build_enabled();
   br.fused_sort = br.fused && fused_sort_fits(n, h->n_cus);
-  // the two-launch build: steady state only (decided per attempt below), and it shares the tag table
+  // the two-launch build: steady state only (decided per attempt below)
   br.bucketed_ok = bucket_build_enabled() && bucket_build_fits(n, h->n_cus);
   // A cloud the two-launch build declined (BG_BUCKET: a bucket beyond a block's LDS or hash table, far-away coordinates)
   // is usually followed by more of its kind (the same map, the next keyframe): the attempt costs two launches and, for a
@@ -163,7 +163,7 @@ int build_begin(ndt_handle* h, const float* x, const float* y, const float* z, s
     --h->bucket_skip;
     br.bucketed_ok = false;
   }
-  if ((br.fused_sort || br.bucketed_ok) && !h->sort_tags.p) {
+  if (br.fused_sort && !h->sort_tags.p) {
     HIP_TRY(h, h->sort_tags.ensure(fused_table_words()));
     HIP_TRY(h, hipMemsetAsync(h->sort_tags.p, 0, h->sort_tags.cap * sizeof(uint32_t), s));
     h->sort_seq = 0;
@@ -212,10 +212,10 @@ int build_enqueue(ndt_handle* h, ndt_handle::BuildRun& br) {
   if (br.bucketed) {
     // bounds, partition, sort, sums and statistics in two launches (k_bucket_pass, k_bucket_leaves)
     FinalizeParams fpb{h->prm.eig_inflation_ratio, h->prm.cov_mode};
-    HIP_TRY(h, launch_bucket_build(x, y, z, n, br.leaf, br.inv_leaf, cap_cells, min_pts, fpb, h->gd.p, h->gdh.d, h->sort_tags.p,
-                                   &h->sort_seq, h->stats.p, br.dirty_slots, h->cell2leaf.p, h->cell2leaf.cap, h->bnd.p,
-                                   h->bucket_off.p, h->nleaf.p, h->tickets.p + 4, h->xyz4.p, h->leaf_sums.p, h->rec.p,
-                                   h->cent.p, h->stats.p, max_leaves, h->small.d + 8, done_tag, s, h->n_cus));
+    HIP_TRY(h, launch_bucket_build(x, y, z, n, br.leaf, br.inv_leaf, cap_cells, min_pts, fpb, h->gd.p, h->gdh.d, h->bucket_tab.p,
+                                   h->stats.p, br.dirty_slots, h->cell2leaf.p, h->cell2leaf.cap, h->bnd.p,
+                                   h->nleaf.p, h->tickets.p + 4, h->xyz4.p, h->leaf_sums.p, h->rec.p,
+                                   h->cent.p, h->stats.p, max_leaves, h->small.d + 8, done_tag, s));
   } else {
     launch_bounds_geometry(x, y, z, n, br.leaf, br.inv_leaf, cap_cells, passes, h->brows.p, h->tickets.p, h->gd.p, h->gdh.d,
                            optimistic ? h->stats.p : nullptr, optimistic ? br.dirty_slots : 0, h->cell2leaf.p,

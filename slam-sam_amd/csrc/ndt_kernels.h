@@ -53,24 +53,36 @@ hipError_t sort_cloud_fused(const float* x, const float* y, const float* z, size
                             bool* result_in_b);
 
 // The whole build in TWO launches (k_bucket_pass + k_bucket_leaves, ndt_target.hip): steady state only --
-// every buffer exists and the dense grid holds nothing but the `dirty_slots` cells of old_stats.  `table` /
-// *seq: the tagged tile-count table of the fused sort passes (shared with them).  rows: 8 ints per tile of
-// 8192 points; bucket_off: 257 ints; pts4: n float4 (the cloud partitioned by bucket); sums: 9 doubles per
-// leaf slot.  Refusals leave BG_BUCKET / BG_SPIN / BG_CAPACITY / ... in *gd_host with nothing written.
+// every buffer exists and the dense grid holds nothing but the `dirty_slots` cells of old_stats.  tab: the
+// partition's column table, bucket_table_words() words (written by the first launch, read by the second: no
+// tags, no initial state); pts4: n float4 (the cloud, tile by tile, each tile in bucket order); sums: 9 doubles
+// per leaf slot.  Neither launch waits for sibling blocks.  Refusals leave BG_BUCKET / BG_CAPACITY / ... in
+// *gd_host: decided before anything is written, except a bucket beyond a block's LDS or hash table (late BG_BUCKET).
 bool bucket_build_enabled();                            // NDT_BUCKET_BUILD != 0 (default on)
-// the 8 bounds words {min xyz, max xyz, #finite, largest bucket} between two builds (host copy for (re)initialisation;
+// the 8 bounds words {min xyz, max xyz, #finite, unused} between two builds (host copy for (re)initialisation;
 // the launch pair leaves them neutral again whenever it runs to its end)
 void bucket_bounds_neutral(int out[8]);
 bool bucket_build_fits(size_t n, int compute_units);
 int bucket_build_tiles(size_t n);
+size_t bucket_table_words();
+// ... or piecewise (the asynchronous host hand-off runs the partition under the transfer, chunk by chunk, and only the
+// leaves launch behind the last chunk): tiles [tile_first, tile_end) of bucket_build_tiles(n), each of
+// bucket_tile_points(n) points; every tile exactly once, tile 0's launch first (it resets the previous build's cells)
+size_t bucket_tile_points(size_t n);
+hipError_t launch_bucket_pass_tiles(const float* x, const float* y, const float* z, size_t n, float inv_leaf, uint32_t* tab,
+                                    const LeafStats* old_stats, int dirty_slots, int* cell2leaf, size_t c2l_cap, int* bnd,
+                                    int* d_nleaf, float* pts4, int tile_first, int tile_end, hipStream_t s);
+hipError_t launch_bucket_leaves(size_t n, float leaf, float inv_leaf, long long cell_capacity, int min_pts, FinalizeParams fp,
+                                BuildGeom* gd, BuildGeom* gd_host, const uint32_t* tab, int* cell2leaf, int* bnd, int* d_nleaf,
+                                unsigned int* ticket, const float* pts4, double* sums, VoxelRecord* rec, float* cent4,
+                                LeafStats* stats, int max_leaves, int* nleaf_host, int done_tag, hipStream_t s);
 hipError_t launch_bucket_build(const float* x, const float* y, const float* z, size_t n, float leaf, float inv_leaf,
                                long long cell_capacity, int min_pts, FinalizeParams fp, BuildGeom* gd, BuildGeom* gd_host,
-                               uint32_t* table, uint32_t* seq, const LeafStats* old_stats, int dirty_slots, int* cell2leaf,
-                               size_t c2l_cap, int* bnd /* 8 ints, see bucket_bounds_neutral */, int* bucket_off, int* d_nleaf,
+                               uint32_t* tab, const LeafStats* old_stats, int dirty_slots, int* cell2leaf,
+                               size_t c2l_cap, int* bnd /* 8 ints, see bucket_bounds_neutral */, int* d_nleaf,
                                unsigned int* ticket, float* pts4,
                                double* sums, VoxelRecord* rec, float* cent4 /* 4 floats per leaf slot: f32 centroid + chain link */,
-                               LeafStats* stats, int max_leaves, int* nleaf_host, int done_tag, hipStream_t s,
-                               int compute_units /* of the device: the pass takes 4096-point tiles when they all fit it */);
+                               LeafStats* stats, int max_leaves, int* nleaf_host, int done_tag, hipStream_t s);
 
 // runs of equal cell key with >= min_pts points get a leaf slot (ascending cell order);
 // block_counts / block_offsets: runs_blocks(n) ints each; d_nleaf[0] receives the total

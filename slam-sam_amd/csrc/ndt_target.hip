@@ -1334,32 +1334,35 @@ __device__ __forceinline__ uint32_t bucket_of(float fx, float fy, float fz) {
   return h >> 24;
 }
 
-// ROUNDS: points per thread = tile size / 1024.  8 (8192-point tiles: 123 blocks for 1 M points, fewer than half the
-// compute units) or 4 (4096-point tiles: 245 blocks; the same partition, stable in input order whatever the tile size,
-// so the output is bit-identical).  4 is an A/B knob (launch_bucket_build): no faster.
+// ROUNDS: points per thread = tile size / 1024 (1, 2, 4, 8: bucket_rounds_for(n) keeps the launch at <= BK_MAX_TILES tiles
+// and, for the clouds the drivers hand over, at one tile per compute unit or more).
+//
+// Round 5: the partition is PER TILE.  A tile goes out in bucket order into its own window of pts_out
+// ([tile * TILE, tile * TILE + tile_n): one contiguous, coalesced store of the staged tile) and says where each bucket's
+// points lie in the column table tab[bucket][tile] = {count : 16 | first : 16}; the bucket's block of the next launch
+// gathers its ~ntiles segments in tile order -- the same points in the same (input) order as the cloud-wide partition
+// of rounds 3-4, so the leaves are bit-identical.  What went away: the tagged tile-count table every tile published and
+// then polled for all the others (5.5 us of the launch's 23: write -> visible -> read of 123 KB by every block, and
+// the launch needed every tile resident at once, BG_SPIN when it was not), the cloud-wide bucket offsets and the
+// scattered 16-byte stores.  The launch waits for nothing now: any grid size, any residency.
+constexpr int BK_MAX_TILES = 256;   // = threads that scan a bucket's column in k_bucket_leaves
 template <int ROUNDS>
 __global__ void __launch_bounds__(BK_THREADS) k_bucket_pass(const float* __restrict__ x, const float* __restrict__ y,
-                                                           const float* __restrict__ z, int n, float inv_leaf, int ntiles,
-                                                           uint32_t* __restrict__ table, uint32_t tag, int mute_tile,
-                                                           BuildGeom* __restrict__ gd, BuildGeom* __restrict__ gd_host,
+                                                           const float* __restrict__ z, int n, float inv_leaf,
+                                                           int tile0 /* first tile of this launch (the host hand-off launches the pass chunk by chunk) */,
+                                                           uint32_t* __restrict__ tab,
                                                            const LeafStats* __restrict__ old_stats, int dirty_slots,
                                                            int* __restrict__ cell2leaf, size_t c2l_cap,
-                                                           int* __restrict__ bnd, int* __restrict__ bucket_off,
-                                                           int* __restrict__ d_nleaf, float4* __restrict__ pts_out) {
+                                                           int* __restrict__ bnd, int* __restrict__ d_nleaf,
+                                                           float4* __restrict__ pts_out) {
   constexpr int TILE = BK_THREADS * ROUNDS;
   __shared__ int cnt[BK_WAVES][SORT_BINS];
-  // the column partial sums, and later -- once they have been folded -- the tile in bucket order
-  constexpr int STAGE_WORDS = TILE > 2 * BK_WAVES * SORT_BINS / 4 ? TILE : 2 * BK_WAVES * SORT_BINS / 4;  // float4s
-  __shared__ float4 stage[STAGE_WORDS];
-  int (*part_total)[SORT_BINS] = reinterpret_cast<int (*)[SORT_BINS]>(stage);
-  int (*part_before)[SORT_BINS] = reinterpret_cast<int (*)[SORT_BINS]>(reinterpret_cast<int*>(stage) + BK_WAVES * SORT_BINS);
-  __shared__ int gbase[SORT_BINS];
+  __shared__ float4 stage[TILE];   // the tile in bucket order
   __shared__ int lbase[SORT_BINS];
-  __shared__ int wsum[2 * SORT_BINS / 64];
+  __shared__ int wsum[SORT_BINS / 64];
   __shared__ int wrow[BK_WAVES][8];
-  __shared__ int s_fail, s_bmax;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tile = blockIdx.x;
+  const int tile = tile0 + (int)blockIdx.x;
   // the cells the PREVIOUS build published (the dense grid is filled with -1 once per allocation)
   for (int slot = blockIdx.x * BK_THREADS + threadIdx.x; slot < dirty_slots; slot += gridDim.x * BK_THREADS) {
     const int cell = old_stats[slot].cell;
@@ -1374,6 +1377,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_pass(const float* __restr
     const int j = i < n ? i : 0;
     a[r] = x[j]; b[r] = y[j]; c[r] = z[j];
   }
+  for (int d = threadIdx.x; d < BK_WAVES * SORT_BINS; d += BK_THREADS) (&cnt[0][0])[d] = 0;
   uint32_t dig[ROUNDS];
   int mn[3] = {INT_MAX, INT_MAX, INT_MAX}, mx[3] = {INT_MIN, INT_MIN, INT_MIN}, nfin = 0;
 #pragma unroll
@@ -1389,8 +1393,6 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_pass(const float* __restr
       ++nfin;
     }
   }
-  for (int d = threadIdx.x; d < BK_WAVES * SORT_BINS; d += BK_THREADS) (&cnt[0][0])[d] = 0;
-  if (threadIdx.x == 0) { s_fail = 0; s_bmax = 0; }
   // ref: pcl::getMinMax3D at voxel_grid_covariance_impl.hpp:103 -- this tile's share of the bounds
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -1423,7 +1425,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_pass(const float* __restr
     else atomicAdd(&bnd[6], v);
   }
   NDT_BSTAMP(4, 1);  // points loaded, bounds row written
-  // stable rank among the equal buckets before it in the wave's 512 points (8 ballots per round)
+  // stable rank among the equal buckets before it in the wave's 64 * ROUNDS points (8 ballots per round)
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   int rank[ROUNDS];
 #pragma unroll
@@ -1446,7 +1448,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_pass(const float* __restr
   }
   __syncthreads();
   NDT_BSTAMP(4, 2);  // ranked
-  int my_count = 0;  // bucket threadIdx.x in this tile
+  int my_count = 0, l_excl = 0;  // bucket threadIdx.x in this tile: its points, and the tile's points in the buckets before it
   if (threadIdx.x < SORT_BINS) {
     int run = 0;
 #pragma unroll
@@ -1456,79 +1458,21 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_pass(const float* __restr
       run += t;
     }
     my_count = run;
-    if (tile != mute_tile)
-      __hip_atomic_store(table + (size_t)tile * SORT_BINS + threadIdx.x, (tag << 16) | (uint32_t)run, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-  }
-  {  // the whole table, 16 bytes (four buckets) per lane and one tile row per wave and trip (as k_sort_pass)
-    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(table, 0, 0xFFFFFFFFu, 0x00020000);
-    int tot[4] = {0, 0, 0, 0}, bef[4] = {0, 0, 0, 0};
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    constexpr int BATCH = 8;
-    for (int r0 = wave; r0 < ntiles; r0 += BATCH * BK_WAVES) {
-      u32x4_t w[BATCH];
-      for (;;) {
-        asm volatile("" ::: "memory");  // the loads below must be re-issued on every trip
-        bool ok = true;
-#pragma unroll
-        for (int k = 0; k < BATCH; ++k) {
-          const int row = r0 + k * BK_WAVES;
-          if (row < ntiles)
-            w[k] = __builtin_amdgcn_raw_buffer_load_b128(rt, ((unsigned int)row * SORT_BINS + 4u * lane) * 4u, 0, 16 /* sc1 */);
-          else
-            w[k].x = w[k].y = w[k].z = w[k].w = tag << 16;
-        }
-#pragma unroll
-        for (int k = 0; k < BATCH; ++k)
-          ok = ok && (w[k].x >> 16) == tag && (w[k].y >> 16) == tag && (w[k].z >> 16) == tag && (w[k].w >> 16) == tag;
-        if (ok) break;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > FUSED_TIMEOUT_TICKS) { s_fail = 1; break; }
-        __builtin_amdgcn_s_sleep(1);
-      }
-#pragma unroll
-      for (int k = 0; k < BATCH; ++k) {
-        const int row = r0 + k * BK_WAVES;
-        const int c0 = w[k].x & 0xffff, c1 = w[k].y & 0xffff, c2 = w[k].z & 0xffff, c3 = w[k].w & 0xffff;
-        tot[0] += c0; tot[1] += c1; tot[2] += c2; tot[3] += c3;
-        if (row < tile) { bef[0] += c0; bef[1] += c1; bef[2] += c2; bef[3] += c3; }
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { part_total[wave][4 * lane + q] = tot[q]; part_before[wave][4 * lane + q] = bef[q]; }
-  }
-  __syncthreads();
-  NDT_BSTAMP(4, 3);  // table read
-  if (s_fail) {
-    if (threadIdx.x == 0) { gd->status = BG_SPIN; gd_host->status = BG_SPIN; }
-    return;
-  }
-  int g_excl = 0, l_excl = 0, b_total = 0;  // bucket threadIdx.x: first output slot over all tiles / inside this tile
-  if (threadIdx.x < SORT_BINS) {
-    int t = 0, bsum = 0;
-#pragma unroll
-    for (int q = 0; q < BK_WAVES; ++q) { t += part_total[q][threadIdx.x]; bsum += part_before[q][threadIdx.x]; }
-    const int incl = wave_inclusive_scan(t, lane);
     const int lincl = wave_inclusive_scan(my_count, lane);
-    if (lane == 63) { wsum[wave] = incl; wsum[4 + wave] = lincl; }
-    g_excl = incl - t + bsum;
+    if (lane == 63) wsum[wave] = lincl;
     l_excl = lincl - my_count;
-    b_total = incl - t;
-    if (tile == 0) atomicMax(&s_bmax, t);   // the largest bucket of the cloud (it must fit one block of the next launch)
-  }
-  __syncthreads();  // part_total / part_before are dead from here on: `stage` becomes the staging tile
-  if (threadIdx.x < SORT_BINS) {
-    int before = 0, lbefore = 0;
-    for (int w = 0; w < wave; ++w) { before += wsum[w]; lbefore += wsum[4 + w]; }
-    gbase[threadIdx.x] = before + g_excl;
-    lbase[threadIdx.x] = lbefore + l_excl;
-    if (tile == 0) {  // first point of every bucket in the partitioned cloud, for the next launch
-      bucket_off[threadIdx.x] = before + b_total;
-      if (threadIdx.x == SORT_BINS - 1) bucket_off[SORT_BINS] = n;
-      if (threadIdx.x == 0) bnd[7] = s_bmax;
-    }
   }
   __syncthreads();
-  // the tile in bucket order through LDS, so that a wave's global stores fall into a few contiguous runs
+  if (threadIdx.x < SORT_BINS) {
+    int lbefore = 0;
+    for (int w = 0; w < wave; ++w) lbefore += wsum[w];
+    const int first = lbefore + l_excl;   // <= TILE <= 8192: 16 bits each
+    lbase[threadIdx.x] = first;
+    tab[(size_t)threadIdx.x * BK_MAX_TILES + tile] = ((uint32_t)my_count << 16) | (uint32_t)first;
+  }
+  __syncthreads();
+  NDT_BSTAMP(4, 3);  // bucket offsets of the tile known, column entries issued
+  // the tile in bucket order through LDS: the global stores below are one contiguous run
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
     if (fused_index<ROUNDS>(tile, wave, r, lane) >= n) break;
@@ -1538,13 +1482,12 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_pass(const float* __restr
   __syncthreads();
   NDT_BSTAMP(4, 4);  // staged
   const int tile_n = min(TILE, n - tile * TILE);
+  float4* __restrict__ window = pts_out + (size_t)tile * TILE;
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
     const int j = r * BK_THREADS + (int)threadIdx.x;
     if (j >= tile_n) break;
-    const float4 q = stage[j];
-    const uint32_t d = __float_as_uint(q.w);
-    pts_out[gbase[d] + (j - lbase[d])] = q;
+    window[j] = stage[j];   // (non-temporal stores measured: 54.6 against 54.5 us per build, nothing)
   }
 #ifdef NDT_STAMPS
   __builtin_amdgcn_s_waitcnt(0);
@@ -1667,7 +1610,8 @@ __device__ __forceinline__ void reset_bounds_words(int* __restrict__ bnd) {
   bnd[7] = 0;
 }
 
-__global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __restrict__ pts, const int* __restrict__ bucket_off,
+__global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __restrict__ pts, const uint32_t* __restrict__ coltab,
+                                                             int ntiles, int tile_shift,
                                                              int* __restrict__ bnd, float leaf,
                                                              float inv_leaf, long long cell_capacity, int min_pts,
                                                              FinalizeParams fp, BuildGeom* __restrict__ gd,
@@ -1690,24 +1634,51 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __re
   static_assert(sizeof(BucketLeaf) * BK_MAX_LEAVES <= sizeof(region_a), "leaf list aliases region A");
   __shared__ unsigned short sidx[BK_MAXP];
   __shared__ int dbase[SORT_BINS];
+  __shared__ uint32_t idcell[SORT_BINS];   // the cell behind a dense id (buckets of <= 256 distinct cells: one digit pass)
   __shared__ int wsum[BK_WAVES];
   __shared__ int wave_head[BK_WAVES], wave_total[BK_WAVES];
   __shared__ int s_base, s_ok, s_decline;
+  // where the bucket's points lie: position p of the bucket (input order) is pts[t_src[t] + p] for the last tile t
+  // with t_first[t] <= p (t_first: first position a tile contributes; INT_MAX beyond the launch's tiles)
+  __shared__ int t_first[BK_MAX_TILES + 1], t_src[BK_MAX_TILES];
+  __shared__ int csum[BK_MAX_TILES / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int bucket = blockIdx.x;
   NDT_BSTAMP(5, 0);
-  // ---- everything this block reads from HBM is requested now: the bounds rows, the bucket sizes, its points ----
-  // (the launch starts on cold caches: every dependent round trip is ~2 us, so the verdict of the partition
-  // launch travels with the bucket's range instead of in front of it)
-  const int prior_status = gd->status;
+  // ---- everything this block needs before its points is requested now: the bounds words and its column of the
+  // partition's table (the launch starts on cold caches: every dependent round trip is ~2 us) ----
+  uint32_t col = 0u;
+  if ((int)threadIdx.x < ntiles) col = coltab[(size_t)bucket * BK_MAX_TILES + threadIdx.x];
   int bw[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) bw[k] = bnd[k];   // uniform: scalar loads
-  const int base = bucket_off[bucket], m = bucket_off[bucket + 1] - base;
-  if (prior_status == BG_SPIN) {  // the partition launch gave up waiting (uniform over the grid)
-    if (bucket == 0 && threadIdx.x == 0) reset_bounds_words(bnd);
-    return;
+  int m_all;
+  {
+    const int mine = (int)(col >> 16);
+    const int incl = wave_inclusive_scan(mine, lane);
+    if (lane == 63 && wave < BK_MAX_TILES / 64) csum[wave] = incl;
+    __syncthreads();
+    int before = incl - mine;
+    m_all = 0;
+#pragma unroll
+    for (int w = 0; w < BK_MAX_TILES / 64; ++w) {
+      if (w < wave) before += csum[w];
+      m_all += csum[w];
+    }
+    m_all = __builtin_amdgcn_readfirstlane(m_all);   // (uniform: the round counts below stay scalar)
+    if (threadIdx.x < BK_MAX_TILES) {
+      const bool live = (int)threadIdx.x < ntiles;
+      t_first[threadIdx.x] = live ? before : INT_MAX;
+      t_src[threadIdx.x] = ((int)threadIdx.x << tile_shift) + (int)(col & 0xffffu) - before;
+    }
+    if (threadIdx.x == 0) t_first[BK_MAX_TILES] = INT_MAX;
+    __syncthreads();
   }
+  NDT_BSTAMP(5, 7);  // column scanned: the bucket knows where its points lie
+  // a bucket beyond a block's LDS (a voxel holding thousands of points, a cloud beyond ~1.3 M): this block takes no
+  // point and says so in the launch's tail word; the host clears the grid and repeats the build sort-based
+  const bool oversize = m_all > BK_MAXP;
+  const int m = oversize ? 0 : m_all;
   // Position p = wave * C + round * 64 + lane: a wave owns C consecutive positions, so "tile order" is (wave, round,
   // lane) as in the sort passes above; C is the smallest multiple of 64 that spreads the bucket over all 16 waves
   // (a bucket of 3906 points: 4 rounds on every wave instead of 8 rounds on half of them).
@@ -1717,7 +1688,13 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __re
   for (int r = 0; r < BK_ROUNDS; ++r) {
     const int p = wave * C + r * 64 + lane;
     q[r] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (r < R && p < m) q[r] = pts[base + p];
+    if (r < R && p < m) {
+      int t = 0;
+#pragma unroll
+      for (int step = BK_MAX_TILES / 2; step >= 1; step >>= 1)
+        if (t_first[t + step] <= p) t += step;
+      q[r] = pts[t_src[t] + p];
+    }
   }
   // ---- geometry: every wave derives the same BuildGeom from the seven bounds words, in registers ---------------
   // (same f32 arithmetic as voxel_grid_covariance_impl.hpp:108-140; no LDS, no barrier)
@@ -1730,7 +1707,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __re
       bool big = false;
 #pragma unroll
       for (int k = 0; k < 6; ++k) big = big || !(fabsf(floorf(decode_ordered_dev(bw[k]) * inv_leaf)) < BK_COORD_LIMIT);
-      if (big || bw[7] > BK_MAXP) out->status = BG_BUCKET;
+      if (big) out->status = BG_BUCKET;
     }
   };
   GridGeom g;
@@ -1824,9 +1801,15 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __re
     dd[1] = (unsigned short)(before + o0);
     dd[2] = (unsigned short)(before + o0 + o1);
     dd[3] = (unsigned short)(before + o0 + o1 + o2);
+    if (total <= SORT_BINS) {   // (uniform) id -> cell, for the leaf list that comes straight out of the digit counters
+      if (o0) idcell[before] = t4.x;
+      if (o1) idcell[before + o0] = t4.y;
+      if (o2) idcell[before + o0 + o1] = t4.z;
+      if (o3) idcell[before + o0 + o1 + o2] = t4.w;
+    }
     __syncthreads();
   }
-  const bool decline = s_decline != 0 || ndistinct > BK_MAX_DISTINCT;   // uniform over the block
+  const bool decline = oversize || s_decline != 0 || ndistinct > BK_MAX_DISTINCT;   // uniform over the block
   uint32_t key[BK_ROUNDS];   // the dense id of the point's cell from here on
   unsigned short idx[BK_ROUNDS];
 #pragma unroll
@@ -1841,6 +1824,13 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __re
   while ((1 << idbits) < ndistinct) ++idbits;
   const int npass = decline ? 0 : (idbits + 7) / 8;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  // One digit pass (<= 256 distinct cells, the usual bucket): the digit IS the dense id, so the pass's counters are the
+  // runs -- id d starts at dbase[d] and holds its column total -- and the leaf list is a scan over 256 flags under the
+  // scatter, where the general path below walks the 8192 sorted positions once more (two barriers, ~3 us).  Same leaves
+  // in the same (id) order with the same slots.
+  const bool one_pass = npass == 1;
+  int id_count = 0, id_start = 0, id_flag = 0, id_incl = 0;
+  uint32_t id_cell = 0u;
   for (int pass = 0; pass < npass; ++pass) {
     const int width = (idbits + npass - 1 - pass) / npass;           // e.g. 11 bits: 6 + 5
     const int shift = pass == 0 ? 0 : (idbits + npass - 1) / npass;  // (two passes at most: ndistinct <= 3584)
@@ -1880,12 +1870,24 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __re
       const int incl = wave_inclusive_scan(run, lane);
       if (lane == 63) wsum[wave] = incl;
       dbase[threadIdx.x] = incl - run;
+      id_count = run;
     }
     __syncthreads();
     if (threadIdx.x < SORT_BINS) {
       int before = 0;
       for (int w = 0; w < wave; ++w) before += wsum[w];
       dbase[threadIdx.x] += before;
+      id_start = dbase[threadIdx.x];
+      if (one_pass) {
+        // ref :270-273: a run of >= min_pts points whose cell lies in the box (the points that classify nowhere share
+        // the sentinel key g.ncells) is a leaf
+        if ((int)threadIdx.x < ndistinct && id_count >= min_pts) {
+          id_cell = idcell[threadIdx.x];
+          id_flag = id_cell < (uint32_t)g.ncells ? 1 : 0;
+        }
+        id_incl = wave_inclusive_scan(id_flag, lane);
+        if (lane == 63) wave_total[wave] = id_incl;
+      }
     }
     __syncthreads();
 #pragma unroll
@@ -1893,9 +1895,18 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __re
       if (r < R && wave * C + r * 64 + lane < m) {
         const uint32_t d = (key[r] >> shift) & digit_mask;
         const int o = dbase[d] + cnt[wave][d] + rank[r];
-        sid[o] = (unsigned short)key[r];
+        if (!one_pass) sid[o] = (unsigned short)key[r];   // (the leaf list lies where the sorted ids would)
         sidx[o] = idx[r];
       }
+    }
+    if (one_pass && threadIdx.x < SORT_BINS && id_flag) {
+      int li = id_incl - 1;
+      for (int w = 0; w < wave; ++w) li += wave_total[w];
+      BucketLeaf L;
+      L.cell = (int)id_cell;
+      L.start = (unsigned short)id_start;
+      L.cnt = (unsigned short)id_count;
+      leaves[li] = L;
     }
     __syncthreads();
     if (pass + 1 < npass) {
@@ -1907,8 +1918,13 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __re
       __syncthreads();
     }
   }
-  // ---- runs of equal id: thread t owns the 8 consecutive sorted positions [8 t, 8 t + 8) ------------
   NDT_BSTAMP(5, 3);  // sorted
+  int nl = 0;
+  if (one_pass) {
+    nl = wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3];
+    if (threadIdx.x == 0) s_base = nl > 0 ? atomicAdd(&d_nleaf[0], nl) : 0;
+  } else {
+  // ---- runs of equal id: thread t owns the 8 consecutive sorted positions [8 t, 8 t + 8) ------------
   const int ms = decline ? 0 : m;
   const int s0 = (int)threadIdx.x * BK_ROUNDS;
   uint32_t k[BK_ROUNDS];
@@ -1963,7 +1979,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __re
   int lincl = wave_inclusive_scan(nleaf, lane);
   if (lane == 63) wave_total[wave] = lincl;
   __syncthreads();
-  int nl = 0, li0 = lincl - nleaf;
+  int li0 = lincl - nleaf;
   for (int w = 0; w < BK_WAVES; ++w) {
     if (w < wave) li0 += wave_total[w];
     nl += wave_total[w];
@@ -1980,6 +1996,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __re
   // this block's leaf slots: the atomic's round trip runs under the first batch of sums
   if (threadIdx.x == 0) s_base = nl > 0 ? atomicAdd(&d_nleaf[0], nl) : 0;
   __syncthreads();   // leaf list complete (s_base is read behind the next barrier only)
+  }  // (general run search)
   NDT_BSTAMP(5, 4);  // runs found
   NDT_WSTAMP(0);
   // ---- per-voxel sums (ref :236-239), from LDS, in input order: 8 lanes per leaf, crowded leaves by the wave ----
@@ -2507,7 +2524,22 @@ hipError_t sort_cloud_fused(const float* x, const float* y, const float* z, size
 
 // ---- bucketed build (two launches) ----
 bool bucket_build_enabled() { return tuning().bucket_build != 0; }
-int bucket_build_tiles(size_t n) { return (int)((n + BK_MAXP - 1) / BK_MAXP); }
+// points per thread of the partition launch: the smallest tile of >= 2048 points that keeps the launch at <= BK_MAX_TILES tiles
+// (a 131 k-point scan: 64 tiles of 2048 points, the 1 M-point map: 245 tiles of 4096); ndt_tuning::bucket_tile forces a size that fits
+static int bucket_rounds_for(size_t n) {
+  const int forced = tuning().bucket_tile;
+  if (forced != 0 && (n + (size_t)forced - 1) / (size_t)forced <= (size_t)BK_MAX_TILES) return forced / BK_THREADS;
+  // (1024-point tiles are compiled and measured: C2's 131 k points, 128 tiles, 40.4 us against 38.8 with 64 tiles of 2048 --
+  // a bucket's segments of 4 points are half a cache line)
+  for (int r = 2; r < BK_ROUNDS; r *= 2)
+    if ((n + (size_t)(BK_THREADS * r) - 1) / (size_t)(BK_THREADS * r) <= (size_t)BK_MAX_TILES) return r;
+  return BK_ROUNDS;
+}
+int bucket_build_tiles(size_t n) {
+  const size_t tile = (size_t)BK_THREADS * bucket_rounds_for(n);
+  return (int)((n + tile - 1) / tile);
+}
+size_t bucket_table_words() { return (size_t)BK_BUCKETS * BK_MAX_TILES; }
 void bucket_bounds_neutral(int out[8]) {
   for (int k = 0; k < 3; ++k) { out[k] = INT_MAX; out[3 + k] = INT_MIN; }
   out[6] = 0;
@@ -2515,53 +2547,68 @@ void bucket_bounds_neutral(int out[8]) {
 }
 // The hash spreads voxels, not points: the largest bucket of a lidar map is ~1.6x the mean (crowded voxels
 // near the sensor), and a bucket must fit BK_MAXP points -- so clouds up to 256 * BK_MAXP / 1.6 points are
-// worth trying (a bucket that overflows anyway costs one refused launch pair, BG_BUCKET).  Every block of
-// the partition launch waits for every other: one tile per compute unit at most.
+// worth trying (a bucket that overflows anyway costs one declined launch pair, BG_BUCKET).  Neither launch waits
+// for sibling blocks (round 5), so the device's size does not matter.
 bool bucket_build_fits(size_t n, int compute_units) {
-  if (n == 0 || n > (size_t)BK_BUCKETS * BK_MAXP * 5 / 8) return false;
-  return bucket_build_tiles(n) <= (compute_units < FUSED_MAX_TILES ? compute_units : FUSED_MAX_TILES);
+  (void)compute_units;
+  return n != 0 && n <= (size_t)BK_BUCKETS * BK_MAXP * 5 / 8;
+}
+
+template <int ROUNDS>
+static void launch_bucket_pass(int tile0, int ntiles, hipStream_t s, const float* x, const float* y, const float* z, int n, float inv_leaf,
+                               uint32_t* tab, const LeafStats* old_stats, int dirty_slots, int* cell2leaf, size_t c2l_cap,
+                               int* bnd, int* d_nleaf, float4* pts4) {
+  hipLaunchKernelGGL(k_bucket_pass<ROUNDS>, dim3((unsigned)ntiles), dim3(BK_THREADS), 0, s, x, y, z, n, inv_leaf, tile0, tab, old_stats,
+                     dirty_slots, cell2leaf, c2l_cap, bnd, d_nleaf, pts4);
+}
+
+size_t bucket_tile_points(size_t n) { return (size_t)BK_THREADS * bucket_rounds_for(n); }
+
+hipError_t launch_bucket_pass_tiles(const float* x, const float* y, const float* z, size_t n, float inv_leaf, uint32_t* tab,
+                                    const LeafStats* old_stats, int dirty_slots, int* cell2leaf, size_t c2l_cap, int* bnd,
+                                    int* d_nleaf, float* pts4, int tile_first, int tile_end, hipStream_t s) {
+  if (n == 0 || !bucket_build_fits(n, 0) || tile_first < 0 || tile_end > bucket_build_tiles(n) || tile_end > BK_MAX_TILES)
+    return hipErrorInvalidValue;
+  if (tile_end <= tile_first) return hipSuccess;
+  float4* p4 = reinterpret_cast<float4*>(pts4);
+  const int nt = tile_end - tile_first;
+  const int dirty = tile_first == 0 ? dirty_slots : 0;   // the launch that holds tile 0 resets the previous build's cells
+  switch (bucket_rounds_for(n)) {
+    case 1: launch_bucket_pass<1>(tile_first, nt, s, x, y, z, (int)n, inv_leaf, tab, old_stats, dirty, cell2leaf, c2l_cap, bnd, d_nleaf, p4); break;
+    case 2: launch_bucket_pass<2>(tile_first, nt, s, x, y, z, (int)n, inv_leaf, tab, old_stats, dirty, cell2leaf, c2l_cap, bnd, d_nleaf, p4); break;
+    case 4: launch_bucket_pass<4>(tile_first, nt, s, x, y, z, (int)n, inv_leaf, tab, old_stats, dirty, cell2leaf, c2l_cap, bnd, d_nleaf, p4); break;
+    default: launch_bucket_pass<8>(tile_first, nt, s, x, y, z, (int)n, inv_leaf, tab, old_stats, dirty, cell2leaf, c2l_cap, bnd, d_nleaf, p4); break;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_bucket_leaves(size_t n, float leaf, float inv_leaf, long long cell_capacity, int min_pts, FinalizeParams fp,
+                                BuildGeom* gd, BuildGeom* gd_host, const uint32_t* tab, int* cell2leaf, int* bnd, int* d_nleaf,
+                                unsigned int* ticket, const float* pts4, double* sums, VoxelRecord* rec, float* cent4,
+                                LeafStats* stats, int max_leaves, int* nleaf_host, int done_tag, hipStream_t s) {
+  if (n == 0 || !bucket_build_fits(n, 0)) return hipErrorInvalidValue;
+  const int ntiles = bucket_build_tiles(n);
+  if (ntiles > BK_MAX_TILES) return hipErrorInvalidValue;
+  int tile_shift = 10;
+  while (((size_t)1 << tile_shift) < bucket_tile_points(n)) ++tile_shift;
+  hipLaunchKernelGGL(k_bucket_leaves, dim3(BK_BUCKETS), dim3(BK_THREADS), 0, s, reinterpret_cast<const float4*>(pts4),
+                     tab, ntiles, tile_shift, bnd, leaf, inv_leaf, cell_capacity, min_pts, fp, gd, gd_host, d_nleaf,
+                     reinterpret_cast<unsigned long long*>(ticket) /* 8-byte aligned, zero between builds */, sums,
+                     rec, reinterpret_cast<float4*>(cent4), stats, cell2leaf, max_leaves, nleaf_host, done_tag);
+  return hipGetLastError();
 }
 
 hipError_t launch_bucket_build(const float* x, const float* y, const float* z, size_t n, float leaf, float inv_leaf,
                                long long cell_capacity, int min_pts, FinalizeParams fp, BuildGeom* gd, BuildGeom* gd_host,
-                               uint32_t* table, uint32_t* seq, const LeafStats* old_stats, int dirty_slots, int* cell2leaf,
-                               size_t c2l_cap, int* bnd, int* bucket_off, int* d_nleaf, unsigned int* ticket, float* pts4,
+                               uint32_t* tab, const LeafStats* old_stats, int dirty_slots, int* cell2leaf,
+                               size_t c2l_cap, int* bnd, int* d_nleaf, unsigned int* ticket, float* pts4,
                                double* sums, VoxelRecord* rec, float* cent4, LeafStats* stats, int max_leaves, int* nleaf_host,
-                               int done_tag, hipStream_t s, int compute_units) {
-  if (n == 0) return hipErrorInvalidValue;
-  uint32_t tag = (*seq + 1u) & 0xffffu;
-  if (tag == 0u) {  // wrapped: forget every old tag before tag 1 is handed out again
-    hipError_t e = hipMemsetAsync(table, 0, fused_table_words() * sizeof(uint32_t), s);
-    if (e != hipSuccess) return e;
-    tag = 1u;
-  }
-  *seq = tag;
-#ifdef NDT_TEST_SEAMS
-  static const int mute_tile = [] { const char* e = getenv("NDT_DEBUG_FUSED_MUTE_TILE"); return e && *e ? atoi(e) : -1; }();
-#else
-  constexpr int mute_tile = -1;
-#endif
-  // ndt_tuning::bucket_tile = 4096 (A/B switch): 4096-point tiles when they all fit the machine at once -- 245 blocks instead of 123
-  // for 1 M points.  Measured in round 4: 23.5 us against 23.2 (profiles/r04_bucket_tile_ab.txt) -- the pass is a chain of
-  // cold-start latencies, not short of parallelism -- so 8192 stays.
-  const int tile_env = tuning().bucket_tile;
-  const int cap_tiles = compute_units < FUSED_MAX_TILES ? compute_units : FUSED_MAX_TILES;
-  const int small_tiles = (int)((n + 4095) / 4096);
-  if (tile_env == 4096 && small_tiles <= cap_tiles) {
-    hipLaunchKernelGGL(k_bucket_pass<4>, dim3((unsigned)small_tiles), dim3(BK_THREADS), 0, s, x, y, z, (int)n, inv_leaf, small_tiles,
-                       table, tag, mute_tile, gd, gd_host, old_stats, dirty_slots, cell2leaf, c2l_cap, bnd, bucket_off, d_nleaf,
-                       reinterpret_cast<float4*>(pts4));
-  } else {
-    const int ntiles = bucket_build_tiles(n);
-    hipLaunchKernelGGL(k_bucket_pass<BK_ROUNDS>, dim3((unsigned)ntiles), dim3(BK_THREADS), 0, s, x, y, z, (int)n, inv_leaf, ntiles,
-                       table, tag, mute_tile, gd, gd_host, old_stats, dirty_slots, cell2leaf, c2l_cap, bnd, bucket_off, d_nleaf,
-                       reinterpret_cast<float4*>(pts4));
-  }
-  hipLaunchKernelGGL(k_bucket_leaves, dim3(BK_BUCKETS), dim3(BK_THREADS), 0, s, reinterpret_cast<const float4*>(pts4),
-                     bucket_off, bnd, leaf, inv_leaf, cell_capacity, min_pts, fp, gd, gd_host, d_nleaf,
-                     reinterpret_cast<unsigned long long*>(ticket) /* 8-byte aligned, zero between builds */, sums,
-                     rec, reinterpret_cast<float4*>(cent4), stats, cell2leaf, max_leaves, nleaf_host, done_tag);
-  return hipGetLastError();
+                               int done_tag, hipStream_t s) {
+  hipError_t e = launch_bucket_pass_tiles(x, y, z, n, inv_leaf, tab, old_stats, dirty_slots, cell2leaf, c2l_cap, bnd, d_nleaf, pts4,
+                                          0, bucket_build_tiles(n), s);
+  if (e != hipSuccess) return e;
+  return launch_bucket_leaves(n, leaf, inv_leaf, cell_capacity, min_pts, fp, gd, gd_host, tab, cell2leaf, bnd, d_nleaf, ticket, pts4,
+                              sums, rec, cent4, stats, max_leaves, nleaf_host, done_tag, s);
 }
 
 int runs_blocks(size_t n) { return (int)((n + 256 * 8 - 1) / (256 * 8)); }

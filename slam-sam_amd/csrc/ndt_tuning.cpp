@@ -40,7 +40,7 @@ bool valid(const ndt_tuning& t) {
   if (t.deriv_single_level_max < 1) return false;
   if (t.deriv_xcd < 0 || t.deriv_xcd > 2) return false;
   if (!flag(t.bucket_build) || !flag(t.fused_sort)) return false;
-  if (t.bucket_tile != 0 && t.bucket_tile != 4096 && t.bucket_tile != 8192) return false;
+  if (t.bucket_tile != 0 && t.bucket_tile != 1024 && t.bucket_tile != 2048 && t.bucket_tile != 4096 && t.bucket_tile != 8192) return false;
   if (t.bounds_blocks < 1) return false;
   if (t.bounds_unroll != 4 && t.bounds_unroll != 8) return false;
   if (t.finalize_threads != 64 && t.finalize_threads != 256) return false;

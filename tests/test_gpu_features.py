@@ -455,16 +455,33 @@ def test_fused_sort_passes_equal_classic_passes_and_fall_back():
     its counts every block of the fused pass gives up after its time-out, the build is marked
     BG_SPIN, and the engine repeats it with the classic passes: same leaves, and the fallback is
     counted."""
-    fused = _leaf_dump({"NDT_FUSED_SORT": "1"})
-    classic = _leaf_dump({"NDT_FUSED_SORT": "0"})
+    # (the two-launch build is switched off: since round 5 it waits for no sibling block, so every build of this test
+    # takes the sort-based pipeline the seam sits in)
+    fused = _leaf_dump({"NDT_FUSED_SORT": "1", "NDT_BUCKET_BUILD": "0"})
+    classic = _leaf_dump({"NDT_FUSED_SORT": "0", "NDT_BUCKET_BUILD": "0"})
     assert fused[1] > 1000 and fused[2] == 0 and classic[2] == 0
     assert fused[:2] == classic[:2]
-    muted = _leaf_dump({"NDT_FUSED_SORT": "1", "NDT_DEBUG_FUSED_MUTE_TILE": "0", "NDT_HIP_LIB": SEAMS_LIB})
+    assert _leaf_dump({})[:2] == classic[:2]      # ... and the two-launch build gives the same leaves, bit for bit
+    muted = _leaf_dump({"NDT_FUSED_SORT": "1", "NDT_BUCKET_BUILD": "0", "NDT_DEBUG_FUSED_MUTE_TILE": "0", "NDT_HIP_LIB": SEAMS_LIB})
     # the production library carries no such seam: the variable changes nothing there
-    inert = _leaf_dump({"NDT_FUSED_SORT": "1", "NDT_DEBUG_FUSED_MUTE_TILE": "0"})
+    inert = _leaf_dump({"NDT_FUSED_SORT": "1", "NDT_BUCKET_BUILD": "0", "NDT_DEBUG_FUSED_MUTE_TILE": "0"})
     assert inert == fused
     assert muted[:2] == classic[:2]
     assert muted[2] == 3          # every one of the three builds fell back
+
+
+def test_two_launch_build_is_tile_size_independent():
+    """k_bucket_pass partitions the cloud tile by tile (round 5: a tile's window + the column table, no cloud-wide
+    offsets); k_bucket_leaves gathers a bucket's segments in tile order.  Whatever the tile size (1024 ... 8192 points:
+    128 ... 16 tiles for this scan, the last one ragged for none of them -- the 100 003-point cloud below has one),
+    the bucket holds the same points in input order: leaves and the aligned transform are bit-identical to the
+    sort-based pipeline's."""
+    ref = _leaf_dump({"NDT_BUCKET_BUILD": "0"})
+    assert ref[1] > 1000
+    for tile in ("1024", "2048", "4096", "8192"):
+        got = _leaf_dump({"NDT_BUCKET_TILE": tile})
+        assert got[:2] == ref[:2], tile
+        assert got[2] == 0
 
 
 def test_fused_build_launch_tags_wrap_around(pkg, hipmem):
