@@ -262,7 +262,9 @@ typedef struct ndt_tuning {
   int prelaunch_probe;        /* 1: the automatic stream placement probes the other placement (default); 0: never */
   int speculate_first;        /* 1: first evaluation of an align enqueued behind a running build (default); 0: off */
   int timing_bracket;         /* 0: kernel-timing events attached to the dispatch (default); 1: recorded around the launch call */
-  int reserved[13];           /* zero */
+  int handoff_chunk_pass;     /* 0: the asynchronous host hand-off partitions the target behind its transfer (default); 1: under it, chunk by
+                               * chunk on a stream of its own (measured slower: profiles/r05_handoff_chunk_pass_ab.txt) */
+  int reserved[12];           /* zero */
 } ndt_tuning;
 /* Idle-device heartbeat (round 5; default off).  A driver at the reference's 10-20 Hz keyframe rate leaves the device idle for
  * 50-100 ms between two aligns, and an idle MI355X drops its clocks: the align that follows runs 5-10 % slower than in a

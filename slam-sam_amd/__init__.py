@@ -132,7 +132,7 @@ class Tuning(C.Structure):
         "deriv_block", "deriv_summer", "deriv_dedicated", "deriv_single_level_max", "deriv_xcd", "bucket_build",
         "bucket_tile", "fused_sort", "bounds_blocks", "bounds_unroll", "finalize_threads", "build_events",
         "build_wait_sync", "mbox_tagged", "mbox_preload", "prelaunch_streams", "prelaunch_probe", "speculate_first",
-        "timing_bracket")] + [("reserved", C.c_int * 13)]
+        "timing_bracket", "handoff_chunk_pass")] + [("reserved", C.c_int * 12)]
 
 
 # the variables the tuning programs under tools/ (and bench.py's rehearsals) have always used, mapped onto ndt_tuning by
@@ -146,6 +146,7 @@ TUNING_ENV = {
     "NDT_MBOX_TAGGED": "mbox_tagged", "NDT_MBOX_PRELOAD": "mbox_preload",
     "NDT_PRELAUNCH_STREAMS": "prelaunch_streams", "NDT_PRELAUNCH_PROBE": "prelaunch_probe",
     "NDT_SPECULATE_FIRST": "speculate_first", "NDT_TIMING_BRACKET": "timing_bracket",
+    "NDT_HANDOFF_CHUNK_PASS": "handoff_chunk_pass",
 }
 
 
@@ -310,6 +311,8 @@ def lib():
         L.ndt_debug_prelaunch_counters.argtypes = [vp, C.POINTER(C.c_int64)]  # test seam, not in the header
         L.ndt_debug_build_counters.argtypes = [vp, C.POINTER(C.c_int64)]  # test seam, not in the header
         L.ndt_debug_speculation_counters.argtypes = [vp, C.POINTER(C.c_int64)]  # test seam, not in the header
+        if hasattr(L, "ndt_debug_handoff_counters"):   # (a library of an earlier round under NDT_HIP_LIB has none)
+            L.ndt_debug_handoff_counters.argtypes = [vp, C.POINTER(C.c_int64)]  # test seam, not in the header
         L.ndt_debug_set_speculation.argtypes = [vp, C.c_int]  # tuning aid, not in the header
         L.ndt_debug_sort_pairs.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, vp]  # test seam, not in the header
         _lib = L
@@ -848,6 +851,12 @@ class NormalDistributionsTransform:
         out = (C.c_int64 * 8)()
         self._check(lib().ndt_debug_prelaunch_counters(self._h, out))
         return int(out[4])
+
+    def handoffCounters(self):
+        """(host hand-offs of a target whose partition launch ran under the transfer, launches of tile ranges they made)."""
+        out = (C.c_int64 * 2)()
+        self._check(lib().ndt_debug_handoff_counters(self._h, out))
+        return int(out[0]), int(out[1])
 
     def buildCounters(self):
         """(builds that fell back from the fused sort passes to the classic ones, two-launch bucketed builds

@@ -136,6 +136,7 @@ struct ndt_handle {
   DevBuf<uint32_t> bucket_tab;        // two-launch build: where a tile holds a bucket's points, [bucket][tile] = {count : 16 | first : 16}
   DevBuf<int> bnd;                    // its 8 bounds words {min xyz, max xyz, #finite, largest bucket}; neutral between builds
   long long n_bucket_builds = 0, n_bucket_fallbacks = 0;
+  long long n_chunked_pass_builds = 0, n_chunked_pass_launches = 0;   // host hand-offs whose partition ran under the transfer
   int bucket_skip = 0, bucket_backoff = 0;  // builds to go before the two-launch build is tried again after a decline
   const float* vx = nullptr;          // the source as evaluated: the engine's own copy (sx/sy/sz) or,
   const float* vy = nullptr;          // after ndt_set_source_device_view, the caller's arrays
@@ -189,6 +190,8 @@ struct ndt_handle {
   };
   UploadLane lane_t, lane_s;
   hipStream_t ustream = nullptr;     // the source lane's stream (the target lane shares `stream` with the build)
+  hipStream_t pstream = nullptr;     // partition launches of a host target's build, beside the pull kernels on `stream` (created on first use)
+  std::vector<hipEvent_t> pass_ev;   // ... one event per chunk in flight + the join
   bool src_upload_pending = false;   // the engine's streams have not yet been ordered behind the source hand-off
   int handoff_mode = NDT_HANDOFF_ASYNC;
   // The voxel-grid build of an asynchronous hand-off: enqueued by ndt_set_target, its verdict collected by the first
@@ -209,6 +212,9 @@ struct ndt_handle {
     int attempt = 0;
     bool optimistic = false, bucketed = false;
     int done_tag = 0;
+    // the asynchronous host hand-off runs the two-launch build's partition under the transfer, chunk by chunk
+    bool pass_chunked = false;   // attempt 0 finds its partition enqueued already (every tile)
+    int pass_tiles = 0;          // tiles enqueued so far
   };
   BuildRun brun;
   bool build_pending = false;
@@ -324,7 +330,7 @@ bool params_valid(const ndt_params* p, std::string* why);
 int lane_wait(ndt_handle* h, ndt_handle::UploadLane& lane);
 int upload_soa(ndt_handle* h, ndt_handle::UploadLane& lane, hipStream_t stream, const float* xyz, const float* x,
                const float* y, const float* z, size_t n, size_t stride, DevBuf<float>& dx, DevBuf<float>& dy,
-               DevBuf<float>& dz, bool sync);
+               DevBuf<float>& dz, bool sync, const std::function<void(size_t /* points on the device so far */, bool /* last chunk */)>* after_chunk = nullptr);
 bool timing_brackets_launch();
 bool auto_probe_enabled();
 int pack_records(ndt_handle* h, bool wait);

@@ -149,6 +149,7 @@ int ndt_destroy(ndt_handle* h) {
   (void)hipSetDevice(h->device);
   settle_discard(h);
   if (h->ustream) (void)hipStreamSynchronize(h->ustream);
+  if (h->pstream) (void)hipStreamSynchronize(h->pstream);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->stream2) (void)hipStreamSynchronize(h->stream2);
   h->pool.reset();
@@ -182,6 +183,8 @@ int ndt_destroy(ndt_handle* h) {
   if (h->stream) (void)hipStreamDestroy(h->stream);
   if (h->stream2) (void)hipStreamDestroy(h->stream2);
   if (h->ustream) (void)hipStreamDestroy(h->ustream);
+  if (h->pstream) (void)hipStreamDestroy(h->pstream);
+  for (hipEvent_t e : h->pass_ev) (void)hipEventDestroy(e);
   h->arrive_ctr.release(); h->arrived.release();
   delete h;
   return NDT_OK;
@@ -377,6 +380,14 @@ int ndt_debug_build_counters(const ndt_handle* h, int64_t out[3]) {
   out[0] = h->n_fused_sort_fallbacks;
   out[1] = h->n_bucket_fallbacks;   // two-launch builds that were declined and repeated sort-based
   out[2] = h->n_bucket_builds;      // builds that went through in two launches
+  return NDT_OK;
+}
+
+// test seam (not in the public header): host hand-offs whose partition ran under the transfer {builds, launches of tile ranges}
+int ndt_debug_handoff_counters(const ndt_handle* h, int64_t out[2]) {
+  if (!h || !out) return NDT_ERR_INVALID_ARG;
+  out[0] = h->n_chunked_pass_builds;
+  out[1] = h->n_chunked_pass_launches;
   return NDT_OK;
 }
 

@@ -29,7 +29,7 @@ int lane_wait(ndt_handle* h, ndt_handle::UploadLane& lane) {
 
 int upload_soa(ndt_handle* h, ndt_handle::UploadLane& lane, hipStream_t stream, const float* xyz, const float* x,
                const float* y, const float* z, size_t n, size_t stride, DevBuf<float>& dx, DevBuf<float>& dy,
-               DevBuf<float>& dz, bool sync) {
+               DevBuf<float>& dz, bool sync, const std::function<void(size_t, bool)>* after_chunk) {
   const auto t_begin = std::chrono::steady_clock::now();
   int rc = lane_wait(h, lane);  // the previous hand-off's copies out of this lane's staging buffer
   if (rc) return rc;
@@ -61,6 +61,7 @@ int upload_soa(ndt_handle* h, ndt_handle::UploadLane& lane, hipStream_t stream, 
   const float* stage_dev = lane.stage.d;
   stage_cloud(h->pool.get(), workers, job, [&](size_t c, size_t lo, size_t hi) {
     launch_pull_chunk(stage_dev + 3 * lo, hi - lo, job.seg(c), dx.p + lo, dy.p + lo, dz.p + lo, stream);
+    if (after_chunk) (*after_chunk)(hi, hi >= n);
   });
   HIP_TRY(h, hipGetLastError());
   if (lane.timed) HIP_TRY(h, hipEventRecord(lane.t1, stream));
@@ -212,10 +213,18 @@ int build_enqueue(ndt_handle* h, ndt_handle::BuildRun& br) {
   if (br.bucketed) {
     // bounds, partition, sort, sums and statistics in two launches (k_bucket_pass, k_bucket_leaves)
     FinalizeParams fpb{h->prm.eig_inflation_ratio, h->prm.cov_mode};
-    HIP_TRY(h, launch_bucket_build(x, y, z, n, br.leaf, br.inv_leaf, cap_cells, min_pts, fpb, h->gd.p, h->gdh.d, h->bucket_tab.p,
-                                   h->stats.p, br.dirty_slots, h->cell2leaf.p, h->cell2leaf.cap, h->bnd.p,
-                                   h->nleaf.p, h->tickets.p + 4, h->xyz4.p, h->leaf_sums.p, h->rec.p,
-                                   h->cent.p, h->stats.p, max_leaves, h->small.d + 8, done_tag, s));
+    if (br.pass_chunked && br.attempt == 0 && br.pass_tiles == bucket_build_tiles(n)) {
+      // the partition ran under the transfer (chunked_pass_hook): only the leaves launch is left, and the build's clock
+      // starts here
+      br.t0 = std::chrono::steady_clock::now();
+      if (br.build_events) HIP_TRY(h, hipEventRecord(h->ev0, s));
+    } else {
+      HIP_TRY(h, launch_bucket_pass_tiles(x, y, z, n, br.inv_leaf, h->bucket_tab.p, h->stats.p, br.dirty_slots, h->cell2leaf.p,
+                                          h->cell2leaf.cap, h->bnd.p, h->nleaf.p, h->xyz4.p, 0, bucket_build_tiles(n), s));
+    }
+    HIP_TRY(h, launch_bucket_leaves(n, br.leaf, br.inv_leaf, cap_cells, min_pts, fpb, h->gd.p, h->gdh.d, h->bucket_tab.p,
+                                    h->cell2leaf.p, h->bnd.p, h->nleaf.p, h->tickets.p + 4, h->xyz4.p, h->leaf_sums.p, h->rec.p,
+                                    h->cent.p, h->stats.p, max_leaves, h->small.d + 8, done_tag, s));
   } else {
     launch_bounds_geometry(x, y, z, n, br.leaf, br.inv_leaf, cap_cells, passes, h->brows.p, h->tickets.p, h->gd.p, h->gdh.d,
                            optimistic ? h->stats.p : nullptr, optimistic ? br.dirty_slots : 0, h->cell2leaf.p,
@@ -385,6 +394,85 @@ int build_grid(ndt_handle* h, const float* x, const float* y, const float* z, si
   return build_complete(h, h->brun);
 }
 
+// The asynchronous hand-off of a HOST target.  ndt_tuning::handoff_chunk_pass = 1 (OFF by default): the
+// two-launch build's partition needs no grid geometry and no sibling tile (round 5), so it can run UNDER the transfer --
+// behind every chunk's pull kernel the tiles that chunk completes are partitioned while the next chunk crosses PCIe -- and
+// only k_bucket_leaves is left behind the last chunk.  Decided before the first chunk (build_begin knows everything but
+// the points); anything that is not a steady-state two-launch build goes the old way: transfer, then the whole build.  Same
+// kernels over the same tiles: the grid is bit-identical either way (tests/test_gpu_handoff.py).
+// MEASURED AND NOT THE DEFAULT (profiles/r05_handoff_chunk_pass_ab.txt, C3, alternating blocks of scans in one process): on
+// the pull kernels' stream every partition launch stands between two transfers (a 32-tile launch is a 10-14 us chain with
+// PCIe idle: 0.84 -> 0.92 ms per scan); on a stream of its own the two event hops around the last chunk's launch (pull ->
+// partition -> leaves, ~20 us each on this runtime) cost more than the 14 us of partition they hide (0.80 -> 0.84 ms).
+int build_grid_handoff(ndt_handle* h, const float* xyz, const float* x, const float* y, const float* z, size_t n, size_t stride) {
+  h->build_pending = false;
+  h->deferred_rc = 0;
+  h->ms_settle_wait = 0;
+  HIP_TRY(h, h->tx.ensure(n));
+  HIP_TRY(h, h->ty.ensure(n));
+  HIP_TRY(h, h->tz.ensure(n));
+  ndt_handle::BuildRun& br = h->brun;
+  int rc = build_begin(h, h->tx.p, h->ty.p, h->tz.p, n, br);
+  if (rc) return rc;
+  const bool steady = br.clean_cap != 0 && br.clean_cap == h->cell2leaf.cap;   // (build_enqueue's `optimistic`)
+  br.pass_chunked = br.bucketed_ok && steady && tuning().handoff_chunk_pass != 0;
+  br.pass_tiles = 0;
+  hipError_t hook_err = hipSuccess;
+  const size_t tile = br.pass_chunked ? bucket_tile_points(n) : 1;
+  const int ntiles = br.pass_chunked ? bucket_build_tiles(n) : 0;
+  // The partition launches go to a stream of their own, each behind its chunk's pull kernel by an event: on the pull
+  // kernels' stream they would stand between two transfers (measured: PCIe idle for every partition launch, the scan
+  // 0.84 -> 0.92 ms); the leaves launch joins them below.
+  size_t ev_used = 0;
+  if (br.pass_chunked && !h->pstream) HIP_TRY(h, hipStreamCreateWithFlags(&h->pstream, hipStreamNonBlocking));
+  const std::function<void(size_t, bool)> hook = [&](size_t have, bool last) {
+    const int upto = last ? ntiles : (int)(have / tile);
+    if (upto <= br.pass_tiles || hook_err != hipSuccess) return;
+    if (ev_used == h->pass_ev.size()) {
+      hipEvent_t e = nullptr;
+      if ((hook_err = hipEventCreateWithFlags(&e, hipEventDisableTiming)) != hipSuccess) return;
+      h->pass_ev.push_back(e);
+    }
+    hipEvent_t e = h->pass_ev[ev_used++];
+    if ((hook_err = hipEventRecord(e, h->stream)) != hipSuccess) return;
+    if ((hook_err = hipStreamWaitEvent(h->pstream, e, 0)) != hipSuccess) return;
+    hook_err = launch_bucket_pass_tiles(h->tx.p, h->ty.p, h->tz.p, n, br.inv_leaf, h->bucket_tab.p, h->stats.p, br.dirty_slots,
+                                        h->cell2leaf.p, h->cell2leaf.cap, h->bnd.p, h->nleaf.p, h->xyz4.p, br.pass_tiles, upto,
+                                        h->pstream);
+    br.pass_tiles = upto;
+    ++h->n_chunked_pass_launches;
+  };
+  rc = upload_soa(h, h->lane_t, h->stream, xyz, x, y, z, n, stride, h->tx, h->ty, h->tz, false, br.pass_chunked ? &hook : nullptr);
+  if (rc == NDT_OK && hook_err == hipSuccess && br.pass_tiles > 0) {   // the join: `stream` goes on behind the last partition launch
+    if (ev_used == h->pass_ev.size()) {
+      hipEvent_t e = nullptr;
+      if ((hook_err = hipEventCreateWithFlags(&e, hipEventDisableTiming)) == hipSuccess) h->pass_ev.push_back(e);
+    }
+    if (hook_err == hipSuccess) hook_err = hipEventRecord(h->pass_ev[ev_used], h->pstream);
+    if (hook_err == hipSuccess) hook_err = hipStreamWaitEvent(h->stream, h->pass_ev[ev_used], 0);
+  }
+  if (rc == NDT_OK && hook_err != hipSuccess) rc = fail(h, NDT_ERR_HIP, hipGetErrorString(hook_err));
+  if (rc) {
+    if (br.pass_tiles > 0) {   // (the tiles enqueued so far have folded their bounds into the words)
+      (void)hipStreamSynchronize(h->pstream);
+      (void)neutral_bounds(h);
+    }
+    return rc;
+  }
+  if (br.pass_chunked) ++h->n_chunked_pass_builds;
+  if (!br.pass_chunked) {   // the build's clock starts behind the transfer, as it does for build_grid
+    br.t0 = std::chrono::steady_clock::now();
+    if (br.build_events) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+  }
+  rc = build_enqueue(h, br);
+  if (rc) return rc;
+  if (br.optimistic) {
+    h->build_pending = true;
+    return NDT_OK;
+  }
+  return build_complete(h, br);
+}
+
 // Completes whatever an asynchronous hand-off left in flight that the caller is about to depend on: the pending
 // build's verdict (a failed build is reported HERE, by the first call that needs the grid), and the order of the
 // engine's streams behind the source lane.
@@ -459,6 +547,7 @@ int ndt_set_target(ndt_handle* h, const float* xyz, size_t n, size_t stride_byte
   if (rc) return rc;
   settle_discard(h);
   const bool async = h->handoff_mode == NDT_HANDOFF_ASYNC;
+  if (async && n > 0) return build_grid_handoff(h, xyz, nullptr, nullptr, nullptr, n, stride_bytes);
   rc = upload_soa(h, h->lane_t, h->stream, xyz, nullptr, nullptr, nullptr, n, stride_bytes, h->tx, h->ty, h->tz, !async);
   if (rc) return rc;
   return build_grid(h, h->tx.p, h->ty.p, h->tz.p, n, async);
@@ -470,6 +559,7 @@ int ndt_set_target_soa(ndt_handle* h, const float* x, const float* y, const floa
   if (rc) return rc;
   settle_discard(h);
   const bool async = h->handoff_mode == NDT_HANDOFF_ASYNC;
+  if (async && n > 0) return build_grid_handoff(h, nullptr, x, y, z, n, 0);
   rc = upload_soa(h, h->lane_t, h->stream, nullptr, x, y, z, n, 0, h->tx, h->ty, h->tz, !async);
   if (rc) return rc;
   return build_grid(h, h->tx.p, h->ty.p, h->tz.p, n, async);

@@ -1781,6 +1781,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __re
   }
   NDT_BSTAMP(5, 2);  // points in LDS, cells in the table
   __syncthreads();
+  NDT_BSTAMP(1, 0);  // table complete (barrier passed)
   // dense ids: exclusive scan of the table's occupancy (4 slots per thread)
   int ndistinct;
   {
@@ -1809,6 +1810,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __re
     }
     __syncthreads();
   }
+  NDT_BSTAMP(1, 1);  // dense ids written
   const bool decline = oversize || s_decline != 0 || ndistinct > BK_MAX_DISTINCT;   // uniform over the block
   uint32_t key[BK_ROUNDS];   // the dense id of the point's cell from here on
   unsigned short idx[BK_ROUNDS];
@@ -1819,6 +1821,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __re
     idx[r] = (unsigned short)p;
   }
   __syncthreads();   // table and ids are dead: region A becomes {sorted ids, digit counters}
+  NDT_BSTAMP(1, 2);  // ids fetched, region A free
   // ---- stable LSD radix sort of (dense id, position) in LDS: ceil(log2(ndistinct) / 8) passes ---------------
   int idbits = 1;
   while ((1 << idbits) < ndistinct) ++idbits;
@@ -1859,6 +1862,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __re
       }
     }
     __syncthreads();
+    NDT_BSTAMP(1, 3);  // ranked
     if (threadIdx.x < SORT_BINS) {
       int run = 0;
 #pragma unroll
@@ -1890,6 +1894,7 @@ __global__ void __launch_bounds__(BK_THREADS) k_bucket_leaves(const float4* __re
       }
     }
     __syncthreads();
+    NDT_BSTAMP(1, 4);  // digit bases known
 #pragma unroll
     for (int r = 0; r < BK_ROUNDS; ++r) {
       if (r < R && wave * C + r * 64 + lane < m) {

@@ -29,6 +29,7 @@ void tuning_defaults(ndt_tuning* t) {
   t->prelaunch_probe = 1;
   t->speculate_first = 1;
   t->timing_bracket = 0;
+  t->handoff_chunk_pass = 0;
 }
 
 namespace {
@@ -47,7 +48,7 @@ bool valid(const ndt_tuning& t) {
   if (t.build_events < -1 || t.build_events > 1) return false;
   if (!flag(t.build_wait_sync) || !flag(t.mbox_tagged) || !flag(t.mbox_preload)) return false;
   if (t.prelaunch_streams != 1 && t.prelaunch_streams != 2) return false;
-  if (!flag(t.prelaunch_probe) || !flag(t.speculate_first) || !flag(t.timing_bracket)) return false;
+  if (!flag(t.prelaunch_probe) || !flag(t.speculate_first) || !flag(t.timing_bracket) || !flag(t.handoff_chunk_pass)) return false;
   for (int v : t.reserved)
     if (v != 0) return false;
   return true;
@@ -88,6 +89,7 @@ void init_once() {
     env("NDT_PRELAUNCH_PROBE", &t.prelaunch_probe);
     env("NDT_SPECULATE_FIRST", &t.speculate_first);
     env("NDT_TIMING_BRACKET", &t.timing_bracket);
+    env("NDT_HANDOFF_CHUNK_PASS", &t.handoff_chunk_pass);
     if (valid(t)) g_tuning = t;
 #endif
   });

@@ -354,3 +354,48 @@ def test_first_evaluation_behind_a_build_that_is_refused_or_repeated(pkg, S):
             assert np.array_equal(a[1], b[1]) and a[2:] == b[2:]
         else:
             assert a[1] == b[1] == -4   # NDT_ERR_NO_TARGET
+
+
+def test_partition_under_the_transfer_builds_the_same_grid(pkg, S):
+    """Round 5: a steady-state asynchronous hand-off of a host target launches the two-launch
+    build's partition chunk by chunk behind the pull kernels (the partition needs neither the grid geometry nor a
+    sibling tile), so that only k_bucket_leaves is left behind the last chunk.  Same kernels over the same tiles: leaves,
+    transform, iteration count and score are bit-identical to the hand-off that partitions behind the transfer
+    (ndt_tuning::handoff_chunk_pass = 0) and to the blocking hand-off -- for clouds of several chunks, of one chunk, with
+    a ragged last tile, and for one the two-launch build declines (a crowded voxel: the sort-based build repeats it)."""
+    c3, c2 = S.config_c3(), S.config_c2()
+    rng = np.random.default_rng(3)
+    crowded = np.concatenate([c2["target"], (rng.uniform(0.0, 0.9, (9000, 3)) + np.float32(5.0)).astype(np.float32)])
+    clouds = [(c3["target"][:700001], c3["source"][:60000], c3["guess"], 0.5), (c2["target"], c2["source"], c2["guess"], 1.0),
+              (c2["target"][:5000], c2["source"][:4000], c2["guess"], 1.0), (crowded, c2["source"], c2["guess"], 1.0)]
+    before = pkg.get_tuning()
+    out = {}
+    try:
+        for variant in ("chunked", "behind", "sync"):
+            pkg.set_tuning(handoff_chunk_pass=0 if variant == "behind" else 1)
+            res = []
+            for tgt, src, guess, leaf in clouds:
+                ndt = _ndt(pkg, resolution=leaf)
+                ndt.setHandoffMode(pkg.HANDOFF_SYNC if variant == "sync" else pkg.HANDOFF_ASYNC)
+                for rep in range(3):   # (the first build of a handle waits for the geometry; the later ones are steady state)
+                    t = _xyzi(tgt)
+                    ndt.setInputTarget(t); t[:] = np.nan
+                    ndt.setInputSource(src)
+                    T = ndt.align(guess)
+                r = ndt.getResult()
+                res.append((ndt.getLeaves(), T.copy(), r["iterations"], r["score"], ndt.handoffCounters(), ndt.buildCounters()))
+            out[variant] = res
+    finally:
+        pkg.set_tuning(**before)
+    for k in range(len(clouds)):
+        a = out["chunked"][k]
+        for other in ("behind", "sync"):
+            b = out[other][k]
+            _leaves_equal(a[0], b[0])
+            assert np.array_equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3]
+            assert b[4] == (0, 0)
+    # two steady-state hand-offs per cloud ran their partition under the transfer; the 700 001-point cloud in several launches
+    assert out["chunked"][0][4][0] == 2 and out["chunked"][0][4][1] >= 2 * 3, out["chunked"][0][4]
+    assert out["chunked"][1][4][0] == 2 and out["chunked"][2][4][0] == 2
+    # the crowded cloud: its first steady-state build is declined (counted), the back-off then skips the two-launch build
+    assert out["chunked"][3][5][1] >= 1 and out["chunked"][3][4][0] >= 1

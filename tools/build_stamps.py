@@ -17,6 +17,7 @@ t = raw.reshape(6, 512, 8).astype(np.int64)
 n = len(cfg["target"])
 print("build counters (fused fallbacks, bucket fallbacks, bucketed builds):", ndt.buildCounters())
 names = {0: ["entry", "keys loaded", "ranked", "table read", "staged", "stores done"], 3: ["entry", "counted", "offset known", "emitted"],
+         1: ["table complete", "dense ids", "ids fetched", "ranked", "digit bases"],
          4: ["entry", "loaded+bounds", "ranked", "offsets", "staged", "stores done"],
          5: ["entry", "geometry", "points in", "sorted", "runs+slots", "sums", "statistics", "column"]}
 tile = next(t for t in (2048, 4096, 8192) if (n + t - 1) // t <= 256)   # bucket_rounds_for()
@@ -27,6 +28,13 @@ for slot, nb, label in ((0, (n + 8191) // 8192, "sort pass 0 (from points)"), (1
     b = t[slot, :min(nb, 512), :len(nm)]
     if b[:, 0].max() == 0:
         print("%s: not run" % label)
+        continue
+    if slot == 1 and t[5, :, 0].max() > 0:   # a bucketed build: the rows of sort pass 1 hold k_bucket_leaves' finer stamps
+        b = t[1, :256, :len(nm)]
+        rel = (b - t[5, :256, 0].min()) * 0.01
+        print("k_bucket_leaves, inside 'points in' -> 'sorted' (us since the first block's entry):")
+        for k, name in enumerate(nm):
+            print("  %-14s min %6.2f  median %6.2f  max %6.2f" % (name, rel[:, k].min(), np.median(rel[:, k]), rel[:, k].max()))
         continue
     rel = (b - b[:, 0].min()) * 0.01
     print("%s: %d blocks (us since the first block's entry)" % (label, nb))
