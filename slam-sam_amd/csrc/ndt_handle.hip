@@ -402,6 +402,18 @@ int ndt_debug_item_owners(int threads, unsigned int* owners, unsigned int* fin_w
   return NDT_OK;
 }
 
+// test seam (not in the public header): the two-launch build's partition plan for a cloud of n points --
+// {fits (0 / 1), points per tile, tiles, words of the column table}
+int ndt_debug_bucket_plan(size_t n, long long out[4]) {
+  if (!out) return NDT_ERR_INVALID_ARG;
+  const bool fits = bucket_build_fits(n, 0);
+  out[0] = fits ? 1 : 0;
+  out[1] = fits ? (long long)bucket_tile_points(n) : 0;
+  out[2] = fits ? bucket_build_tiles(n) : 0;
+  out[3] = (long long)bucket_table_words();
+  return NDT_OK;
+}
+
 // test seam (not in the public header): the voxel build's radix sort on caller-supplied keys;
 // vals_out receives the stable sorting permutation.  Host arrays.
 int ndt_debug_sort_pairs(ndt_handle* h, const uint32_t* keys, size_t n, int end_bit, uint32_t* keys_out,

@@ -371,3 +371,37 @@ def test_angle_tables_are_the_derivatives_of_the_rotation(pkg):
     b = -2.0 * np.log((-np.log(c1 * np.exp(-0.5) + c2) - d3) / a)
     assert abs(d1c.value - a) < 1e-15 and abs(d2c.value - b) < 1e-15
     assert L.ndt_gauss_constants(0.0, 0.55, C.byref(d1c), C.byref(d2c)) != 0
+
+
+def test_two_launch_build_partition_plan(pkg):
+    """Host logic of the two-launch target build (round 5: per-tile partition): the tile is the smallest of 2048 / 4096 /
+    8192 points that keeps the launch at <= 256 tiles -- the column table has 256 x 256 words and k_bucket_leaves scans a
+    column with 256 threads -- for every cloud the build accepts (<= 1 310 720 points); ndt_tuning::bucket_tile forces a
+    size where it fits.  No device needed."""
+    L = pkg.lib()
+    L.ndt_debug_bucket_plan.argtypes = [C.c_size_t, C.POINTER(C.c_longlong)]
+
+    def plan(n):
+        out = (C.c_longlong * 4)()
+        assert L.ndt_debug_bucket_plan(n, out) == 0
+        return tuple(out)
+
+    assert plan(0)[0] == 0 and plan(1310721)[0] == 0
+    for n, tile in ((1, 2048), (5000, 2048), (131072, 2048), (524288, 2048), (524289, 4096), (1000000, 4096),
+                    (1048576, 4096), (1048577, 8192), (1310720, 8192)):
+        fits, t, tiles, words = plan(n)
+        assert fits == 1 and t == tile and tiles == (n + tile - 1) // tile and tiles <= 256 and words == 256 * 256, (n, plan(n))
+    import random
+    rnd = random.Random(7)
+    for _ in range(2000):
+        n = rnd.randint(1, 1310720)
+        fits, t, tiles, _w = plan(n)
+        assert fits == 1 and t in (2048, 4096, 8192) and tiles == (n + t - 1) // t and tiles <= 256
+        assert t == 2048 or (n + t // 2 - 1) // (t // 2) > 256      # no smaller tile would have fitted
+    before = pkg.get_tuning()
+    try:
+        for forced, n, want in ((8192, 131072, 8192), (1024, 131072, 1024), (1024, 1000000, 4096), (4096, 50000, 4096)):
+            pkg.set_tuning(bucket_tile=forced)
+            assert plan(n)[1] == want, (forced, n, plan(n))
+    finally:
+        pkg.set_tuning(**before)

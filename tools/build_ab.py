@@ -24,8 +24,8 @@ SETS = [
     ("bucketed (2 launches), device time", {"NDT_BUILD_EVENTS": "1", "NDT_BUCKET_BUILD": "1"}),
 ] + ([("libndt_hip_base.so: bucketed, device time", {"NDT_BUILD_EVENTS": "1", "NDT_BUCKET_BUILD": "1", "NDT_HIP_LIB": os.path.join(ROOT, "slam-sam_amd", "libndt_hip_base.so")})]
      if os.path.exists(os.path.join(ROOT, "slam-sam_amd", "libndt_hip_base.so")) else []) + (
-    [("libndt_hip_ab.so: bucketed, device time", {"NDT_BUILD_EVENTS": "1", "NDT_BUCKET_BUILD": "1", "NDT_HIP_LIB": os.path.join(ROOT, "slam-sam_amd", "libndt_hip_ab.so")})]
-     if os.path.exists(os.path.join(ROOT, "slam-sam_amd", "libndt_hip_ab.so")) else []) + [
+    [("%s: bucketed, device time" % nm, {"NDT_BUILD_EVENTS": "1", "NDT_BUCKET_BUILD": "1", "NDT_HIP_LIB": os.path.join(ROOT, "slam-sam_amd", nm)})
+     for nm in ("libndt_hip_ab.so", "libndt_hip_prev.so") if os.path.exists(os.path.join(ROOT, "slam-sam_amd", nm))]) + [
     ("bucketed, 8192-point tiles, device time", {"NDT_BUILD_EVENTS": "1", "NDT_BUCKET_BUILD": "1", "NDT_BUCKET_TILE": "8192"}),
     ("bucketed, 2048-point tiles (where <= 256 tiles), device time", {"NDT_BUILD_EVENTS": "1", "NDT_BUCKET_BUILD": "1", "NDT_BUCKET_TILE": "2048"}),
     ("sort-based (8 launches), device time", {"NDT_BUILD_EVENTS": "1", "NDT_BUCKET_BUILD": "0"}),
