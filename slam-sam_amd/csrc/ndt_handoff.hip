@@ -294,18 +294,15 @@ int build_collect(ndt_handle* h, ndt_handle::BuildRun& br) {
     HIP_TRY(h, hipStreamSynchronize(s));
   }
   const BuildGeom& bg = *h->gdh.h;
-  if (br.bucketed && (bg.status == BG_BUCKET || bg.status == BG_SPIN)) {
-    // declined (a bucket beyond a block's LDS or table, huge coordinates) or gave up waiting for sibling
-    // blocks.  Once more, sort-based.  BG_SPIN: neither launch has written a leaf and the old cells are
-    // already reset; BG_BUCKET may come late (one bucket's table overflowed after others had published
-    // leaves): that retry does not trust the grid -- full clear, geometry awaited.
+  if (br.bucketed && bg.status == BG_BUCKET) {
+    // declined: huge coordinates (decided before anything was written), or a bucket beyond a block's LDS or hash table --
+    // found by that bucket's block after others had published leaves.  Once more, sort-based; the retry does not trust
+    // the grid: full clear, geometry awaited.  (Neither launch waits for a sibling block since round 5: no BG_SPIN here.)
     br.bucketed_ok = false;
     br.dirty_slots = 0;
-    if (bg.status == BG_BUCKET) {
-      br.clean_cap = 0;
-      h->bucket_backoff = std::min(64, std::max(8, 2 * h->bucket_backoff));
-      h->bucket_skip = h->bucket_backoff;
-    }
+    br.clean_cap = 0;
+    h->bucket_backoff = std::min(64, std::max(8, 2 * h->bucket_backoff));
+    h->bucket_skip = h->bucket_backoff;
     ++h->n_bucket_fallbacks;
     int rc = neutral_bounds(h);   // (the launch pair resets them itself on every path; belt and braces)
     return rc ? rc : 1;
