@@ -264,7 +264,9 @@ typedef struct ndt_tuning {
   int timing_bracket;         /* 0: kernel-timing events attached to the dispatch (default); 1: recorded around the launch call */
   int handoff_chunk_pass;     /* 0: the asynchronous host hand-off partitions the target behind its transfer (default); 1: under it, chunk by
                                * chunk on a stream of its own (measured slower: profiles/r05_handoff_chunk_pass_ab.txt) */
-  int reserved[12];           /* zero */
+  int deriv_summer_split;     /* 1: four summing blocks, one 128-byte line of every row each, where compute units are spare (default); 0: one;
+                               * 4 | 8: that many (A/B) */
+  int reserved[11];           /* zero */
 } ndt_tuning;
 /* Idle-device heartbeat (round 5; default off).  A driver at the reference's 10-20 Hz keyframe rate leaves the device idle for
  * 50-100 ms between two aligns, and an idle MI355X drops its clocks: the align that follows runs 5-10 % slower than in a

@@ -904,16 +904,22 @@ __device__ __forceinline__ double xchg_allsum(const XchgInfo* __restrict__ xi, u
   return s;
 }
 
+// WLOG / word0 (round 5, "split summing blocks"): the block adds the 1 << WLOG words from word0 on -- all 32 (WLOG = 5), or the
+// eight of ONE 128-byte line of every row (WLOG = 3), with eight lanes per column instead of 32.  The COLUMNS are the same
+// either way (blockDim / 32 of them, whatever WLOG), and so are the order of a column's additions, the pairing of the
+// columns and the tree over the pairs: a word's sum does not depend on which block, or how many lanes beside it, added it.
+template <int WLOG>
 __device__ __forceinline__ void sum_rows(__amdgpu_buffer_rsrc_t rows, unsigned int rows_off, int first, int end,
                                          unsigned long long seq, double (*lds_c)[EV_WORDS],
                                          __amdgpu_buffer_rsrc_t dst, unsigned int dst_off, bool dst_system,
                                          double* plain_dst, int* s_fail, const XchgInfo* __restrict__ xi = nullptr,
-                                         unsigned long long xround = 0ull) {
-  const int v = threadIdx.x & 31, c = threadIdx.x >> 5;
+                                         unsigned long long xround = 0ull, int word0 = 0) {
+  constexpr int W = 1 << WLOG;
   const int ncols = (int)blockDim.x >> 5;
+  const int v = (int)(threadIdx.x & (unsigned)(W - 1)) + word0, c = (int)(threadIdx.x >> WLOG);
   const unsigned int tag_lo = (unsigned int)seq, tag_hi = (unsigned int)(seq >> 32);
   double s = 0.0;
-  for (int b0 = first + c; b0 < end; b0 += SUM_BATCH * ncols) {
+  for (int b0 = first + c; c < ncols && b0 < end; b0 += SUM_BATCH * ncols) {
     u32x4 t[SUM_BATCH];
     // Slots that carry this launch's tag are kept; only the MISSING ones are requested again.  (Re-reading the whole
     // batch on every trip -- 241 rows x 32 slots = 123 KB per trip for the 200 k-point scan -- made a trip ~1.5 us,
@@ -968,29 +974,32 @@ __device__ __forceinline__ void sum_rows(__amdgpu_buffer_rsrc_t rows, unsigned i
   NDT_WSTAMP(6);
   // the two columns of a wave first (lanes v and v + 32 hold the same word), then the waves' sums as a fixed tree of
   // depth 4 -- a chain of up to 32 dependent LDS reads and adds stood here (0.6 us behind the last row, stamps of round 5)
-  s += __shfl_xor(s, 32);
-  if ((threadIdx.x & 32u) == 0) lds_c[c >> 1][v] = s;
+  s += __shfl_xor(s, W);   // (the neighbouring column: lanes v and v + 32 of a wave, or -- eight lanes per column -- v and v + 8)
+  if ((threadIdx.x & (unsigned)W) == 0 && c < ncols) lds_c[c >> 1][v] = s;
   __syncthreads();
   NDT_WSTAMP(7);
-  if (threadIdx.x < EV_WORDS) {
+  if (threadIdx.x < (unsigned)W) {
     const int nwv = ((int)blockDim.x + 63) >> 6;
     double q[MAX_WAVES];
 #pragma unroll
-    for (int k = 0; k < MAX_WAVES; ++k) q[k] = k < nwv ? lds_c[k][threadIdx.x] : 0.0;
+    for (int k = 0; k < MAX_WAVES; ++k) q[k] = k < nwv ? lds_c[k][v] : 0.0;
 #pragma unroll
     for (int w = 1; w < MAX_WAVES; w <<= 1)
 #pragma unroll
       for (int k = 0; k + w < MAX_WAVES; k += 2 * w) q[k] += q[k + w];
     double t = q[0];
-    if (threadIdx.x == EV_WORDS - 1 && *s_fail) t += 1.0;
-    if (xi != nullptr && !*s_fail) {
+    if (v == EV_WORDS - 1 && *s_fail) t += 1.0;
+    // (a block that adds a part of the words and gave up waiting cannot raise word 31 unless it is its own: its words
+    // go out as NaN, which the host reads as a lost row -- evaluate() in ndt_evaluate.hip)
+    if (W < EV_WORDS && v != EV_WORDS - 1 && *s_fail) t = __longlong_as_double(0x7ff8000000000000ll);
+    if (W == EV_WORDS && xi != nullptr && !*s_fail) {
       // (a local sum that missed rows is NOT published: the host re-evaluates, peers wait for that)
       bool late = false;
-      t = xchg_allsum(xi, xround, (int)threadIdx.x, t, &late);
-      if (__ballot(late) != 0ull && threadIdx.x == EV_WORDS - 1) t = 3.0;
+      t = xchg_allsum(xi, xround, v, t, &late);
+      if (__ballot(late) != 0ull && v == EV_WORDS - 1) t = 3.0;
     }
-    if (plain_dst) plain_dst[threadIdx.x] = t;
-    else store_slot(dst, dst_off + threadIdx.x * 16u, seq, t, dst_system);
+    if (plain_dst) plain_dst[v] = t;
+    else store_slot(dst, dst_off + (unsigned int)v * 16u, seq, t, dst_system);
   }
   NDT_WSTAMP(8);
 }
@@ -1052,7 +1061,7 @@ __device__ __forceinline__ void block_reduce_finish(double (*lds_w)[EV_WORDS] /*
     if (threadIdx.x == 0) s_last = ticket_is_last(counters + 1 + grp, (unsigned int)(end - first));
     __syncthreads();
     if (!s_last) return;
-    sum_rows(rrows, 0u, first, end, seq, lds_c, rgroups, (unsigned int)grp * EV_WORDS * 16u, false, nullptr, &s_fail);
+    sum_rows<5>(rrows, 0u, first, end, seq, lds_c, rgroups, (unsigned int)grp * EV_WORDS * 16u, false, nullptr, &s_fail);
     __syncthreads();
   }
   const bool two_level = nb > single_level_max;
@@ -1071,8 +1080,8 @@ __device__ __forceinline__ void block_reduce_finish(double (*lds_w)[EV_WORDS] /*
     __syncthreads();
     if (!s_last) return;
   }
-  sum_rows(two_level ? rgroups : rrows, 0u, 0, nrows, seq, lds_c, slots_rsrc(host_slots), 0u, true,
-           host_slots ? nullptr : out, &s_fail, xi, xround);
+  sum_rows<5>(two_level ? rgroups : rrows, 0u, 0, nrows, seq, lds_c, slots_rsrc(host_slots), 0u, true,
+              host_slots ? nullptr : out, &s_fail, xi, xround);
   NDT_STAMP(6);
   if (threadIdx.x <= ngroups && !(fixed_summer && !two_level))  // leave the tickets at zero for the next launch
     __hip_atomic_store(counters + threadIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1084,9 +1093,12 @@ __device__ __forceinline__ void block_reduce_finish(double (*lds_w)[EV_WORDS] /*
 // that row is still to be fetched -- where a computing block that doubles as the summer first finishes its own
 // points and then pays a whole memory round trip for all the rows (2.6 us behind the last row for the 200 k-point
 // scan, profiles/r03_stamps_prelaunch.txt).  One spare compute unit (the scan's grid is 241 of 256).
+// Round 5: SEVERAL summing blocks (EvalConsts::dedicated_summer = SUMMER_SPLIT).  Each polls ONE 128-byte line -- eight
+// words -- of every row and writes its eight result slots itself.  Same columns, same order, same tree per word
+// (sum_rows): the bits do not change.
 __device__ __forceinline__ void summer_finish(double* __restrict__ rows, double* __restrict__ out,
                                               unsigned long long* host_slots, unsigned long long seq, int nrows,
-                                              const XchgInfo* __restrict__ xi, unsigned long long xround) {
+                                              const XchgInfo* __restrict__ xi, unsigned long long xround, int nsummers) {
   extern __shared__ int lds_dyn[];   // (the summing block has no regions)
   double (*lds_c)[EV_WORDS] = reinterpret_cast<double (*)[EV_WORDS]>(lds_dyn);
   __shared__ int s_fail;
@@ -1094,8 +1106,15 @@ __device__ __forceinline__ void summer_finish(double* __restrict__ rows, double*
   __syncthreads();
   NDT_STAMP(5);
   NDT_WSTAMP(5);
-  sum_rows(slots_rsrc(rows), 0u, 0, nrows, seq, lds_c, slots_rsrc(host_slots), 0u, true, host_slots ? nullptr : out, &s_fail,
-           xi, xround);
+  if (nsummers == 4)
+    sum_rows<3>(slots_rsrc(rows), 0u, 0, nrows, seq, lds_c, slots_rsrc(host_slots), 0u, true, host_slots ? nullptr : out, &s_fail,
+                nullptr, 0ull, (EV_WORDS / 4) * (int)blockIdx.x);
+  else if (nsummers == 8)
+    sum_rows<2>(slots_rsrc(rows), 0u, 0, nrows, seq, lds_c, slots_rsrc(host_slots), 0u, true, host_slots ? nullptr : out, &s_fail,
+                nullptr, 0ull, (EV_WORDS / 8) * (int)blockIdx.x);
+  else
+    sum_rows<5>(slots_rsrc(rows), 0u, 0, nrows, seq, lds_c, slots_rsrc(host_slots), 0u, true, host_slots ? nullptr : out, &s_fail,
+                xi, xround);
   NDT_STAMP(6);
   NDT_STAMP(7);
 #ifdef NDT_STAMPS
@@ -1185,7 +1204,7 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
   // exactly one source point per thread: the 32 accumulator words are only live from the
   // per-point expansion to the block reduction, not across the pair loop
   // (with a dedicated summing block the points start at block 1; block 0's threads own none)
-  const bool summing_block = ec.dedicated_summer != 0 && blockIdx.x == 0;
+  const bool summing_block = (int)blockIdx.x < ec.dedicated_summer;   // (0, 1, 4 or 8 of them, in front of the point blocks)
   // (position among the row's point blocks; the XCD of position 0 follows from the block's LINEAR workgroup id;
   // xcd_chunk: ndt_device.h)
   const int pos = (int)blockIdx.x - ec.dedicated_summer, npos = (int)gridDim.x - ec.dedicated_summer;
@@ -1271,8 +1290,18 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
     if (go <= 0) {
       // quit: nothing to do.  timed out: say so in the result slots (word 31 = 2), the host
       // evaluates this pose through an ordinary launch instead
-      if (go < 0 && blockIdx.x == 0 && threadIdx.x < EV_WORDS && flag != nullptr)
-        store_slot(slots_rsrc(flag), threadIdx.x * 16u, seq, threadIdx.x == EV_FAIL ? 2.0 : 0.0, true);
+      if (go < 0 && flag != nullptr) {
+        if (ec.dedicated_summer <= 1) {
+          if (blockIdx.x == 0 && threadIdx.x < EV_WORDS)
+            store_slot(slots_rsrc(flag), threadIdx.x * 16u, seq, threadIdx.x == EV_FAIL ? 2.0 : 0.0, true);
+        } else if (summing_block && (int)threadIdx.x < EV_WORDS / ec.dedicated_summer) {
+          // every summing block says so in its OWN slots: word 31's owner raises it, the others' words go out as NaN
+          // (which the host reads as "nothing usable": should a sibling have caught the pose and published, the
+          // evaluation is still repeated)
+          const unsigned int w = (unsigned int)(EV_WORDS / ec.dedicated_summer) * blockIdx.x + threadIdx.x;
+          store_slot(slots_rsrc(flag), w * 16u, seq, w == (unsigned int)EV_FAIL ? 2.0 : __longlong_as_double(0x7ff8000000000000ll), true);
+        }
+      }
       return;
     }
     if (!ec.mbox_tagged) {
@@ -1307,7 +1336,8 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
   if (summing_block) {   // uniform
     double* sbase = partials + (size_t)blockIdx.y * (gridDim.x + NGROUPS) * ROW_WORDS;
     summer_finish(sbase + (size_t)NGROUPS * ROW_WORDS, out + (size_t)blockIdx.y * EV_WORDS,
-                  flag ? flag + (size_t)blockIdx.y * ROW_WORDS : nullptr, seq, (int)gridDim.x - 1, BATCH ? nullptr : xinfo, xround);
+                  flag ? flag + (size_t)blockIdx.y * ROW_WORDS : nullptr, seq, (int)gridDim.x - ec.dedicated_summer,
+                  BATCH ? nullptr : xinfo, xround, ec.dedicated_summer);
     return;
   }
   PairAcc a;
@@ -1529,6 +1559,12 @@ static int derivs_dedicated_summer(size_t n_src, int K, int cus) {
   if (!deriv_dedicated_enabled() || deriv_fixed_summer() == 0) return 0;
   const int pb = derivs_point_blocks(n_src, K, cus);
   if (pb > deriv_single_level_max()) return 0;
+  // SUMMER_SPLIT of them where the point blocks leave that many compute units (the 200 k-point scan: 241 + 4 of 256),
+  // single-pose launches only: each polls one 128-byte line of every row (summer_finish)
+  {
+    const int want = tuning().deriv_summer_split == 1 ? SUMMER_SPLIT : tuning().deriv_summer_split;   // (4 | 8: A/B)
+    if (K == 1 && want > 1 && pb + want <= cus_or_default(cus)) return want;
+  }
   // The summing block needs a compute unit of its own.  A single-pose grid whose point blocks fill the machine EXACTLY
   // -- 256 blocks of 512 threads: a 128 x 1024 Ouster scan, the size of C2 and of every C5 frame -- would push one
   // compute unit to two point blocks (4 waves per SIMD instead of 2), and the launch waits for that unit: 15.5 us against
@@ -1601,6 +1637,10 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
   ecl.single_level_max = deriv_single_level_max();
   ecl.fixed_summer = deriv_fixed_summer();
   ecl.dedicated_summer = derivs_dedicated_summer(n_src, d_poses ? K : 1, cus);
+  if (ecl.dedicated_summer > 1 && d_xinfo != nullptr) {   // the in-kernel cross-rank exchange is one block's (xchg_allsum)
+    blocks -= ecl.dedicated_summer - 1;
+    ecl.dedicated_summer = 1;
+  }
   if (ec.safe_sum) {
     // Same rows in the same order, added by the block that draws the last ticket: by then every row has been issued,
     // so nothing in the launch waits for a block that is not resident (a device shared with other processes).

@@ -110,6 +110,8 @@ __host__ __device__ inline unsigned int mbox_tag32(unsigned long long seq) { ret
 constexpr unsigned long long MBOX_QUIT = 1ull << 63;
 constexpr unsigned long long MBOX_TIMEOUT_TICKS = 2000000ull;  // 20 ms of the 100 MHz s_memrealtime clock
 
+constexpr int SUMMER_SPLIT = 4;   // summing blocks of a single-pose launch where compute units are spare (k_derivatives)
+
 struct EvalConsts {
   double d1, d2;   // Gauss constants (ref: svn_ndt_impl.hpp:80-131)
   int direct7;     // 1: centre + 6 face neighbours, 0: centre only (ignored in KDTREE mode)
@@ -121,7 +123,8 @@ struct EvalConsts {
   int direct26;    // 1: every valid voxel of the 3x3x3 block around the point's cell (pclomp DIRECT26)
   int score_only;  // 1: score / NVTL / counts only, no gradient or Hessian (ndt_score_transform)
   int fixed_summer;  // 1: block 0 adds the partial rows (polls their tags), no tickets (single-level grids)
-  int dedicated_summer;  // 1: block 0 of the grid owns no points: it only adds the rows (one extra block per pose)
+  int dedicated_summer;  // n > 0: blocks 0 .. n - 1 of the grid own no points: they only add the rows -- 1 (all 32 words), or
+                         // SUMMER_SPLIT (eight words = one 128-byte line of every row each; single-pose launches)
   int mbox_tagged;  // pre-launched kernels: 1 = the pose arrives as tagged 8-byte granules, 0 = words then sequence number
   int mbox_preload; // pre-launched kernels: 1 = the point is fetched before the wait for the pose
   int multigrid;   // 1: the table is a union of grids (radius search, leaves of a cell chained through VoxelRecord::pad)

@@ -499,7 +499,12 @@ int evaluate(ndt_handle* h, const double p[6], const float T[16], bool need_h, E
   }
   // word 31 is zero by construction; the in-kernel final sum raises it when it gave up waiting
   // for a partial row (a lost hand-off must not look like a converged result), and the kernel
-  // never produces a non-finite score from finite records
+  // never produces a non-finite score from finite records.  With several summing blocks (SUMMER_SPLIT) only one of them
+  // owns word 31: the others say "gave up" by publishing their words as NaN -- read here as a lost row, AFTER the
+  // cross-rank sum (a NaN goes through it: every rank sees it and repeats the evaluation).
+  if (words[EV_FAIL] == 0.0)
+    for (int v = 0; v < EV_WORDS; ++v)
+      if (std::isnan(words[v])) { words[EV_FAIL] = 1.0; break; }
   if (words[EV_FAIL] == 2.0 && via_mailbox) {
     // the pre-launched kernel gave up waiting for its pose (this thread was away for > 20 ms):
     // nothing was evaluated.  Evaluate the ordinary way, and stop pre-launching for this align.

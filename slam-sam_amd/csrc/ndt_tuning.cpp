@@ -30,6 +30,7 @@ void tuning_defaults(ndt_tuning* t) {
   t->speculate_first = 1;
   t->timing_bracket = 0;
   t->handoff_chunk_pass = 0;
+  t->deriv_summer_split = 1;
 }
 
 namespace {
@@ -49,6 +50,7 @@ bool valid(const ndt_tuning& t) {
   if (!flag(t.build_wait_sync) || !flag(t.mbox_tagged) || !flag(t.mbox_preload)) return false;
   if (t.prelaunch_streams != 1 && t.prelaunch_streams != 2) return false;
   if (!flag(t.prelaunch_probe) || !flag(t.speculate_first) || !flag(t.timing_bracket) || !flag(t.handoff_chunk_pass)) return false;
+  if (t.deriv_summer_split != 0 && t.deriv_summer_split != 1 && t.deriv_summer_split != 4 && t.deriv_summer_split != 8) return false;
   for (int v : t.reserved)
     if (v != 0) return false;
   return true;
@@ -90,6 +92,7 @@ void init_once() {
     env("NDT_SPECULATE_FIRST", &t.speculate_first);
     env("NDT_TIMING_BRACKET", &t.timing_bracket);
     env("NDT_HANDOFF_CHUNK_PASS", &t.handoff_chunk_pass);
+    env("NDT_DERIV_SUMMER_SPLIT", &t.deriv_summer_split);
     if (valid(t)) g_tuning = t;
 #endif
   });

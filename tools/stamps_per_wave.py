@@ -24,7 +24,8 @@ L.ndt_debug_read_wave_stamps.argtypes = [C.c_void_p, C.c_int]
 L.ndt_debug_read_wave_stamps.restype = C.c_int
 n = len(cfg["source"])
 bt = int(os.environ.get("NDT_DERIV_BLOCK", "0")) or (((n + 254) // 255 + 63) // 64) * 64
-ded = 0 if os.environ.get("NDT_DERIV_DEDICATED") == "0" else 1
+split = int(os.environ.get("NDT_DERIV_SUMMER_SPLIT", "1"))
+ded = 0 if os.environ.get("NDT_DERIV_DEDICATED") == "0" else (1 if split == 0 else (4 if split == 1 else split))   # summing blocks in front of the point blocks
 nb = (n + bt - 1) // bt + ded
 nwv = bt // 64
 
@@ -105,14 +106,18 @@ def report(title, t, hw, trips, t0):
     fw = [q + 4 * (((nwv - q + 3) // 4) - 1) if (nwv >= 4 and (nwv - q + 3) // 4 > pmin) else q for q in range(min(4, nwv))]
     for k in (2, 4, 5):
         print("    finishing waves %-46s %s" % (NAMES[k], "  ".join("w%d %.2f" % (w, np.median(rel[:, w, k])) for w in fw)))
+    for sb in range(ded):
+        live = t[sb, :nwv, 6] > 0       # (a block that adds a quarter of the words uses a quarter of its waves)
+        sm = (t[sb, :nwv, :] - t0[0]) * 0.01
+        print("  summing block %d: polling from %.2f | a wave has all its slots: first %.2f last %.2f | barrier passed %.2f | result issued %.2f | acknowledged (wave 0) %.2f"
+              % (sb, np.min(sm[live, 5]), np.min(sm[live, 6]), np.max(sm[live, 6]), np.max(sm[:, 7]), sm[0, 8], sm[0, 9]))
     if ded:
         sm = (t[0, :nwv, :] - t0[0]) * 0.01
-        print("  summing block: polling from %.2f | a wave has all its slots: first %.2f last %.2f | barrier passed %.2f | result issued %.2f | acknowledged (wave 0) %.2f"
-              % (np.min(sm[:, 5]), np.min(sm[:, 6]), np.max(sm[:, 6]), np.max(sm[:, 7]), sm[0, 8], sm[0, 9]))
+        live = t[0, :nwv, 6] > 0
         ntr = int(trips[2 * WS_TRIPS])
         tr = [((trips[2 * i] - t0[0]) * 0.01, int(trips[2 * i + 1])) for i in range(min(ntr, WS_TRIPS))]
         print("  summing block, wave 0: %d poll trips; (us, lanes still missing a slot): %s" % (ntr, " ".join("(%.2f,%d)" % x for x in tr[-12:])))
-        print("  last row acknowledged %.2f -> summing wave complete %.2f -> result issued %.2f" % (np.nanmax(acked), np.max(sm[:, 6]), sm[0, 8]))
+        print("  last row acknowledged %.2f -> summing wave complete (block 0) %.2f -> result issued %.2f" % (np.nanmax(acked), np.max(sm[live, 6]), sm[0, 8]))
 
 
 # --- ordinary launches at the converged pose ---------------------------------------------------------------------
