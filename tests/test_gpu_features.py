@@ -273,6 +273,37 @@ def test_prelaunched_evaluations_change_no_number(pkg, S):
     assert used1 == n_ev - 3 and quit1 == 3
 
 
+def test_split_summing_blocks_change_no_bit(pkg, S):
+    """Round 5: where compute units are spare a single-pose launch has FOUR summing blocks in front of its point blocks,
+    each polling one 128-byte line (eight words) of every row and publishing those words itself (ndt_tuning::
+    deriv_summer_split; eight blocks of four words as an A/B).  Columns, order of additions, pairing and tree of a word
+    are the one summing block's: the evaluation, the aligned transform and the Hessian are the same BITS with one, four
+    or eight of them, through ordinary and pre-launched launches."""
+    cfg = S.config_c3()
+    src = cfg["source"][:150000]            # 181 point blocks of 832 threads: 4 or 8 more fit the 256 compute units
+    before = pkg.get_tuning()
+    res = {}
+    try:
+        for split in (0, 1, 8):
+            pkg.set_tuning(deriv_summer_split=split)
+            ndt = _ndt(pkg, resolution=0.5)
+            ndt.setInputTarget(cfg["target"])
+            ndt.setInputSource(src)
+            T = ndt.align(cfg["guess"])
+            r = ndt.getResult()
+            e = ndt.evalDerivatives(r["pose"])[0]
+            res[split] = (T.copy(), r["hessian"].copy(), r["iterations"], r["n_evaluations"], r["score"], e["score"], e["gradient"].copy(),
+                          e["hessian"].copy(), ndt.prelaunchCounters()[2])
+            ndt.close()
+    finally:
+        pkg.set_tuning(**before)
+    for split in (1, 8):
+        a, b = res[0], res[split]
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:6] == b[2:6], split
+        assert np.array_equal(a[6], b[6]) and np.array_equal(a[7], b[7]), split
+        assert b[8] == 0
+
+
 def test_prelaunched_kernel_that_times_out_falls_back(pkg, S):
     """A pre-launched kernel that waited 20 ms for its pose gives up; the host sees it (word 31 of
     the result = 2), stops pre-launching on that handle and evaluates the pose through an ordinary
