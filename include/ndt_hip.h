@@ -266,7 +266,9 @@ typedef struct ndt_tuning {
                                * chunk on a stream of its own (measured slower: profiles/r05_handoff_chunk_pass_ab.txt) */
   int deriv_summer_split;     /* 1: four summing blocks, one 128-byte line of every row each, where compute units are spare (default); 0: one;
                                * 4 | 8: that many (A/B) */
-  int reserved[11];           /* zero */
+  int deriv_one_block_per_cu; /* 1: a single-pose launch of at most one block per compute unit asks for more than half a unit's LDS, so that no
+                               * two of its blocks share a unit (default); 0: blocks of <= 8 waves may */
+  int reserved[10];           /* zero */
 } ndt_tuning;
 /* Idle-device heartbeat (round 5; default off).  A driver at the reference's 10-20 Hz keyframe rate leaves the device idle for
  * 50-100 ms between two aligns, and an idle MI355X drops its clocks: the align that follows runs 5-10 % slower than in a

@@ -132,7 +132,7 @@ class Tuning(C.Structure):
         "deriv_block", "deriv_summer", "deriv_dedicated", "deriv_single_level_max", "deriv_xcd", "bucket_build",
         "bucket_tile", "fused_sort", "bounds_blocks", "bounds_unroll", "finalize_threads", "build_events",
         "build_wait_sync", "mbox_tagged", "mbox_preload", "prelaunch_streams", "prelaunch_probe", "speculate_first",
-        "timing_bracket", "handoff_chunk_pass", "deriv_summer_split")] + [("reserved", C.c_int * 11)]
+        "timing_bracket", "handoff_chunk_pass", "deriv_summer_split", "deriv_one_block_per_cu")] + [("reserved", C.c_int * 10)]
 
 
 # the variables the tuning programs under tools/ (and bench.py's rehearsals) have always used, mapped onto ndt_tuning by
@@ -147,6 +147,7 @@ TUNING_ENV = {
     "NDT_PRELAUNCH_STREAMS": "prelaunch_streams", "NDT_PRELAUNCH_PROBE": "prelaunch_probe",
     "NDT_SPECULATE_FIRST": "speculate_first", "NDT_TIMING_BRACKET": "timing_bracket",
     "NDT_HANDOFF_CHUNK_PASS": "handoff_chunk_pass", "NDT_DERIV_SUMMER_SPLIT": "deriv_summer_split",
+    "NDT_DERIV_ONE_BLOCK_PER_CU": "deriv_one_block_per_cu",
 }
 
 

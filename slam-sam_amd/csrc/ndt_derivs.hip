@@ -1677,7 +1677,15 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
   derivs_item_owners(threads, &ecl.item_owner, &ecl.fin_waves, &ecl.lone_wave);
   // one LDS region per wave: the 27-cell modes' candidate list, then the wave's hand-over to the finishing waves
   // (the summing stage's 4 KB of scratch lie over them)
-  const size_t dyn_lds = std::max<size_t>((size_t)(threads / 64) * (size_t)wave_region_bytes(nb >= 2 && nb <= 4), (size_t)MAX_WAVES * EV_WORDS * sizeof(double));
+  size_t dyn_lds = std::max<size_t>((size_t)(threads / 64) * (size_t)wave_region_bytes(nb >= 2 && nb <= 4), (size_t)MAX_WAVES * EV_WORDS * sizeof(double));
+  // ONE block of a single-pose launch per compute unit.  Two 8-wave blocks fit a unit, and the hardware deals workgroups to the
+  // shader engines in turn whatever the engines' number of (harvested) compute units: of the 256 blocks of a 128 x 1024 scan two
+  // landed beside a sibling on every box stamped, took twice as long, and the evaluation waited 2.7 us for their rows
+  // (tools/stamps_prelaunch.py, profiles/r05_c2_stragglers.txt).  A block that asks for more than half a unit's LDS has the unit to
+  // itself; the kernel pre-launched for the next evaluation then moves in as this one's blocks leave, as it always has for the
+  // 13-wave blocks of the 200 k-point scan.
+  if (!d_poses && ec.own_units && d_xinfo == nullptr && tuning().deriv_one_block_per_cu != 0 && blocks <= cus && dyn_lds <= (size_t)80 * 1024)
+    dyn_lds = (size_t)80 * 1024 + 512;
   // ev_start / ev_stop: events attached to THIS dispatch (hipExtLaunchKernel): they carry the kernel's own begin and
   // end timestamps, what rocprofv3 reports -- events recorded around the launch include ~2.4 us of dispatch
 #define NDT_LAUNCH2(B, M, NBH, MB, GY, FLAG, SEQ)                                                            \

@@ -132,6 +132,7 @@ struct EvalConsts {
   int xcd_count;   // > 1: the blocks an XCD receives (linear workgroup id mod xcd_count) take CONSECUTIVE chunks of the source
   int xcd_stripe;  // ... per stripe of xcd_count * xcd_stripe blocks (0: the whole row is one stripe); see xcd_chunk()
   int compute_units;  // host side only: compute units of the handle's device (block shapes, XCD count)
+  int own_units;      // host side only: 1 = the handle has its device to itself (no multi-rank reducer): one block per compute unit
   int safe_sum;    // 1: the final sum is made by the block that draws the LAST TICKET (no block waits for rows of blocks that
                    // may not be resident): the re-evaluation after a lost row
   unsigned int item_owner;  // k_derivatives: 2 bits per wave of a block -- the SIMD whose finishing wave expands that wave's points

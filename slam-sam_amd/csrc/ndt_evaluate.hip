@@ -75,6 +75,9 @@ EvalConsts make_eval_consts(const ndt_handle* h, bool need_h) {
   ec.mbox_tagged = h->mbox_tagged ? 1 : 0;
   ec.mbox_preload = h->mbox_preload ? 1 : 0;
   ec.compute_units = h->n_cus;   // block shapes and the XCD count are those of THIS handle's device (CPX partitions: 32)
+  // (a rank of a multi-rank job may share its device with the other ranks -- the one-device rehearsals do --, and blocks
+  // that insist on a compute unit of their own would keep a peer's blocks, which this rank's kernel may be waiting for, out)
+  ec.own_units = h->red.mode() == NDT_REDUCE_NONE ? 1 : 0;
   ec.item_salt = process_item_salt();
   return ec;
 }

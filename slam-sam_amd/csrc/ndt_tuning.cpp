@@ -31,6 +31,7 @@ void tuning_defaults(ndt_tuning* t) {
   t->timing_bracket = 0;
   t->handoff_chunk_pass = 0;
   t->deriv_summer_split = 1;
+  t->deriv_one_block_per_cu = 1;
 }
 
 namespace {
@@ -49,7 +50,7 @@ bool valid(const ndt_tuning& t) {
   if (t.build_events < -1 || t.build_events > 1) return false;
   if (!flag(t.build_wait_sync) || !flag(t.mbox_tagged) || !flag(t.mbox_preload)) return false;
   if (t.prelaunch_streams != 1 && t.prelaunch_streams != 2) return false;
-  if (!flag(t.prelaunch_probe) || !flag(t.speculate_first) || !flag(t.timing_bracket) || !flag(t.handoff_chunk_pass)) return false;
+  if (!flag(t.prelaunch_probe) || !flag(t.speculate_first) || !flag(t.timing_bracket) || !flag(t.handoff_chunk_pass) || !flag(t.deriv_one_block_per_cu)) return false;
   if (t.deriv_summer_split != 0 && t.deriv_summer_split != 1 && t.deriv_summer_split != 4 && t.deriv_summer_split != 8) return false;
   for (int v : t.reserved)
     if (v != 0) return false;
@@ -93,6 +94,7 @@ void init_once() {
     env("NDT_TIMING_BRACKET", &t.timing_bracket);
     env("NDT_HANDOFF_CHUNK_PASS", &t.handoff_chunk_pass);
     env("NDT_DERIV_SUMMER_SPLIT", &t.deriv_summer_split);
+    env("NDT_DERIV_ONE_BLOCK_PER_CU", &t.deriv_one_block_per_cu);
     if (valid(t)) g_tuning = t;
 #endif
   });

@@ -36,4 +36,12 @@ for rep in range(4):
     names = ["(entry)", "xyz loaded", "pairs done", "expanded", "row stored"]
     for k in range(1, 5):
         print("  %-12s  min %6.2f  median %6.2f  max %6.2f   (us after the first block saw the pose)" % (names[k], rel[comp, k].min(), np.median(rel[comp, k]), rel[comp, k].max()))
+    rs = rel[comp, 4]
+    print("  row stored percentiles: p50 %.2f  p75 %.2f  p90 %.2f  p95 %.2f  p99 %.2f  max %.2f" % tuple(np.percentile(rs, [50, 75, 90, 95, 99, 100])))
+    hw = raw[nb * 8:nb * 9].view(np.uint32).reshape(nb, 2)
+    order = np.argsort(-rs)[:12]
+    # HW_ID (gfx9): wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13 (se 2 bits on some parts)
+    print("  slowest blocks (block: row stored, pairs done | XCC, SE, SH, CU): " +
+          "  ".join("%d: %.1f %.1f | %d %d %d %d" % (b + comp.start, rs[b], rel[comp, 2][b], hw[b + comp.start, 1] & 0xf, (hw[b + comp.start, 0] >> 13) & 7,
+                                                     (hw[b + comp.start, 0] >> 12) & 1, (hw[b + comp.start, 0] >> 8) & 15) for b in order))
     print("  block 0 (%s): polling since %.2f, rows summed %.2f, result stored %.2f" % ("summing only" if ded else "computes too", rel[0, 5], rel[0, 6], rel[0, 7]))
