@@ -1024,7 +1024,8 @@ __device__ __forceinline__ void block_reduce_finish(double (*lds_w)[EV_WORDS] /*
                                                     int single_level_max, bool fixed_summer,
                                                     const XchgInfo* __restrict__ xi, unsigned long long xround,
                                                     int my_row /* this block's row */, int nb /* rows = computing blocks */,
-                                                    bool dedicated /* a block without points adds the rows */, int mute_row = 0) {
+                                                    bool dedicated /* a block without points adds the rows */, int mute_row = 0,
+                                                    bool split_words = false /* rows 0 .. 3's blocks add eight words each */) {
   // (the summing stage's scratch lies over the waves' regions: every wave is past the barrier below by then)
   extern __shared__ int lds_dyn[];
   double (*lds_c)[EV_WORDS] = reinterpret_cast<double (*)[EV_WORDS]>(lds_dyn);
@@ -1072,6 +1073,18 @@ __device__ __forceinline__ void block_reduce_finish(double (*lds_w)[EV_WORDS] /*
     // the tags; every other block is done once its row store is issued.  Takes the ticket's
     // atomic round trip out of the launch's critical path.  Block 0 depends on the others, never
     // the other way round, so a grid larger than the machine cannot dead-lock on it.
+    if (split_words) {
+      // (round 5) ... or the blocks of rows 0 .. SUMMER_SPLIT - 1, eight words -- one 128-byte line of every row -- each: a
+      // grid whose point blocks fill the machine (the 128 x 1024 scan) has no unit for dedicated summing blocks, and one block
+      // polling 1024 lines per trip behind its own points was the evaluation's tail.  Same columns, order and tree per word.
+      if (my_row >= SUMMER_SPLIT) return;
+      NDT_STAMP(5);
+      sum_rows<3>(rrows, 0u, 0, nrows, seq, lds_c, slots_rsrc(host_slots), 0u, true, host_slots ? nullptr : out, &s_fail, nullptr, 0ull,
+                  (EV_WORDS / SUMMER_SPLIT) * my_row);
+      NDT_STAMP(6);
+      NDT_STAMP(7);
+      return;
+    }
     if (my_row != 0) return;
     NDT_STAMP(5);
   } else {
@@ -1291,7 +1304,12 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
       // quit: nothing to do.  timed out: say so in the result slots (word 31 = 2), the host
       // evaluates this pose through an ordinary launch instead
       if (go < 0 && flag != nullptr) {
-        if (ec.dedicated_summer <= 1) {
+        if (ec.doubling_split) {   // the blocks of rows 0 .. 3 add eight words each: each says so in its own slots (see below)
+          if (chunk < SUMMER_SPLIT && (int)threadIdx.x < EV_WORDS / SUMMER_SPLIT) {
+            const unsigned int w = (unsigned int)((EV_WORDS / SUMMER_SPLIT) * chunk) + threadIdx.x;
+            store_slot(slots_rsrc(flag), w * 16u, seq, w == (unsigned int)EV_FAIL ? 2.0 : __longlong_as_double(0x7ff8000000000000ll), true);
+          }
+        } else if (ec.dedicated_summer <= 1) {
           if (blockIdx.x == 0 && threadIdx.x < EV_WORDS)
             store_slot(slots_rsrc(flag), threadIdx.x * 16u, seq, threadIdx.x == EV_FAIL ? 2.0 : 0.0, true);
         } else if (summing_block && (int)threadIdx.x < EV_WORDS / ec.dedicated_summer) {
@@ -1450,7 +1468,7 @@ k_derivatives(const float* __restrict__ sx, const float* __restrict__ sy, const 
                       flag ? flag + (size_t)blockIdx.y * ROW_WORDS : nullptr,  // pose y's 32 host slots
                       seq, ec.single_level_max,
                       ec.fixed_summer != 0, BATCH ? nullptr : xinfo, xround, chunk,
-                      (int)gridDim.x - ec.dedicated_summer, ec.dedicated_summer != 0, ec.mute_row);
+                      (int)gridDim.x - ec.dedicated_summer, ec.dedicated_summer != 0, ec.mute_row, !BATCH && ec.doubling_split != 0);
 }
 
 __global__ void __launch_bounds__(256) k_transform(const float* __restrict__ sx, const float* __restrict__ sy,
@@ -1641,6 +1659,7 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
     blocks -= ecl.dedicated_summer - 1;
     ecl.dedicated_summer = 1;
   }
+  ecl.doubling_split = 0;
   if (ec.safe_sum) {
     // Same rows in the same order, added by the block that draws the last ticket: by then every row has been issued,
     // so nothing in the launch waits for a block that is not resident (a device shared with other processes).
@@ -1658,6 +1677,10 @@ void launch_derivatives(const float* sx, const float* sy, const float* sz, size_
   const int xcd_mode = tuning().deriv_xcd;
   const int nxcd = std::max(1, cus / 32);
   const int point_blocks = blocks - ecl.dedicated_summer;
+  // no unit to spare for summing blocks (the 128 x 1024 scan): the blocks of rows 0 .. 3 add eight words each
+  if (!d_poses && d_xinfo == nullptr && !ec.safe_sum && ecl.dedicated_summer == 0 && ecl.fixed_summer != 0 && tuning().deriv_summer_split != 0 &&
+      point_blocks >= SUMMER_SPLIT && point_blocks <= ecl.single_level_max)
+    ecl.doubling_split = 1;
   const int per_cu = std::max(1, 1024 / threads);
   const bool resident = blocks <= cus * per_cu + 1 && !d_poses;
   ecl.xcd_count = 0;

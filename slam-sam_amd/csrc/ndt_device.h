@@ -125,6 +125,7 @@ struct EvalConsts {
   int fixed_summer;  // 1: block 0 adds the partial rows (polls their tags), no tickets (single-level grids)
   int dedicated_summer;  // n > 0: blocks 0 .. n - 1 of the grid own no points: they only add the rows -- 1 (all 32 words), or
                          // SUMMER_SPLIT (eight words = one 128-byte line of every row each; single-pose launches)
+  int doubling_split;    // 1: no dedicated summing block, and the blocks of rows 0 .. SUMMER_SPLIT - 1 add eight words each behind their own points
   int mbox_tagged;  // pre-launched kernels: 1 = the pose arrives as tagged 8-byte granules, 0 = words then sequence number
   int mbox_preload; // pre-launched kernels: 1 = the point is fetched before the wait for the pose
   int multigrid;   // 1: the table is a union of grids (radius search, leaves of a cell chained through VoxelRecord::pad)

@@ -1,6 +1,7 @@
 """Stress of the pose hand-over to pre-launched kernels under host CPU contention (debugging aid, not
 collected by pytest): a background thread keeps the BLAS worker threads busy while the main thread
-aligns; every failure is reported with the engine's counters.  Usage: gpu_mbox_stress.py [aligns]"""
+aligns; every failure is reported with the engine's counters.  Usage: mbox_stress.py [aligns [source points]]
+(131072 source points = the launch shape of C2 / C5: 256 point blocks, no dedicated summing block)"""
 import os, sys, time, threading
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,6 +9,8 @@ import __graft_entry__ as ge
 pkg = ge.load_package(); S = pkg.synth
 cfg = S.config_c3()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+if len(sys.argv) > 2:
+    cfg["source"] = cfg["source"][:int(sys.argv[2])]
 ndt = pkg.NormalDistributionsTransform(device_id=0, resolution=0.5, step_size=0.1, trans_epsilon=1e-4, max_iterations=35)
 ndt.setInputTarget(cfg["target"]); ndt.setInputSource(cfg["source"])
 g = pkg.ColMajor4f(cfg["guess"])
