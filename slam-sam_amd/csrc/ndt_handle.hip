@@ -402,6 +402,20 @@ int ndt_debug_item_owners(int threads, unsigned int* owners, unsigned int* fin_w
   return NDT_OK;
 }
 
+// test seam (not in the public header): the shape of a k_derivatives launch over n_src points and K poses on a device of `cus`
+// compute units -- {threads per block, blocks that own points, summing blocks in front of them, blocks of the grid (per pose)}
+int ndt_debug_launch_shape(size_t n_src, int K, int cus, int out[4]) {
+  if (!out || K < 1 || cus < 1) return NDT_ERR_INVALID_ARG;
+  const int threads = derivs_block_threads(n_src, K, cus);
+  const int grid = derivs_grid_blocks(n_src, K, cus);
+  const int pb = (int)std::max<size_t>(1, (n_src + (size_t)threads - 1) / (size_t)threads);
+  out[0] = threads;
+  out[1] = pb;
+  out[2] = grid - pb;
+  out[3] = grid;
+  return NDT_OK;
+}
+
 // test seam (not in the public header): the two-launch build's partition plan for a cloud of n points --
 // {fits (0 / 1), points per tile, tiles, words of the column table}
 int ndt_debug_bucket_plan(size_t n, long long out[4]) {

@@ -405,3 +405,40 @@ def test_two_launch_build_partition_plan(pkg):
             assert plan(n)[1] == want, (forced, n, plan(n))
     finally:
         pkg.set_tuning(**before)
+
+
+def test_derivative_launch_shapes(pkg):
+    """Host logic behind k_derivatives' launches (the partition of the scan decides the last bits of the sums, so it is
+    pinned here): one source point per thread; single-pose scans of 131 k - 262 k points take one block per compute unit
+    (one unit left to the summing side); FOUR summing blocks stand in front of the point blocks where the machine has
+    the units (round 5), one where only one is spare, none where the point blocks fill it (the 128 x 1024 scan: rows
+    0 .. 3's blocks share the final sum); batched launches keep one per pose.  No device needed."""
+    L = pkg.lib()
+    L.ndt_debug_launch_shape.argtypes = [C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_int)]
+
+    def shape(n, K=1, cus=256):
+        out = (C.c_int * 4)()
+        assert L.ndt_debug_launch_shape(n, K, cus, out) == 0
+        return tuple(out)
+
+    assert shape(200000) == (832, 241, 4, 245)            # C3
+    assert shape(131072) == (512, 256, 0, 256)            # C2 / C5: the point blocks fill the machine
+    assert shape(131072, K=20) == (512, 256, 1, 257)      # SVN Stage 1: one summing block per pose
+    assert shape(130000) == (512, 254, 1, 255)            # one unit spare: one summing block
+    assert shape(25000) == (256, 98, 4, 102)              # a rank's share of the scan
+    assert shape(1000) == (256, 4, 4, 8)
+    assert shape(1000000) == (512, 1954, 1, 1955)          # several residency rounds: one block adds the rows directly (<= 2048 of them)
+    assert shape(1200000) == (512, 2344, 0, 2344)          # ... beyond that the two-level sum, no dedicated block
+    for n in (1, 63, 64, 65, 5000, 99999, 131071, 131073, 200001, 262144, 262145, 400000):
+        t, pb, ns, grid = shape(n)
+        assert t % 64 == 0 and 64 <= t <= 1024 and pb == max(1, -(-n // t)) and grid == pb + ns and ns in (0, 1, 4)
+        if ns == 4:
+            assert pb + 4 <= 256
+    before = pkg.get_tuning()
+    try:
+        pkg.set_tuning(deriv_summer_split=0)
+        assert shape(200000) == (832, 241, 1, 242) and shape(131072) == (512, 256, 0, 256)
+        pkg.set_tuning(deriv_summer_split=8)
+        assert shape(200000) == (832, 241, 8, 249)
+    finally:
+        pkg.set_tuning(**before)
