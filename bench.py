@@ -36,6 +36,7 @@ for _v in ("OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "BLIS_NUM_THREADS"):
     os.environ.setdefault(_v, "1")
 # A rank that stops answering inside an all-reduce is a failed reduce variant here, not something to sit out
 os.environ.setdefault("NDT_COMM_TIMEOUT_S", "20")
+import gc
 import hashlib
 import struct
 import sys
@@ -286,6 +287,10 @@ def main():
             failed = e
         fence()
         pre0 = ndt.prelaunchCounters()
+        # (the K steps are ~14 ms in all: one cyclic garbage collection of the interpreter inside them -- the process holds the
+        # synthetic clouds and every earlier leg's results -- would be a tenth of that; collected here, switched off until the fence)
+        gc.collect()
+        gc.disable()
         t0 = time.perf_counter()
         iters = evals = reused = 0
         t_build = t_align = 0.0
@@ -303,6 +308,7 @@ def main():
             failed = e
         fence()
         elapsed = time.perf_counter() - t0
+        gc.enable()
         if failed is not None:
             print("rank %d: engine error inside the timed region (%s)" % (rank, failed), file=sys.stderr, flush=True)
             elapsed = float("inf")
